@@ -1,0 +1,405 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own CPU bodies.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Runs only in the authoring container
+(needs /root/reference); the GPU box only ever sees the committed .npz files.
+
+    python oracle/make_golden.py            # rewrites tests/golden/
+
+How the reference is imported: torchvision / lmdb / tensorboard / sklearn-free
+stubs are placed in sys.modules, torch.utils.cpp_extension.load is neutralised (the CPU path of
+upfirdn2d / fused_leaky_relu never touches the JIT-built CUDA module), and Tensor.cuda is the
+identity (FlowHead.__init__ calls .cuda(), warping_heads.py:158).  Nothing is written to
+/root/reference.
+"""
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get('GANGEALING_REFERENCE', '/root/reference')
+OUT = os.path.join(REPO, 'tests', 'golden')
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+from oracle.det_weights import det_array, det_state_dict  # noqa: E402
+
+
+class _Stub(types.ModuleType):
+    """Module stub whose every attribute is a do-nothing callable/class."""
+
+    def __getattr__(self, item):
+        if item.startswith('__'):
+            raise AttributeError(item)
+        return type(item, (), {'__init__': lambda self, *a, **k: None, '__call__': lambda self, *a, **k: None})
+
+
+def import_reference():
+    for name in ['torchvision', 'torchvision.models', 'torchvision.datasets', 'torchvision.datasets.utils',
+                 'torchvision.transforms', 'torchvision.utils', 'lmdb', 'tensorboard',
+                 'torch.utils.tensorboard', 'moviepy', 'moviepy.editor', 'ray', 'termcolor', 'cv2', 'lpips']:
+        if name not in sys.modules:
+            m = _Stub(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    sys.modules['torchvision'].models = sys.modules['torchvision.models']
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    sys.modules['torchvision'].utils = sys.modules['torchvision.utils']
+    sys.modules['torch.utils.tensorboard'].SummaryWriter = object
+    sys.modules['torchvision.datasets.utils'].download_url = lambda *a, **k: None
+    import torch.utils.cpp_extension as cpp
+    cpp.load = lambda *a, **k: types.SimpleNamespace()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+    import models  # noqa: F401  (reference package)
+    return models
+
+
+def save(name, cases):
+    flat = {}
+    for ci, case in enumerate(cases):
+        for k, v in case.items():
+            if isinstance(v, (dict, list, tuple, str, int, float, bool)) and not isinstance(v, np.ndarray):
+                v = np.frombuffer(json.dumps(v).encode(), dtype=np.uint8)
+            elif isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            flat[f'case{ci:02d}/{k}'] = v
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **flat)
+    print(f'{name}: {len(cases)} cases, {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def rnd(name, shape, scale=1.0, dtype=np.float32):
+    return torch.from_numpy(det_array(name, shape, scale, dtype))
+
+
+# ---------------------------------------------------------------------------------------------
+
+def gen_upfirdn2d():
+    from models.stylegan2.op.upfirdn2d import upfirdn2d_native
+    from models.stylegan2.networks import make_kernel
+    k1331 = make_kernel([1, 3, 3, 1])
+    specs = [
+        # (N,C,H,W), kernel, up, down, (pad_x0,pad_x1,pad_y0,pad_y1), tag
+        ((2, 3, 9, 9), k1331 * 4, 1, 1, (1, 1, 1, 1), 'G blur after up-conv 9->8'),
+        ((2, 2, 17, 17), k1331 * 4, 1, 1, (1, 1, 1, 1), 'G blur 17->16'),
+        ((1, 2, 33, 33), k1331 * 4, 1, 1, (1, 1, 1, 1), 'G blur 33->32'),
+        ((2, 3, 4, 4), k1331 * 4, 2, 1, (2, 1, 2, 1), 'ToRGB skip upsample 4->8'),
+        ((1, 3, 16, 16), k1331 * 4, 2, 1, (2, 1, 2, 1), 'ToRGB skip upsample 16->32'),
+        ((2, 2, 16, 16), k1331, 1, 1, (2, 2, 2, 2), 'STN blur before 3x3 s2 16->17'),
+        ((2, 2, 16, 16), k1331, 1, 1, (1, 1, 1, 1), 'STN blur before 1x1 s2 16->15'),
+        ((1, 2, 8, 8), k1331, 1, 2, (1, 1, 1, 1), 'Downsample (bwd of upsample) 8->4'),
+        ((1, 2, 67, 70), k1331, 1, 1, (2, 2, 2, 2), 'multi-tile non-square'),
+        ((1, 1, 5, 7), torch.from_numpy(det_array('k34', (3, 4))), 1, 1, (2, 1, 1, 2), 'asymmetric 3x4 taps'),
+        ((1, 2, 6, 6), k1331, 2, 2, (2, 1, 2, 1), 'up=down=2'),
+        ((1, 1, 9, 9), k1331, 1, 1, (-1, 0, 0, -2), 'negative pad (crop)'),
+        ((2, 1, 1, 1), k1331 * 4, 2, 1, (2, 1, 2, 1), '1x1 input'),
+        ((1, 1, 6, 6), torch.from_numpy(det_array('k55', (5, 5))), 3, 2, (3, 2, 3, 2), 'generic 5x5 up3 down2'),
+        ((1, 1, 8, 8), torch.from_numpy(det_array('k22', (2, 2))), 1, 2, (0, 0, 0, 0), '2x2 down2 (mode 6)'),
+    ]
+    cases = []
+    for i, (shape, k, up, down, pad, tag) in enumerate(specs):
+        x = rnd(f'upfirdn.x{i}', shape).requires_grad_(True)
+        out = upfirdn2d_native(x, k, up, up, down, down, *pad)
+        g = rnd(f'upfirdn.g{i}', out.shape)
+        (gx,) = torch.autograd.grad(out, x, g)
+        cases.append(dict(x=x, k=k, out=out, g=g, gx=gx,
+                          meta=dict(up=up, down=down, pad=list(pad), tag=tag)))
+    save('upfirdn2d', cases)
+
+
+def gen_fused_act():
+    from models.stylegan2.op.fused_act import fused_leaky_relu
+    cases = []
+    for i, shape in enumerate([(4, 8), (2, 6, 5, 5), (3, 16, 8, 8), (1, 4, 3, 7), (2, 5, 1, 1)]):
+        x = rnd(f'fused.x{i}', shape).requires_grad_(True)
+        b = rnd(f'fused.b{i}', (shape[1],), 0.5).requires_grad_(True)
+        if i == 1:  # plant exact zeros of x+b and of x
+            with torch.no_grad():
+                x[0, 0, 0, 0] = -b[0]
+                x[0, 1, 0, 0] = 0.0
+        out = fused_leaky_relu(x, b)          # CPU branch, fused_act.py:87-94 (slope hard-coded 0.2)
+        g = rnd(f'fused.g{i}', shape)
+        gx, gb = torch.autograd.grad(out, (x, b), g)
+        cases.append(dict(x=x, b=b, out=out, g=g, gx=gx, gb=gb, meta=dict(negative_slope=0.2, scale=2 ** 0.5)))
+    save('fused_act', cases)
+
+
+def make_grids(n, r):
+    """A family of sampling grids (N,r,r,2) exercising identity / zoom / rotation / smooth flow."""
+    def aff(theta):
+        return F.affine_grid(torch.tensor(theta, dtype=torch.float32).view(1, 2, 3).repeat(n, 1, 1),
+                             (n, 3, r, r), align_corners=False)
+    c, s = math.cos(0.6), math.sin(0.6)
+    smooth = aff([[1, 0, 0], [0, 1, 0]])
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, r), torch.linspace(-1, 1, r), indexing='ij')
+    smooth = smooth + 0.35 * torch.stack([torch.sin(3 * yy + 1) * xx, torch.cos(2 * xx) * yy], -1)[None]
+    return {
+        'identity': aff([[1, 0, 0], [0, 1, 0]]),
+        'zoom_in_0.5': aff([[0.5, 0, 0.1], [0, 0.5, -0.2]]),
+        'zoom_out_2': aff([[2, 0, 0], [0, 2, 0]]),
+        'zoom_out_4': aff([[4, 0, 0.3], [0, 4, 0]]),
+        'zoom_out_6_rot': aff([[6 * c, -6 * s, 0], [6 * s, 6 * c, 0]]),
+        'rot_shift': aff([[1.3 * c, -1.3 * s, 0.4], [1.3 * s, 1.3 * c, -0.3]]),
+        'smooth_flow': smooth,
+        'jitter': aff([[1, 0, 0], [0, 1, 0]]) + rnd('jitter', (n, r, r, 2), 0.01),
+    }
+
+
+def gen_mipmap_warp():
+    from models.spatial_transformers.antialiased_sampling import MipmapWarp
+    cases = []
+    ci = 0
+    for (s, r, modes, names) in [
+        (32, 16, ['border', 'reflection', 'zeros'], None),
+        (64, 32, ['reflection'], ['zoom_out_4', 'smooth_flow', 'jitter']),
+        (30, 16, ['border'], ['zoom_out_2', 'rot_shift']),          # non power of two -> pad path
+        (16, 16, ['reflection'], ['identity', 'zoom_out_6_rot']),
+    ]:
+        grids = make_grids(2, r)
+        for name, grid in grids.items():
+            if names is not None and name not in names:
+                continue
+            for mode in modes:
+                x = rnd(f'mip.x{ci}', (2, 3, s, s)).requires_grad_(True)
+                grid_l = grid.clone().requires_grad_(True)
+                warp = MipmapWarp(max_num_levels=3.5)
+                out = warp(x, grid_l, padding_mode=mode)
+                g = rnd(f'mip.g{ci}', out.shape)
+                gx, ggrid = torch.autograd.grad(out, (x, grid_l), g)
+                cases.append(dict(x=x, grid=grid_l, out=out, g=g, gx=gx, ggrid=ggrid,
+                                  levels_map=warp.levels_map,
+                                  meta=dict(padding_mode=mode, grid=name, max_num_levels=3.5)))
+                ci += 1
+    save('mipmap_warp', cases)
+    # plain (non anti-aliased) Warp == F.grid_sample, all padding modes
+    cases = []
+    for ci, mode in enumerate(['border', 'reflection', 'zeros']):
+        grids = make_grids(1, 12)
+        for name in ['zoom_out_2', 'rot_shift', 'smooth_flow']:
+            x = rnd(f'gs.x{ci}{name}', (1, 2, 10, 14))
+            out = F.grid_sample(x, grids[name], padding_mode=mode, align_corners=False)
+            cases.append(dict(x=x, grid=grids[name], out=out, meta=dict(padding_mode=mode, grid=name)))
+    save('grid_sample', cases)
+
+
+def gen_heads():
+    from models.spatial_transformers.warping_heads import SimilarityHead, FlowHead, apply_affine
+    cases = []
+    # similarity: params -> matrix -> composed with base -> affine_grid
+    head = SimilarityHead(8)
+    params = rnd('sim.params', (3, 4), 0.5).requires_grad_(True)
+    matrix = head.make_affine_matrix(*torch.split(params, 1, dim=1))          # (N,1,2,3)
+    base = rnd('sim.base', (3, 1, 2, 3), 0.7)
+    composed = base @ head.make_3x3(matrix)
+    grid = F.affine_grid(composed.reshape(3, 2, 3), (3, 3, 16, 16), align_corners=False)
+    g = rnd('sim.g', grid.shape)
+    (gparams,) = torch.autograd.grad(grid, params, g)
+    cases.append(dict(params=params, matrix=matrix.reshape(3, 2, 3), base=base.reshape(3, 2, 3),
+                      composed=composed.reshape(3, 2, 3), grid=grid, g=g, gparams=gparams, meta=dict(kind='similarity')))
+    save('similarity_head', cases)
+
+    cases = []
+    for ci, (n, h) in enumerate([(2, 4), (1, 16)]):
+        fh = FlowHead((1, 8, h, h))
+        low = rnd(f'flow.low{ci}', (n, h, h, 2), 0.05).requires_grad_(True)
+        mask = rnd(f'flow.mask{ci}', (n, 9 * 64, h, h), 1.0).requires_grad_(True)
+        base = rnd(f'flow.base{ci}', (n, 2, 3), 0.6).requires_grad_(True)
+        delta = fh.upsample_flow(low, mask)
+        flow = fh.identity_flow + delta
+        flow = apply_affine(base, flow)
+        g1 = rnd(f'flow.g1{ci}', flow.shape)
+        g2 = rnd(f'flow.g2{ci}', delta.shape)
+        glow, gmask, gbase = torch.autograd.grad([flow, delta], (low, mask, base), [g1, g2])
+        res = flow.size(1)
+        resized = F.interpolate(flow.permute(0, 3, 1, 2), scale_factor=2 * res / flow.size(2),
+                                mode='bilinear').permute(0, 2, 3, 1)
+        cases.append(dict(low=low, mask=mask, base=base, delta=delta, flow=flow, identity=fh.identity_flow,
+                          g_flow=g1, g_delta=g2, glow=glow, gmask=gmask, gbase=gbase, resized2x=resized,
+                          meta=dict(kind='flow', ds=8)))
+    save('flow_head', cases)
+
+
+def gen_misc():
+    from models.spatial_transformers.antialiased_sampling import BilinearDownsample
+    from models.losses.loss import total_variation_loss, flow_identity_loss
+    cases = []
+    for ci, (stride, s) in enumerate([(2, 16), (4, 32), (2, 64)]):
+        x = rnd(f'bd.x{ci}', (2, 3, s, s)).requires_grad_(True)
+        out = BilinearDownsample(stride, 3)(x)
+        g = rnd(f'bd.g{ci}', out.shape)
+        (gx,) = torch.autograd.grad(out, x, g)
+        cases.append(dict(x=x, out=out, g=g, gx=gx, meta=dict(stride=stride)))
+    save('bilinear_downsample', cases)
+    cases = []
+    for ci, scale in enumerate([0.3, 3.0]):
+        d = rnd(f'tv.d{ci}', (2, 16, 16, 2), scale).requires_grad_(True)
+        tv = total_variation_loss(d)
+        idl = flow_identity_loss(d)
+        (gd,) = torch.autograd.grad(1000.0 * tv + idl, d)
+        cases.append(dict(delta=d, tv=tv, identity=idl, gdelta=gd, meta=dict(tv_weight=1000.0, id_weight=1.0)))
+    save('flow_losses', cases)
+
+
+def gen_modconv():
+    from models.stylegan2.networks import ModulatedConv2d, StyledConv, ToRGB
+    cases = []
+    for ci, (cin, cout, k, up, demod, n, h) in enumerate([
+        (8, 6, 3, False, True, 2, 8),
+        (8, 6, 3, True, True, 2, 4),
+        (6, 3, 1, False, False, 2, 8),
+        (16, 16, 3, False, True, 3, 5),
+    ]):
+        m = ModulatedConv2d(cin, cout, k, 12, demodulate=demod, upsample=up)
+        m.load_state_dict(det_state_dict(m), strict=False)
+        x = rnd(f'mc.x{ci}', (n, cin, h, h)).requires_grad_(True)
+        w = rnd(f'mc.w{ci}', (n, 12)).requires_grad_(True)
+        out = m(x, w)
+        g = rnd(f'mc.g{ci}', out.shape)
+        gx, gw = torch.autograd.grad(out, (x, w), g)
+        style = m.modulation(w)
+        cases.append(dict(x=x, w=w, out=out, g=g, gx=gx, gw=gw, style=style,
+                          weight=m.weight[0], mod_weight=m.modulation.weight, mod_bias=m.modulation.bias,
+                          meta=dict(cin=cin, cout=cout, k=k, upsample=up, demodulate=demod)))
+    save('modulated_conv', cases)
+
+
+def gen_generator():
+    from models.stylegan2.networks import Generator
+    g = Generator(16, 512, 8)
+    g.load_state_dict(det_state_dict(g), strict=False)
+    g.eval()
+    z = rnd('gen.z', (2, 512))
+    noise = [rnd(f'gen.noise{i}', (2, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2))) for i in range(g.num_layers)]
+    img, latent = g([z], return_latents=True, noise=noise)
+    w = latent[:, 0].detach().clone().requires_grad_(True)
+    latent2 = w.unsqueeze(1).repeat(1, g.n_latent, 1)
+    img2, _ = g([latent2], input_is_latent=True, noise=noise)
+    gimg = rnd('gen.gimg', img2.shape)
+    (gw,) = torch.autograd.grad(img2, w, gimg)
+    save('generator16', [dict(z=z, img=img, w=latent[:, 0], gimg=gimg, gw=gw, img_from_w=img2,
+                              **{f'noise{i}': t for i, t in enumerate(noise)},
+                              meta=dict(size=16, style_dim=512, n_mlp=8, num_layers=g.num_layers))])
+
+
+def gen_stn():
+    from models.spatial_transformers.spatial_transformer import get_stn
+    from models.losses.loss import total_variation_loss, flow_identity_loss
+    rules = (('warp_head.linear', 0.02), ('flow_out.2', 0.02), ('mask_out', 0.5))
+    cases = []
+    for ci, (transforms, flow_size, supersize, mode) in enumerate([
+        (['similarity'], 32, 32, 'border'),
+        (['similarity', 'flow'], 64, 128, 'reflection'),
+    ]):
+        stn = get_stn(transforms, flow_size=flow_size, supersize=supersize, channel_multiplier=0.5, num_heads=1)
+        sd = det_state_dict(stn, rules)
+        torch.nn.Module.load_state_dict(stn, sd, strict=False)
+        x = rnd(f'stn.x{ci}', (2, 3, supersize, supersize), 0.5)
+        kwargs = dict(return_flow=True, padding_mode=mode)
+        if supersize > flow_size:
+            kwargs['input_img_for_sampling'] = x
+        out, flow_or_m = stn(x, **kwargs)
+        loss = (out ** 2).mean()
+        if 'flow' in transforms:
+            loss = loss + 10.0 * total_variation_loss(flow_or_m) + flow_identity_loss(flow_or_m)
+        names = [n for n, _ in stn.named_parameters()]
+        grads = torch.autograd.grad(loss, list(stn.parameters()), allow_unused=True)
+        gnorm = {n: (float(g.double().norm()) if g is not None else None) for n, g in zip(names, grads)}
+        keep = {n.replace('.', '_'): g for n, g in zip(names, grads)
+                if g is not None and g.numel() <= 4096 and ('warp_head' in n or 'bias' in n)}
+        cases.append(dict(x=x, out=out, flow_or_matrix=flow_or_m, loss=loss,
+                          meta=dict(transforms=transforms, flow_size=flow_size, supersize=supersize,
+                                    padding_mode=mode, scale_rules=[list(r) for r in rules], grad_norms=gnorm),
+                          **{'grad_' + k: v for k, v in keep.items()}))
+    save('stn', cases)
+
+
+def gen_train_step():
+    """One gangealing_loss evaluation (loss.py:64-75) at a plumbing-sized config with an MSE
+    stand-in for the VGG loss (torchvision is not installed).  RNG-dependent inputs (z, per-layer
+    noise) are made deterministic by patching randn / normal_ draws through explicit arguments."""
+    from models.stylegan2.networks import Generator
+    from models.spatial_transformers.spatial_transformer import get_stn
+    from models.latent_learner import DirectionInterpolator
+    from models.spatial_transformers.antialiased_sampling import BilinearDownsample
+    from models.losses.loss import total_variation_loss, flow_identity_loss
+    gen = Generator(64, 512, 8)
+    gen.load_state_dict(det_state_dict(gen), strict=False)
+    gen.eval()
+    rules = (('warp_head.linear', 0.02), ('flow_out.2', 0.02), ('mask_out', 0.5))
+    stn = get_stn(['similarity', 'flow'], flow_size=64, supersize=64, channel_multiplier=0.5, num_heads=1)
+    torch.nn.Module.load_state_dict(stn, det_state_dict(stn, rules), strict=False)
+    ll = DirectionInterpolator(None, 2, 3, gen.n_latent)
+    ll.directions.copy_(rnd('ll.directions', (2, 512)))
+    ll.lat_mean.copy_(rnd('ll.lat_mean', (1, 512)))
+    with torch.no_grad():
+        ll.coefficients.copy_(rnd('ll.coefficients', (1, 2), 0.3))
+    resize = torch.nn.Sequential()   # gen_size == flow_size (train.py:62)
+    psi = 0.5
+    z = rnd('ts.z', (2, 512))
+    noise1 = [rnd(f'ts.n1.{i}', (2, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2))) for i in range(gen.num_layers)]
+    noise2 = [rnd(f'ts.n2.{i}', (2, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2))) for i in range(gen.num_layers)]
+    # sample_gan_supervised_pairs, loss.py:21-29, with explicit noise
+    unaligned, w = gen([z], noise=noise1, return_latents=True)
+    w_aligned = ll([w[:, 0, :]], psi=psi)
+    target, _ = gen(w_aligned, input_is_latent=True, noise=noise2)
+    target = resize(target)
+    pred, delta = stn(resize(unaligned), return_flow=True, input_img_for_sampling=None, padding_mode='reflection')
+    ploss = ((pred - target) ** 2).mean(dim=(1, 2, 3)).mean()
+    tv = total_variation_loss(delta)
+    idl = flow_identity_loss(delta)
+    total = ploss + 1000.0 * tv + 1.0 * idl
+    params = list(stn.parameters()) + [ll.coefficients]
+    grads = torch.autograd.grad(total, params)
+    names = [n for n, _ in stn.named_parameters()] + ['ll.coefficients']
+    gnorm = {n: float(g.double().norm()) for n, g in zip(names, grads)}
+    save('train_step', [dict(z=z, unaligned=unaligned, target=target, pred=pred, delta=delta,
+                             ploss=ploss, tv=tv, identity=idl, total=total, g_coefficients=grads[-1],
+                             meta=dict(gen_size=64, flow_size=64, psi=psi, inject=3, ndirs=2, tv_weight=1000.0,
+                                       flow_identity_weight=1.0, padding_mode='reflection',
+                                       scale_rules=[list(r) for r in rules], grad_norms=gnorm))])
+
+
+def gen_splat_selfcheck():
+    """splat2d has no runnable reference here (no CPU path: functional.py:54-55; the CUDA source
+    does not build against torch>=1.11: splat_gpu.c:7).  The fixture stores inputs and the numpy
+    restatement's output so that the GPU test has a committed, hash-stable target; parity for
+    this op is pinned only to the restated source lines ("parity unpinned" - DESIGN.md)."""
+    from oracle import np_ops
+    cases = []
+    for ci, (n, c, h, w, p, sig, soft) in enumerate([
+        (2, 3, 16, 20, 17, 1.3, False), (1, 1, 12, 12, 1, 0.3, True), (2, 2, 24, 24, 200, 3.0, False),
+        (1, 3, 8, 8, 40, 1.2, True),
+    ]):
+        rs = np.random.RandomState(100 + ci)
+        coords = (rs.rand(n, p, 2) * [w + 4, h + 4] - 2).astype(np.float32)   # some out of bounds
+        coords[:, 0] = [0.0, 0.0]                                               # on the border
+        if p > 2:
+            coords[:, 1] = coords[:, 2]                                         # duplicates
+        values = rs.randn(n, p, c).astype(np.float32)
+        sigma = np.full((n,), sig, dtype=np.float32)
+        inp = np.zeros((n, c, h, w), dtype=np.float32) if ci != 3 else rs.randn(n, c, h, w).astype(np.float32)
+        out = np_ops.splat2d(inp, coords, values, sigma, soft)
+        cases.append(dict(input=inp, coords=coords, values=values, sigma=sigma, out=out,
+                          meta=dict(soft_normalize=soft, source='oracle-restatement')))
+    save('splat2d', cases)
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    import_reference()
+    only = sys.argv[1:]
+    gens = dict(upfirdn2d=gen_upfirdn2d, fused_act=gen_fused_act, mipmap_warp=gen_mipmap_warp, heads=gen_heads,
+                misc=gen_misc, modconv=gen_modconv, generator=gen_generator, stn=gen_stn,
+                train_step=gen_train_step, splat=gen_splat_selfcheck)
+    for name, fn in gens.items():
+        if only and name not in only:
+            continue
+        with torch.enable_grad():
+            fn()
