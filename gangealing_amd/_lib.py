@@ -1,0 +1,119 @@
+"""ctypes binding of libgangealing_hip.so (C ABI declared in include/gangealing_hip.h).
+
+The product path is HIP-only: if the library is missing or a tensor is not on a HIP device the
+call raises - there is no CPU fallback (the CPU restatement lives in oracle/ and is test-only).
+PyTorch is used purely as plumbing: device memory (tensor.data_ptr()), the current HIP stream
+(torch.cuda.current_stream().cuda_stream) and torch.distributed (RCCL).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libgangealing_hip.so')
+ABI_VERSION = 1
+
+# signature alphabet: p device pointer (tensor or None), i int, q long long, f float, d double, s stream
+_PROTOS = {
+    'gg_fused_bias_act_f32': 'ppppiiffqqis',
+    'gg_fused_bias_act_f64': 'ppppiiddqqis',
+    'gg_fused_lrelu_bwd_f32': 'ppppffiiqs',
+    'gg_fused_lrelu_bwd_f64': 'ppppddiiqs',
+    'gg_upfirdn2d_f32': 'pppiiiiiiiiiiiiis',
+    'gg_upfirdn2d_f64': 'pppiiiiiiiiiiiiis',
+    'gg_splat_forward_f32': 'pppppiiiiis',
+    'gg_splat2d_f32': 'ppppppiiiiiis',
+    'gg_mip_downsample2x_f32': 'ppiiis',
+    'gg_mip_downsample2x_bwd_f32': 'ppiiis',
+    'gg_mipmap_warp_fwd_f32': 'pppppppiiiiiiiiiffiis',
+    'gg_mipmap_warp_bwd_f32': 'pppppppppppiiiiiiiiiffiis',
+    'gg_affine_grid_f32': 'ppiiis',
+    'gg_affine_grid_bwd_f32': 'ppiiis',
+    'gg_flow_compose_fwd_f32': 'pppppiiiis',
+    'gg_flow_compose_bwd_f32': 'ppppppppiiiis',
+    'gg_flow_resize_f32': 'ppiiiiifs',
+    'gg_flow_resize_bwd_f32': 'ppiiiiifs',
+    'gg_bilinear_downsample_f32': 'ppiiiis',
+    'gg_bilinear_downsample_bwd_f32': 'ppiiiis',
+    'gg_flow_losses_f32': 'ppiiis',
+    'gg_flow_losses_bwd_f32': 'pppiiis',
+    'gg_conv_pack_weight_f32': 'ppiiiiiiifs',
+    'gg_conv2d_f32': 'ppppppiiiiiiiiiiiis',
+    'gg_conv2d_wgrad_f32': 'pppiiiiiiiiifs',
+    'gg_plane_dot_f32': 'pppiqs',
+    'gg_adam_ema_f32': 'pppppqffffiffs',
+}
+_CTYPE = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'q': ctypes.c_longlong, 'f': ctypes.c_float,
+          'd': ctypes.c_double, 's': ctypes.c_void_p}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return ['gg_abi_version', 'gg_last_error', 'gg_build_arch'] + sorted(_PROTOS)
+
+
+def load():
+    """Load the shared library (once).  Raises HipLibraryError if it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'(hipcc --offload-arch=gfx950).  gangealing_amd has no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.gg_abi_version.restype = ctypes.c_int
+    lib.gg_last_error.restype = ctypes.c_char_p
+    lib.gg_build_arch.restype = ctypes.c_char_p
+    if lib.gg_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f'ABI mismatch: library {lib.gg_abi_version()} != python {ABI_VERSION}; rebuild')
+    for name, proto in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [_CTYPE[c] for c in proto]
+    _lib = lib
+    return lib
+
+
+def _dev_ptr(t):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'expected a tensor or None, got {type(t)}')
+    if t.device.type != 'cuda':
+        raise HipLibraryError('gangealing_amd operators run on HIP devices only (got a %s tensor); '
+                              'the CPU restatement is test infrastructure under oracle/' % t.device.type)
+    if not t.is_contiguous():
+        raise HipLibraryError('internal error: non-contiguous tensor passed to the C ABI')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def call(name, *args):
+    """Invoke a C-ABI entry point on torch's current HIP stream; the trailing stream argument is
+    supplied here.  Tensors are passed as raw device pointers."""
+    lib = load()
+    proto = _PROTOS[name]
+    if len(args) != len(proto) - 1:
+        raise TypeError(f'{name}: expected {len(proto) - 1} arguments, got {len(args)}')
+    conv = []
+    for a, c in zip(args, proto):
+        if c == 'p':
+            conv.append(_dev_ptr(a))
+        elif c in 'iq':
+            conv.append(int(a))
+        else:
+            conv.append(float(a))
+    conv.append(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    rc = getattr(lib, name)(*conv)
+    if rc != 0:
+        raise HipLibraryError(f'{name} failed (code {rc}): {lib.gg_last_error().decode()}')
+
+
+def available():
+    return os.path.exists(LIB_PATH)

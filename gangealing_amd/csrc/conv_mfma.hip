@@ -1,0 +1,597 @@
+// a3/a4  convolutions as implicit GEMM on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+// GEMM orientation (chosen for NCHW stores on 64-wide waves):
+//     D[co, pix] = sum_k  Wm[k, co] * X[k, pix]        k = (ci, tap)
+//   MFMA "A" operand = weights   (lane l: co = l & 31, k = l >> 5)
+//   MFMA "B" operand = im2col'ed activations gathered on the fly (lane l: k = l >> 5, pix = l & 31)
+//   D: lane l owns pixel (l & 31) and 16 output channels -> for every accumulator register the 32
+//   lanes of a half-wave store 32 consecutive pixels of ONE channel plane = 128 B segments.
+// Both LDS tiles are [k][x] with x contiguous, so every ds_read_b32 of a fragment hits 32
+// consecutive banks (conflict free) and needs no swizzle.
+//
+// Block = 256 threads = 4 waves.  Two tilings:
+//   big   : 128 co x 128 pix, waves 2x2, each wave 2x2 MFMA tiles (64 accumulator VGPRs)
+//   narrow:  32 co x 256 pix, waves 1x4, each wave 1x2 MFMA tiles  (ToRGB / flow heads, Cout <= 32)
+// K is consumed in BK = 16 slabs, register-staged double buffering (global loads of slab t+1 are in
+// flight while slab t is multiplied; one __syncthreads per slab).  Small spatial layers (4^2..16^2)
+// do not produce 256 tiles, so K is split across blockIdx.y and partial sums are combined with
+// fp32 atomics (the epilogue is linear: out_scale * partial, bias added by split 0).
+//
+// The modulated convolution (networks.py:233-282) is run in its shared-weight form: the per-sample
+// style multiplies the activation while it is gathered (in_scale) and the demodulation multiplies
+// the accumulator in the epilogue (out_scale); no (N,Cout,Cin,3,3) weight tensor ever exists.
+//
+// Stride-2 transposed convolution (the generator's up-convs and the dgrad of the STN's strided
+// convs) is decomposed by output parity into 4 dense sub-problems (2x2, 2x1, 1x2, 1x1 taps), so no
+// MFMA work is spent on the zero-stuffed positions.
+#include "../../include/gangealing_hip.h"
+#include "gg_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+
+struct ConvArgs {
+  float* y;
+  const float* x;
+  const float* wmat;
+  const float* in_scale;
+  const float* out_scale;
+  const float* bias;
+  int batch, groups, cin_g, cout_g, h, w, oh, ow;
+  int mh, mw;            // M-space grid per image (pixels of this launch)
+  int ys, yo, xs, xo;    // output coordinate = q * s + o
+  int bs, byo, bxo;      // gather base coordinate = q * bs + bo
+  int py, px;            // parity class (MODE 1)
+  int nty, ntx;          // taps per axis of this class (MODE 1); MODE 0: KS
+  int ktot;              // cin_g * ntaps
+  int tiles_co, tiles_pix;
+  int splitk, slabs_per_split, nslabs;
+};
+
+// k -> (ci, ky, kx, dy, dx).  MODE 0: correlation taps; MODE 1: taps of one parity class.
+template <int KS, int MODE>
+__device__ __forceinline__ void decode_k(const ConvArgs& a, int k, int& ci, int& ky, int& kx, int& dy, int& dx) {
+  if (MODE == 0) {
+    constexpr int KK = KS * KS;
+    ci = k / KK;
+    const int tap = k - ci * KK;
+    ky = tap / KS;
+    kx = tap - ky * KS;
+    dy = ky;
+    dx = kx;
+  } else {
+    const int ntaps = a.nty * a.ntx;          // 1, 2 or 4 (ntx, nty in {1, 2})
+    const int sh = (ntaps == 4) ? 2 : (ntaps == 2 ? 1 : 0);
+    ci = k >> sh;
+    const int tap = k & (ntaps - 1);
+    const int jy = (a.ntx == 2) ? (tap >> 1) : tap;
+    const int jx = (a.ntx == 2) ? (tap & 1) : 0;
+    ky = a.py + 2 * jy;
+    kx = a.px + 2 * jx;
+    dy = -jy;
+    dx = -jx;
+  }
+}
+
+template <int KS, int MODE, int WCO, int WPIX, int MI, int NJ>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  constexpr int TCO = WCO * MI * 32;
+  constexpr int TPIX = WPIX * NJ * 32;
+  constexpr int ROWS_A = 256 / TPIX;            // k rows covered per pass by the pixel gather
+  constexpr int PASS_A = BK / ROWS_A;
+  constexpr int ROWS_B = 256 / TCO;
+  constexpr int PASS_B = BK / ROWS_B;
+  constexpr int KK = KS * KS;
+  __shared__ float sX[2][BK][TPIX];
+  __shared__ float sW[2][BK][TCO];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wco = wid / WPIX, wpix = wid % WPIX;
+  const unsigned ntiles = (unsigned)a.tiles_co * a.tiles_pix;
+  const unsigned logical = gg::xcd_remap(blockIdx.x, ntiles);
+  const int tile_co = logical % a.tiles_co, tile_pix = logical / a.tiles_co;
+  const int split = blockIdx.y, g = blockIdx.z;
+  const int co0 = tile_co * TCO;
+  const long long m0 = (long long)tile_pix * TPIX;
+  const long long mtot = (long long)a.batch * a.mh * a.mw;
+  const int hw = a.h * a.w;
+
+  // ---- per-thread gather column (one pixel of the tile) ----
+  const int pcol = tid % TPIX, prow = tid / TPIX;
+  const long long m = m0 + pcol;
+  const bool m_ok = m < mtot;
+  int pn = 0, base_y = 0, base_x = 0;
+  if (m_ok) {
+    const int per = a.mh * a.mw;
+    pn = (int)(m / per);
+    const int rem = (int)(m - (long long)pn * per);
+    const int qy = rem / a.mw, qx = rem - qy * a.mw;
+    base_y = qy * a.bs + a.byo;
+    base_x = qx * a.bs + a.bxo;
+  }
+  const int chan0 = (pn * a.groups + g) * a.cin_g;           // first input channel of this (sample, group)
+  const float* xg = a.x + (size_t)chan0 * hw;
+  const float* sg = a.in_scale ? a.in_scale + chan0 : nullptr;
+  // ---- per-thread weight column ----
+  const int ccol = tid % TCO, crow = tid / TCO;
+  const bool c_ok = (co0 + ccol) < a.cout_g;
+  const float* wg = a.wmat + (size_t)g * ((size_t)a.cin_g * KK) * a.cout_g + co0 + ccol;
+
+  const int slab0 = split * a.slabs_per_split;
+  int slab1 = slab0 + a.slabs_per_split;
+  if (slab1 > a.nslabs) slab1 = a.nslabs;
+
+  float ra[PASS_A], rb[PASS_B];
+
+  auto load_slab = [&](int slab) {
+    const int kbase = slab * BK;
+#pragma unroll
+    for (int p = 0; p < PASS_A; ++p) {
+      const int k = kbase + prow + p * ROWS_A;
+      float v = 0.f;
+      if (m_ok && k < a.ktot) {
+        int ci, ky, kx, dy, dx;
+        decode_k<KS, MODE>(a, k, ci, ky, kx, dy, dx);
+        const int iy = base_y + dy, ix = base_x + dx;
+        if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) {
+          v = xg[(size_t)ci * hw + iy * a.w + ix];
+          if (sg) v *= sg[ci];
+        }
+      }
+      ra[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < PASS_B; ++p) {
+      const int k = kbase + crow + p * ROWS_B;
+      float v = 0.f;
+      if (c_ok && k < a.ktot) {
+        int ci, ky, kx, dy, dx;
+        decode_k<KS, MODE>(a, k, ci, ky, kx, dy, dx);
+        v = wg[(size_t)(ci * KK + ky * KS + kx) * a.cout_g];
+      }
+      rb[p] = v;
+    }
+  };
+  auto store_slab = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < PASS_A; ++p) sX[buf][prow + p * ROWS_A][pcol] = ra[p];
+#pragma unroll
+    for (int p = 0; p < PASS_B; ++p) sW[buf][crow + p * ROWS_B][ccol] = rb[p];
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (slab0 < slab1) {
+    load_slab(slab0);
+    store_slab(0);
+    __syncthreads();
+    int cur = 0;
+    const int kh = lane >> 5, l31 = lane & 31;
+    for (int slab = slab0; slab < slab1; ++slab) {
+      const bool more = slab + 1 < slab1;
+      if (more) load_slab(slab + 1);
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float wa[MI], xb[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) wa[i] = sW[cur][kk * 2 + kh][(wco * MI + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xb[j] = sX[cur][kk * 2 + kh][(wpix * NJ + j) * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i], xb[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) store_slab(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // ---- epilogue: D[co][pix], lane -> pixel (lane & 31), reg r -> co = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int ohw = a.oh * a.ow;
+  const bool atomic = a.splitk > 1;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const long long mm = m0 + (wpix * NJ + j) * 32 + (lane & 31);
+    if (mm >= mtot) continue;
+    const int per = a.mh * a.mw;
+    const int on = (int)(mm / per);
+    const int rem = (int)(mm - (long long)on * per);
+    const int qy = rem / a.mw, qx = rem - qy * a.mw;
+    const int oy = qy * a.ys + a.yo, ox = qx * a.xs + a.xo;
+    const int ochan0 = (on * a.groups + g) * a.cout_g;
+    float* yp = a.y + (size_t)ochan0 * ohw + (size_t)oy * a.ow + ox;
+    const float* osc = a.out_scale ? a.out_scale + ochan0 : nullptr;
+    const float* bia = (a.bias && split == 0) ? a.bias + g * a.cout_g : nullptr;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wco * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co >= a.cout_g) continue;
+        float v = acc[i][j][r];
+        if (osc) v *= osc[co];
+        if (bia) v += bia[co];
+        if (atomic) unsafeAtomicAdd(yp + (size_t)co * ohw, v);
+        else yp[(size_t)co * ohw] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient:  dW[co, j] = sum_{pix} dy[n, co, pix] * x[n, ci(j), pix*stride + tap(j) - pad]
+//   D[i = co][j = (ci,ky,kx)], reduction index k = pixel.  Both global operands are contiguous
+//   along the pixel axis, so they are loaded lane-along-k (128 B rows) and stored to LDS as
+//   [k][row] with an odd row stride (129): lane-along-k writes and lane-along-row fragment reads
+//   are both conflict free.  K (= N*OH*OW, up to 10^6) is split across blockIdx.y; partial tiles
+//   are combined with fp32 atomics into the zero-initialised dW.
+// ------------------------------------------------------------------------------------------------
+constexpr int WBK = 32;
+constexpr int WT = 128;          // tile edge (co and j)
+constexpr int WLD = WT + 1;
+
+struct WgradArgs {
+  float* dw;
+  const float* x;
+  const float* dy;
+  int batch, groups, cin_g, cout_g, h, w, oh, ow, stride, pad;
+  int jtot;                     // cin_g * KS*KS
+  int tiles_co, tiles_j;
+  long long ktot;               // batch*oh*ow
+  long long k_per_split;
+  float scale;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int KK = KS * KS;
+  __shared__ float sD[2][WBK][WLD];   // dy  [k][co]
+  __shared__ float sXg[2][WBK][WLD];  // x    [k][j]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wco = wid >> 1, wj = wid & 1;
+  const unsigned ntiles = (unsigned)a.tiles_co * a.tiles_j;
+  const unsigned logical = gg::xcd_remap(blockIdx.x, ntiles);
+  const int tile_co = logical % a.tiles_co, tile_j = logical / a.tiles_co;
+  const int g = blockIdx.z;
+  const int co0 = tile_co * WT, j0 = tile_j * WT;
+  const long long kbeg = (long long)blockIdx.y * a.k_per_split;
+  long long kend = kbeg + a.k_per_split;
+  if (kend > a.ktot) kend = a.ktot;
+  const int ohw = a.oh * a.ow, hw = a.h * a.w;
+
+  const int kl = tid & 31;        // this thread's k (pixel) lane inside a slab
+  const int r0 = tid >> 5;        // first row (co / j) it loads; rows r0 + 8*p, p < 16
+
+  // decode of this thread's 16 j columns is loop invariant
+  int jci[16], jdy[16], jdx[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const int j = j0 + r0 + 8 * p;
+    if (j < a.jtot) {
+      const int ci = j / KK, tap = j - ci * KK;
+      jci[p] = ci;
+      jdy[p] = tap / KS - a.pad;
+      jdx[p] = tap % KS - a.pad;
+    } else {
+      jci[p] = -1; jdy[p] = 0; jdx[p] = 0;
+    }
+  }
+
+  float rd[16], rx[16];
+  auto load_slab = [&](long long k0) {
+    const long long k = k0 + kl;
+    const bool ok = k < kend;
+    int n = 0, oy = 0, ox = 0;
+    if (ok) {
+      n = (int)(k / ohw);
+      const int rem = (int)(k - (long long)n * ohw);
+      oy = rem / a.ow;
+      ox = rem - oy * a.ow;
+    }
+    const float* dyp = a.dy + ((size_t)(n * a.groups + g) * a.cout_g) * ohw + (size_t)oy * a.ow + ox;
+    const float* xp = a.x + ((size_t)(n * a.groups + g) * a.cin_g) * hw;
+    const int by = oy * a.stride, bx = ox * a.stride;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int co = co0 + r0 + 8 * p;
+      rd[p] = (ok && co < a.cout_g) ? dyp[(size_t)co * ohw] : 0.f;
+      float v = 0.f;
+      if (ok && jci[p] >= 0) {
+        const int iy = by + jdy[p], ix = bx + jdx[p];
+        if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) v = xp[(size_t)jci[p] * hw + iy * a.w + ix];
+      }
+      rx[p] = v;
+    }
+  };
+  auto store_slab = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      sD[buf][kl][r0 + 8 * p] = rd[p];
+      sXg[buf][kl][r0 + 8 * p] = rx[p];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kbeg < kend) {
+    load_slab(kbeg);
+    store_slab(0);
+    __syncthreads();
+    int cur = 0;
+    const int kh = lane >> 5, l31 = lane & 31;
+    for (long long k0 = kbeg; k0 < kend; k0 += WBK) {
+      const bool more = k0 + WBK < kend;
+      if (more) load_slab(k0 + WBK);
+#pragma unroll
+      for (int kk = 0; kk < WBK / 2; ++kk) {
+        float da[2], xb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) da[i] = sD[cur][kk * 2 + kh][(wco * 2 + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xb[j] = sXg[cur][kk * 2 + kh][(wj * 2 + j) * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[i], xb[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) store_slab(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  // D[i = co][j]: lane -> j column (lane & 31), reg r -> co row
+  float* dwg = a.dw + (size_t)g * a.cout_g * a.jtot;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int jj = j0 + (wj * 2 + j) * 32 + (lane & 31);
+    if (jj >= a.jtot) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wco * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co >= a.cout_g) continue;
+        unsafeAtomicAdd(dwg + (size_t)co * a.jtot + jj, acc[i][j][r] * a.scale);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void pack_weight_kernel(float* __restrict__ wmat, const float* __restrict__ w,
+                                                          long long total, int cout_g, int cin_g, int kh, int kw,
+                                                          int transpose_io, int flip, float scale) {
+  // wmat[g][(r, ky, kx)][c], r = reduction channel (cin_g of them), c = output channel (cout_g)
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int kk = kh * kw;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const int c = (int)(o % cout_g);
+    long long q = o / cout_g;
+    const int tap = (int)(q % kk);
+    q /= kk;
+    const int r = (int)(q % cin_g);
+    const int g = (int)(q / cin_g);
+    int ky = tap / kw, kx = tap % kw;
+    if (flip) { ky = kh - 1 - ky; kx = kw - 1 - kx; }
+    const size_t src = transpose_io ? (((size_t)g * cin_g + r) * cout_g + c) * kk + ky * kw + kx
+                                    : (((size_t)g * cout_g + c) * cin_g + r) * kk + ky * kw + kx;
+    wmat[o] = w[src] * scale;
+  }
+}
+
+// per-plane dot product: one block per plane, 16 B loads when possible
+__global__ __launch_bounds__(256) void plane_dot_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                        const float* __restrict__ b, long long hw) {
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.x * hw;
+  float acc = 0.f;
+  if ((hw & 3) == 0) {
+    const float4* a4 = reinterpret_cast<const float4*>(a + base);
+    const float4* b4 = reinterpret_cast<const float4*>(b + base);
+    for (long long i = threadIdx.x; i < hw / 4; i += 256) {
+      const float4 u = a4[i], v = b4[i];
+      acc += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+    }
+  } else {
+    for (long long i = threadIdx.x; i < hw; i += 256) acc += a[base + i] * b[base + i];
+  }
+  const float tot = gg::block_sum_256<float>(acc, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+
+// Fill in tiling / split-K for one launch.  Returns false when the launch is empty.
+bool plan_conv(ConvArgs& a, bool narrow) {
+  const int tco = narrow ? 32 : 128, tpix = narrow ? 256 : 128;
+  const long long mtot = (long long)a.batch * a.mh * a.mw;
+  if (mtot <= 0) return false;
+  a.tiles_co = (a.cout_g + tco - 1) / tco;
+  const long long tp = (mtot + tpix - 1) / tpix;
+  a.tiles_pix = (int)tp;
+  a.nslabs = (a.ktot + BK - 1) / BK;
+  const long long blocks = tp * a.tiles_co * a.groups;
+  int splitk = 1;
+  if (blocks < 2 * gg::kNumCu) {
+    splitk = (int)((2 * gg::kNumCu + blocks - 1) / blocks);
+    const int max_split = (a.nslabs + 7) / 8;      // keep >= 8 slabs (128 k) per split
+    if (splitk > max_split) splitk = max_split;
+    if (splitk < 1) splitk = 1;
+  }
+  a.slabs_per_split = (a.nslabs + splitk - 1) / splitk;
+  splitk = (a.nslabs + a.slabs_per_split - 1) / a.slabs_per_split;
+  a.splitk = splitk < 1 ? 1 : splitk;
+  return true;
+}
+
+template <int KS, int MODE>
+int launch_conv(const ConvArgs& a, bool narrow, hipStream_t st) {
+  if ((long long)a.tiles_pix * a.tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
+  dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
+  if (narrow)
+    conv_igemm_kernel<KS, MODE, 1, 4, 1, 2><<<grid, 256, 0, st>>>(a);
+  else
+    conv_igemm_kernel<KS, MODE, 2, 2, 2, 2><<<grid, 256, 0, st>>>(a);
+  return gg::launch_status("conv_igemm");
+}
+
+template <int KS>
+int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st) {
+  const bool narrow = a.cout_g <= 32;
+  ConvArgs plans[4];
+  int nplans = 0;
+  bool needs_zero = false;
+  if (mode == 0) {
+    a.mh = a.oh; a.mw = a.ow;
+    a.ys = 1; a.yo = 0; a.xs = 1; a.xo = 0;
+    a.bs = stride; a.byo = -pad; a.bxo = -pad;
+    a.py = a.px = 0; a.nty = a.ntx = KS;
+    a.ktot = a.cin_g * KS * KS;
+    if (plan_conv(a, narrow)) plans[nplans++] = a;
+  } else {
+    // transposed, stride 2: one dense sub-problem per parity class of u = y + pad
+    for (int py = 0; py < 2; ++py) {
+      for (int px = 0; px < 2; ++px) {
+        ConvArgs c = a;
+        const int nty = (KS - py + 1) / 2, ntx = (KS - px + 1) / 2;     // taps ky = py, py+2, ... < KS
+        auto axis = [&](int p, int osize, int& q0, int& o0, int& cnt) {
+          q0 = 0;                                                       // y = 2*q + p - pad >= 0
+          while (2 * q0 + p - pad < 0) ++q0;
+          o0 = 2 * q0 + p - pad;
+          cnt = (o0 < osize) ? (osize - 1 - o0) / 2 + 1 : 0;
+        };
+        int qy0, yo, mh, qx0, xo, mw;
+        axis(py, a.oh, qy0, yo, mh);
+        axis(px, a.ow, qx0, xo, mw);
+        if (mh <= 0 || mw <= 0) continue;
+        if (nty <= 0 || ntx <= 0) { needs_zero = true; continue; }     // class receives no tap: stays 0
+        c.mh = mh; c.mw = mw;
+        c.ys = 2; c.yo = yo; c.xs = 2; c.xo = xo;
+        c.bs = 1; c.byo = qy0; c.bxo = qx0;
+        c.py = py; c.px = px; c.nty = nty; c.ntx = ntx;
+        c.ktot = a.cin_g * nty * ntx;
+        if (plan_conv(c, narrow)) plans[nplans++] = c;
+      }
+    }
+  }
+  for (int i = 0; i < nplans; ++i) needs_zero = needs_zero || plans[i].splitk > 1;
+  if (needs_zero) {   // split-K partials are combined with atomics -> start from zero
+    const size_t out_elems = (size_t)a.batch * a.groups * a.cout_g * a.oh * a.ow;
+    hipError_t e = hipMemsetAsync(a.y, 0, sizeof(float) * out_elems, st);
+    if (e != hipSuccess) return gg::fail((int)e, "conv2d: memset failed");
+  }
+  for (int i = 0; i < nplans; ++i) {
+    const int rc = (mode == 0) ? launch_conv<KS, 0>(plans[i], narrow, st) : launch_conv<KS, 1>(plans[i], narrow, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int gg_conv_pack_weight_f32(float* wmat, const float* w, int groups, int cout_g, int cin_g, int kh,
+                                       int kw, int transpose_io, int flip, float scale, void* stream) {
+  const long long total = (long long)groups * cout_g * cin_g * kh * kw;
+  if (total <= 0) return 0;
+  if (!wmat || !w) return gg::fail(-2, "conv_pack_weight: null pointer");
+  pack_weight_kernel<<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(wmat, w, total, cout_g, cin_g,
+                                                                                    kh, kw, transpose_io, flip,
+                                                                                    scale);
+  return gg::launch_status("conv_pack_weight");
+}
+
+extern "C" int gg_conv2d_f32(float* y, const float* x, const float* wmat, const float* in_scale,
+                             const float* out_scale, const float* bias, int batch, int groups, int cin_g, int cout_g,
+                             int h, int w, int ksize, int stride, int pad, int mode, int out_h, int out_w,
+                             void* stream) {
+  if (batch <= 0 || groups <= 0 || cin_g <= 0 || cout_g <= 0) return 0;
+  if (!y || !x || !wmat || h <= 0 || w <= 0) return gg::fail(-2, "conv2d: bad arguments");
+  if (ksize != 1 && ksize != 3) return gg::fail(-2, "conv2d: kernel size %d not supported (1 or 3)", ksize);
+  if (groups > 65535) return gg::fail(-2, "conv2d: too many groups");
+  if (mode != 0 && mode != 1) return gg::fail(-2, "conv2d: mode must be 0 or 1");
+  if (pad < 0) return gg::fail(-2, "conv2d: negative padding");
+  if (mode == 0 && (stride < 1 || stride > 2)) return gg::fail(-2, "conv2d: stride must be 1 or 2");
+  if (mode == 1 && stride != 2)
+    return gg::fail(-2, "conv2d: transposed mode is implemented for stride 2 (stride 1 = mode 0 with flipped taps)");
+  ConvArgs a;
+  a.y = y; a.x = x; a.wmat = wmat; a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
+  a.batch = batch; a.groups = groups; a.cin_g = cin_g; a.cout_g = cout_g; a.h = h; a.w = w;
+  if (mode == 0) {
+    a.oh = (h + 2 * pad - ksize) / stride + 1;
+    a.ow = (w + 2 * pad - ksize) / stride + 1;
+    if ((out_h > 0 && out_h != a.oh) || (out_w > 0 && out_w != a.ow)) return gg::fail(-2, "conv2d: output size mismatch");
+  } else {
+    a.oh = (h - 1) * stride - 2 * pad + ksize;
+    a.ow = (w - 1) * stride - 2 * pad + ksize;
+    // output_padding: rows / columns beyond the natural size receive no contribution (zeros)
+    if (out_h > 0) { if (out_h < a.oh || out_h >= a.oh + stride) return gg::fail(-2, "conv2d: bad out_h"); a.oh = out_h; }
+    if (out_w > 0) { if (out_w < a.ow || out_w >= a.ow + stride) return gg::fail(-2, "conv2d: bad out_w"); a.ow = out_w; }
+  }
+  if (a.oh <= 0 || a.ow <= 0) return 0;
+  hipStream_t st = gg::as_stream(stream);
+  return ksize == 3 ? conv_dispatch<3>(a, stride, pad, mode, st) : conv_dispatch<1>(a, stride, pad, mode, st);
+}
+
+extern "C" int gg_conv2d_wgrad_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g,
+                                   int cout_g, int h, int w, int ksize, int stride, int pad, float scale,
+                                   void* stream) {
+  if (groups <= 0 || cin_g <= 0 || cout_g <= 0) return 0;
+  if (!dw || !x || !dy) return gg::fail(-2, "conv2d_wgrad: null pointer");
+  if (ksize != 1 && ksize != 3) return gg::fail(-2, "conv2d_wgrad: kernel size must be 1 or 3");
+  if (stride < 1 || groups > 65535) return gg::fail(-2, "conv2d_wgrad: bad arguments");
+  hipStream_t st = gg::as_stream(stream);
+  WgradArgs a;
+  a.dw = dw; a.x = x; a.dy = dy;
+  a.batch = batch; a.groups = groups; a.cin_g = cin_g; a.cout_g = cout_g; a.h = h; a.w = w;
+  a.oh = (h + 2 * pad - ksize) / stride + 1;
+  a.ow = (w + 2 * pad - ksize) / stride + 1;
+  a.stride = stride; a.pad = pad; a.scale = scale;
+  a.jtot = cin_g * ksize * ksize;
+  hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)groups * cout_g * a.jtot, st);
+  if (e != hipSuccess) return gg::fail((int)e, "conv2d_wgrad: memset failed");
+  if (batch <= 0 || a.oh <= 0 || a.ow <= 0) return 0;
+  a.ktot = (long long)batch * a.oh * a.ow;
+  a.tiles_co = (cout_g + WT - 1) / WT;
+  a.tiles_j = (a.jtot + WT - 1) / WT;
+  const long long tiles = (long long)a.tiles_co * a.tiles_j * groups;
+  long long splits = (4LL * gg::kNumCu + tiles - 1) / tiles;
+  const long long max_splits = (a.ktot + 8 * WBK - 1) / (8 * WBK);       // >= 8 slabs per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  if (splits > 65535) splits = 65535;
+  long long kps = (a.ktot + splits - 1) / splits;
+  kps = (kps + WBK - 1) / WBK * WBK;
+  splits = (a.ktot + kps - 1) / kps;
+  a.k_per_split = kps;
+  dim3 grid((unsigned)(a.tiles_co * a.tiles_j), (unsigned)splits, (unsigned)groups);
+  if (ksize == 3)
+    conv_wgrad_kernel<3><<<grid, 256, 0, st>>>(a);
+  else
+    conv_wgrad_kernel<1><<<grid, 256, 0, st>>>(a);
+  return gg::launch_status("conv2d_wgrad");
+}
+
+extern "C" int gg_plane_dot_f32(float* out, const float* a, const float* b, int planes, long long hw, void* stream) {
+  if (planes <= 0) return 0;
+  if (!out || !a || !b || hw < 0) return gg::fail(-2, "plane_dot: bad arguments");
+  plane_dot_kernel<<<planes, 256, 0, gg::as_stream(stream)>>>(out, a, b, hw);
+  return gg::launch_status("plane_dot");
+}

@@ -1,0 +1,160 @@
+// a2  fused bias + leaky-relu, forward and one-pass backward (+ bias gradient).
+// Pure HBM streaming: 8 B/elem forward, 12 B/elem backward.  16 B per lane loads/stores, grid
+// capped at 256 CUs x 8 blocks with a grid-stride loop.
+#include "../../include/gangealing_hip.h"
+#include "gg_common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ T act_apply(T v, T r, int mode, T alpha, T scale) {
+  // mode = act*10 + grad  (reference fused_bias_act_kernel.cu:36-47)
+  T y;
+  switch (mode) {
+    case 12: case 32: y = T(0); break;
+    case 30: y = (v > T(0)) ? v : v * alpha; break;
+    case 31: y = (r > T(0)) ? v : v * alpha; break;
+    default: y = v; break;                       // 10, 11 and unknown -> linear
+  }
+  return y * scale;
+}
+
+template <typename T> struct Vec4 { T v[4]; };
+
+// VEC = 4: every group of 4 consecutive elements shares one bias entry (step_b % 4 == 0).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void fused_bias_act_kernel(
+    T* __restrict__ out, const T* __restrict__ x, const T* __restrict__ b, const T* __restrict__ ref,
+    int mode, T alpha, T scale, long long n_items, long long step_b, int size_b) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += stride) {
+    const long long e = i * VEC;
+    T bias = T(0);
+    if (b) bias = b[(e / step_b) % size_b];
+    if (VEC == 4) {
+      Vec4<T> xv = *reinterpret_cast<const Vec4<T>*>(x + e);
+      Vec4<T> rv;
+      if (ref) rv = *reinterpret_cast<const Vec4<T>*>(ref + e);
+      Vec4<T> yv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) yv.v[j] = act_apply<T>(xv.v[j] + bias, ref ? rv.v[j] : T(0), mode, alpha, scale);
+      *reinterpret_cast<Vec4<T>*>(out + e) = yv;
+    } else {
+      out[e] = act_apply<T>(x[e] + bias, ref ? ref[e] : T(0), mode, alpha, scale);
+    }
+  }
+}
+
+// Backward: grid = (splits, C).  Block (s, c) walks hw-range s of every sample n for channel c,
+// writes grad_in and accumulates the channel's partial bias gradient (one atomic per block).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void fused_lrelu_bwd_kernel(
+    T* __restrict__ gin, T* __restrict__ gbias, const T* __restrict__ gout, const T* __restrict__ outv,
+    T alpha, T scale, int n, int c, long long hw, long long chunk) {
+  __shared__ T red[4];
+  const int ch = blockIdx.y;
+  const long long lo = (long long)blockIdx.x * chunk;
+  long long hi = lo + chunk;
+  if (hi > hw) hi = hw;
+  T acc = T(0);
+  for (int s = 0; s < n; ++s) {
+    const long long base = ((long long)s * c + ch) * hw;
+    for (long long p = lo + (long long)threadIdx.x * VEC; p < hi; p += 256 * VEC) {
+      if (VEC == 4) {
+        Vec4<T> g = *reinterpret_cast<const Vec4<T>*>(gout + base + p);
+        Vec4<T> o = *reinterpret_cast<const Vec4<T>*>(outv + base + p);
+        Vec4<T> r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          r.v[j] = ((o.v[j] > T(0)) ? g.v[j] : g.v[j] * alpha) * scale;
+          acc += r.v[j];
+        }
+        *reinterpret_cast<Vec4<T>*>(gin + base + p) = r;
+      } else {
+        const T g = gout[base + p], o = outv[base + p];
+        const T r = ((o > T(0)) ? g : g * alpha) * scale;
+        gin[base + p] = r;
+        acc += r;
+      }
+    }
+  }
+  if (gbias) {
+    const T tot = gg::block_sum_256<T>(acc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(gbias + ch, tot);
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T>
+int fused_bias_act_impl(T* out, const T* x, const T* bias, const T* ref, int act, int grad, T alpha, T scale,
+                        long long size_x, long long step_b, int size_b, void* stream) {
+  if (size_x == 0) return 0;
+  if (size_x < 0 || !out || !x) return gg::fail(-2, "fused_bias_act: bad arguments");
+  if (bias && (step_b <= 0 || size_b <= 0)) return gg::fail(-2, "fused_bias_act: bias needs step_b, size_b > 0");
+  const int mode = act * 10 + grad;
+  const int vecn = 16 / (int)sizeof(T);            // elements per 16-byte access (4 for f32, 2 for f64)
+  const bool vec = (vecn == 4) && (size_x % 4 == 0) && (!bias || step_b % 4 == 0) && aligned16(out) && aligned16(x) &&
+                   (!ref || aligned16(ref));
+  hipStream_t st = gg::as_stream(stream);
+  if (vec) {
+    const long long items = size_x / 4;
+    fused_bias_act_kernel<T, 4><<<gg::stream_grid(items, 256), 256, 0, st>>>(out, x, bias, ref, mode, alpha, scale,
+                                                                             items, step_b, size_b);
+  } else {
+    fused_bias_act_kernel<T, 1><<<gg::stream_grid(size_x, 256), 256, 0, st>>>(out, x, bias, ref, mode, alpha, scale,
+                                                                              size_x, step_b, size_b);
+  }
+  return gg::launch_status("fused_bias_act");
+}
+
+template <typename T>
+int fused_lrelu_bwd_impl(T* gin, T* gbias, const T* gout, const T* outv, T alpha, T scale, int n, int c,
+                         long long hw, void* stream) {
+  if (n <= 0 || c <= 0 || hw <= 0) return 0;
+  if (!gin || !gout || !outv) return gg::fail(-2, "fused_lrelu_bwd: null pointer");
+  if (c > 65535) return gg::fail(-2, "fused_lrelu_bwd: more than 65535 channels");
+  hipStream_t st = gg::as_stream(stream);
+  if (gbias) {
+    hipError_t e = hipMemsetAsync(gbias, 0, sizeof(T) * (size_t)c, st);
+    if (e != hipSuccess) return gg::fail((int)e, "fused_lrelu_bwd: memset failed");
+  }
+  const bool vec = sizeof(T) == 4 && (hw % 4 == 0) && aligned16(gin) && aligned16(gout) && aligned16(outv);
+  const int per = vec ? 4 : 1;
+  // enough blocks to fill the chip (>= ~2048) but at least one full 256-thread sweep per block
+  long long want = (2048 + c - 1) / c;
+  long long max_splits = (hw + 256LL * per - 1) / (256LL * per);
+  long long splits = want < 1 ? 1 : want;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  long long chunk = (hw + splits - 1) / splits;
+  chunk = (chunk + per - 1) / per * per;
+  splits = (hw + chunk - 1) / chunk;
+  dim3 grid((unsigned)splits, (unsigned)c);
+  if (vec)
+    fused_lrelu_bwd_kernel<T, 4><<<grid, 256, 0, st>>>(gin, gbias, gout, outv, alpha, scale, n, c, hw, chunk);
+  else
+    fused_lrelu_bwd_kernel<T, 1><<<grid, 256, 0, st>>>(gin, gbias, gout, outv, alpha, scale, n, c, hw, chunk);
+  return gg::launch_status("fused_lrelu_bwd");
+}
+
+}  // namespace
+
+extern "C" int gg_fused_bias_act_f32(float* out, const float* x, const float* bias, const float* ref, int act,
+                                     int grad, float alpha, float scale, long long size_x, long long step_b,
+                                     int size_b, void* stream) {
+  return fused_bias_act_impl<float>(out, x, bias, ref, act, grad, alpha, scale, size_x, step_b, size_b, stream);
+}
+extern "C" int gg_fused_bias_act_f64(double* out, const double* x, const double* bias, const double* ref, int act,
+                                     int grad, double alpha, double scale, long long size_x, long long step_b,
+                                     int size_b, void* stream) {
+  return fused_bias_act_impl<double>(out, x, bias, ref, act, grad, alpha, scale, size_x, step_b, size_b, stream);
+}
+extern "C" int gg_fused_lrelu_bwd_f32(float* grad_in, float* grad_bias, const float* grad_out, const float* out,
+                                      float alpha, float scale, int n, int c, long long hw, void* stream) {
+  return fused_lrelu_bwd_impl<float>(grad_in, grad_bias, grad_out, out, alpha, scale, n, c, hw, stream);
+}
+extern "C" int gg_fused_lrelu_bwd_f64(double* grad_in, double* grad_bias, const double* grad_out, const double* out,
+                                      double alpha, double scale, int n, int c, long long hw, void* stream) {
+  return fused_lrelu_bwd_impl<double>(grad_in, grad_bias, grad_out, out, alpha, scale, n, c, hw, stream);
+}

@@ -1,0 +1,506 @@
+// a7-a10  the small STN-side operators that the reference spreads over ~40 tiny torch launches:
+//   affine_grid (+bwd), RAFT convex flow upsampling + identity + affine composition (+bwd),
+//   bilinear flow resize (+bwd), BilinearDownsample (+bwd), TV / identity flow losses (+bwd).
+// All of them are latency bound at batch 16 (<= 10 MB of traffic), so each is ONE kernel per
+// direction, thread-per-output, reductions finished with one atomic per block.
+#include "../../include/gangealing_hip.h"
+#include "gg_common.h"
+
+namespace {
+
+// torch.linspace(-1, 1, steps)[i] * (steps-1)/steps  - base coordinate of F.affine_grid(align_corners=False)
+__device__ __forceinline__ float base_coord(int i, int steps) {
+  if (steps <= 1) return 0.f;
+  const float step = 2.f / (float)(steps - 1);
+  const float lin = (i < steps / 2) ? (-1.f + step * (float)i) : (1.f - step * (float)(steps - 1 - i));
+  return lin * (float)(steps - 1) / (float)steps;
+}
+
+// ---------------------------------------------------------------- affine_grid
+
+__global__ __launch_bounds__(256) void affine_grid_kernel(float* __restrict__ grid, const float* __restrict__ theta,
+                                                          long long total, int ho, int wo) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const int j = (int)(o % wo);
+    const long long q = o / wo;
+    const int i = (int)(q % ho);
+    const float* t = theta + (q / ho) * 6;
+    const float x = base_coord(j, wo), y = base_coord(i, ho);
+    grid[o * 2 + 0] = x * t[0] + y * t[1] + t[2];
+    grid[o * 2 + 1] = x * t[3] + y * t[4] + t[5];
+  }
+}
+
+// grid = (splits, n); each block reduces its share of one sample's pixels to 6 numbers.
+__global__ __launch_bounds__(256) void affine_grid_bwd_kernel(float* __restrict__ gtheta,
+                                                              const float* __restrict__ ggrid, int ho, int wo) {
+  __shared__ float red[4];
+  const int s = blockIdx.y;
+  const long long pix = (long long)ho * wo;
+  const float* g = ggrid + (size_t)s * pix * 2;
+  float acc[6] = {0, 0, 0, 0, 0, 0};
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < pix; p += (long long)gridDim.x * 256) {
+    const int j = (int)(p % wo), i = (int)(p / wo);
+    const float x = base_coord(j, wo), y = base_coord(i, ho);
+    const float gx = g[p * 2], gy = g[p * 2 + 1];
+    acc[0] += gx * x; acc[1] += gx * y; acc[2] += gx;
+    acc[3] += gy * x; acc[4] += gy * y; acc[5] += gy;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float tot = gg::block_sum_256<float>(acc[k], red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(gtheta + s * 6 + k, tot);
+  }
+}
+
+// ---------------------------------------------------------------- flow composition
+
+struct Convex {
+  float s[9];        // softmax weights
+  float vx[9], vy[9];  // ds * neighbour flow
+};
+
+__device__ __forceinline__ Convex convex_load(const float* __restrict__ low, const float* __restrict__ mask, int n,
+                                              int ij, int y, int x, int hl, int wl, int ds) {
+  Convex c;
+  const int dd = ds * ds;
+  const size_t plane = (size_t)hl * wl;
+  const float* m = mask + ((size_t)n * 9 * dd + ij) * plane + (size_t)y * wl + x;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    c.s[k] = m[(size_t)k * dd * plane];
+    mx = fmaxf(mx, c.s[k]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    c.s[k] = expf(c.s[k] - mx);
+    sum += c.s[k];
+  }
+  const float inv = 1.f / sum;
+  const float* lx = low + (size_t)n * 2 * plane;
+  const float* ly = lx + plane;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    c.s[k] *= inv;
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    const bool in = yy >= 0 && yy < hl && xx >= 0 && xx < wl;
+    c.vx[k] = in ? (float)ds * lx[(size_t)yy * wl + xx] : 0.f;
+    c.vy[k] = in ? (float)ds * ly[(size_t)yy * wl + xx] : 0.f;
+  }
+  return c;
+}
+
+// thread -> (ij, y, x) with x fastest so that mask reads are coalesced along x; blockIdx.y = sample
+__global__ __launch_bounds__(256) void flow_compose_fwd_kernel(float* __restrict__ delta, float* __restrict__ flow,
+                                                               const float* __restrict__ low,
+                                                               const float* __restrict__ mask,
+                                                               const float* __restrict__ base, int hl, int wl,
+                                                               int ds) {
+  const int n = blockIdx.y;
+  const int per = ds * ds * hl * wl;
+  const int H = ds * hl, W = ds * wl;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < per; t += gridDim.x * 256) {
+    const int x = t % wl;
+    const int y = (t / wl) % hl;
+    const int ij = t / (wl * hl);
+    const Convex c = convex_load(low, mask, n, ij, y, x, hl, wl, ds);
+    float ux = 0.f, uy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { ux += c.s[k] * c.vx[k]; uy += c.s[k] * c.vy[k]; }
+    const int Y = ds * y + ij / ds, X = ds * x + ij % ds;
+    const size_t o = (((size_t)n * H + Y) * W + X) * 2;
+    delta[o] = ux;
+    delta[o + 1] = uy;
+    float fx = base_coord(X, W) + ux, fy = base_coord(Y, H) + uy;
+    if (base) {
+      const float* b = base + n * 6;
+      const float ax = fx * b[0] + fy * b[1] + b[2];
+      const float ay = fx * b[3] + fy * b[4] + b[5];
+      fx = ax; fy = ay;
+    }
+    flow[o] = fx;
+    flow[o + 1] = fy;
+  }
+}
+
+__global__ __launch_bounds__(256) void flow_compose_bwd_kernel(
+    float* __restrict__ glow, float* __restrict__ gmask, float* __restrict__ gbase, const float* __restrict__ g_flow,
+    const float* __restrict__ g_delta, const float* __restrict__ low, const float* __restrict__ mask,
+    const float* __restrict__ base, int hl, int wl, int ds) {
+  __shared__ float red[4];
+  const int n = blockIdx.y;
+  const int per = ds * ds * hl * wl;
+  const int H = ds * hl, W = ds * wl;
+  const int dd = ds * ds;
+  const size_t plane = (size_t)hl * wl;
+  float accb[6] = {0, 0, 0, 0, 0, 0};
+  const int iters = (per + gridDim.x * 256 - 1) / (gridDim.x * 256);
+  for (int it = 0; it < iters; ++it) {
+    const int t = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    if (t >= per) continue;
+    const int x = t % wl;
+    const int y = (t / wl) % hl;
+    const int ij = t / (wl * hl);
+    const Convex c = convex_load(low, mask, n, ij, y, x, hl, wl, ds);
+    const int Y = ds * y + ij / ds, X = ds * x + ij % ds;
+    const size_t o = (((size_t)n * H + Y) * W + X) * 2;
+    float gfx = 0.f, gfy = 0.f, gux = 0.f, guy = 0.f;
+    if (g_flow) { gfx = g_flow[o]; gfy = g_flow[o + 1]; }
+    if (g_delta) { gux = g_delta[o]; guy = g_delta[o + 1]; }
+    if (base) {
+      const float* b = base + n * 6;
+      float ux = 0.f, uy = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { ux += c.s[k] * c.vx[k]; uy += c.s[k] * c.vy[k]; }
+      const float fx = base_coord(X, W) + ux, fy = base_coord(Y, H) + uy;
+      accb[0] += gfx * fx; accb[1] += gfx * fy; accb[2] += gfx;
+      accb[3] += gfy * fx; accb[4] += gfy * fy; accb[5] += gfy;
+      gux += b[0] * gfx + b[3] * gfy;
+      guy += b[1] * gfx + b[4] * gfy;
+    } else {
+      gux += gfx;
+      guy += gfy;
+    }
+    float gs[9], dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      gs[k] = gux * c.vx[k] + guy * c.vy[k];
+      dot += c.s[k] * gs[k];
+    }
+    float* gm = gmask + ((size_t)n * 9 * dd + ij) * plane + (size_t)y * wl + x;
+    float* gl = glow + (size_t)n * 2 * plane;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      gm[(size_t)k * dd * plane] = c.s[k] * (gs[k] - dot);
+      const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+      if (yy >= 0 && yy < hl && xx >= 0 && xx < wl) {
+        unsafeAtomicAdd(gl + (size_t)yy * wl + xx, (float)ds * c.s[k] * gux);
+        unsafeAtomicAdd(gl + plane + (size_t)yy * wl + xx, (float)ds * c.s[k] * guy);
+      }
+    }
+  }
+  if (base && gbase) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const float tot = gg::block_sum_256<float>(accb[k], red);
+      if (threadIdx.x == 0) unsafeAtomicAdd(gbase + n * 6 + k, tot);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- bilinear flow resize
+
+struct Lin { int i0, i1; float l0, l1; };
+
+__device__ __forceinline__ Lin lin_src(int dst, float rscale, int size) {   // ATen UpSample.h, align_corners=False
+  float src = rscale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  Lin l;
+  l.i0 = min((int)src, size - 1);
+  l.i1 = l.i0 + (l.i0 < size - 1 ? 1 : 0);
+  l.l1 = src - (float)l.i0;
+  l.l0 = 1.f - l.l1;
+  return l;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void flow_resize_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                          long long total, int hi, int wi, int ho, int wo,
+                                                          float rscale) {
+  // fwd: dst = out (N,ho,wo,2), src = in (N,hi,wi,2).   bwd: dst = grad_in (accumulated), src = grad_out.
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const int x = (int)(o % wo);
+    const long long q = o / wo;
+    const int y = (int)(q % ho);
+    const size_t n = (size_t)(q / ho);
+    const Lin ly = lin_src(y, rscale, hi), lx = lin_src(x, rscale, wi);
+    const size_t b = n * hi * wi;
+    const size_t p00 = (b + (size_t)ly.i0 * wi + lx.i0) * 2, p01 = (b + (size_t)ly.i0 * wi + lx.i1) * 2;
+    const size_t p10 = (b + (size_t)ly.i1 * wi + lx.i0) * 2, p11 = (b + (size_t)ly.i1 * wi + lx.i1) * 2;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (!BWD) {
+        dst[o * 2 + c] = ly.l0 * (lx.l0 * src[p00 + c] + lx.l1 * src[p01 + c]) +
+                         ly.l1 * (lx.l0 * src[p10 + c] + lx.l1 * src[p11 + c]);
+      } else {
+        const float g = src[o * 2 + c];
+        unsafeAtomicAdd(dst + p00 + c, g * ly.l0 * lx.l0);
+        unsafeAtomicAdd(dst + p01 + c, g * ly.l0 * lx.l1);
+        unsafeAtomicAdd(dst + p10 + c, g * ly.l1 * lx.l0);
+        unsafeAtomicAdd(dst + p11 + c, g * ly.l1 * lx.l1);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- BilinearDownsample
+
+constexpr int MAX_STRIDE = 8;
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  if (i < 0) return -i;
+  if (i >= n) return 2 * n - 2 - i;
+  return i;
+}
+
+__device__ __forceinline__ float tent(int t, int stride) {          // kernel[t], t in [0, 2*stride)
+  const int v = (t < stride) ? 2 * t + 1 : 2 * (2 * stride - 1 - t) + 1;
+  return (float)((double)v / (double)(2 * stride * stride));
+}
+
+__global__ __launch_bounds__(256) void bilinear_down_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                            long long total, int h, int w, int stride) {
+  const int r = stride / 2;
+  const int oh = (h + 2 * r - 2 * stride) / stride + 1, ow = (w + 2 * r - 2 * stride) / stride + 1;
+  const long long gstride = (long long)gridDim.x * blockDim.x;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gstride) {
+    const int ox = (int)(o % ow);
+    const long long q = o / ow;
+    const int oy = (int)(q % oh);
+    const float* src = in + (size_t)(q / oh) * h * w;
+    float acc = 0.f;
+    for (int ty = 0; ty < 2 * stride; ++ty) {
+      const int iy = reflect_idx(stride * oy + ty - r, h);
+      float row = 0.f;
+      for (int tx = 0; tx < 2 * stride; ++tx) {
+        const int ix = reflect_idx(stride * ox + tx - r, w);
+        row += src[(size_t)iy * w + ix] * tent(tx, stride);
+      }
+      acc += row * tent(ty, stride);
+    }
+    out[o] = acc;
+  }
+}
+
+// padded positions q whose source is input index i (ReflectionPad(r)): q = i + r, plus mirror images
+__device__ __forceinline__ int pad_sources(int i, int n, int r, int q[3]) {
+  int cnt = 0;
+  q[cnt++] = i + r;
+  if (i >= 1 && i <= r) q[cnt++] = r - i;
+  if (i >= n - 1 - r && i <= n - 2) q[cnt++] = 2 * n - 2 - i + r;
+  return cnt;
+}
+
+__global__ __launch_bounds__(256) void bilinear_down_bwd_kernel(float* __restrict__ gin,
+                                                                const float* __restrict__ gout, long long total,
+                                                                int h, int w, int stride) {
+  const int r = stride / 2;
+  const int oh = (h + 2 * r - 2 * stride) / stride + 1, ow = (w + 2 * r - 2 * stride) / stride + 1;
+  const long long gstride = (long long)gridDim.x * blockDim.x;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gstride) {
+    const int ix = (int)(o % w);
+    const long long q = o / w;
+    const int iy = (int)(q % h);
+    const float* g = gout + (size_t)(q / h) * oh * ow;
+    int qy[3], qx[3];
+    const int ny = pad_sources(iy, h, r, qy), nx = pad_sources(ix, w, r, qx);
+    float acc = 0.f;
+    for (int a = 0; a < ny; ++a) {
+      const int y_hi = min(qy[a] / stride, oh - 1);
+      const int y_lo = max((qy[a] - 2 * stride + 1 + stride - 1) / stride, 0);     // ceil((q-2s+1)/s), q-2s+1 may be < 0
+      for (int oy = max(y_lo, 0); oy <= y_hi; ++oy) {
+        const int ty = qy[a] - stride * oy;
+        if (ty < 0 || ty >= 2 * stride) continue;
+        const float ky = tent(ty, stride);
+        for (int b = 0; b < nx; ++b) {
+          const int x_hi = min(qx[b] / stride, ow - 1);
+          for (int ox = max(x_hi - 2, 0); ox <= x_hi; ++ox) {
+            const int tx = qx[b] - stride * ox;
+            if (tx < 0 || tx >= 2 * stride) continue;
+            acc += g[(size_t)oy * ow + ox] * ky * tent(tx, stride);
+          }
+        }
+      }
+    }
+    gin[o] = acc;
+  }
+}
+
+// ---------------------------------------------------------------- flow losses
+
+__device__ __forceinline__ float huber(float u) {
+  const float a = fabsf(u);
+  return a <= 1.f ? 0.5f * a * a : a - 0.5f;
+}
+__device__ __forceinline__ float huber_grad(float u) {
+  return fabsf(u) <= 1.f ? u : (u > 0.f ? 1.f : -1.f);
+}
+
+__global__ __launch_bounds__(256) void flow_losses_kernel(float* __restrict__ losses, const float* __restrict__ d,
+                                                          long long total, int hf, int wf, float inv_y, float inv_x,
+                                                          float inv_all) {
+  __shared__ float red[4];
+  float sy = 0.f, sx = 0.f, sq = 0.f;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const long long pix = o >> 1;
+    const int x = (int)(pix % wf);
+    const int y = (int)((pix / wf) % hf);
+    const float v = d[o];
+    sq += v * v;
+    if (y + 1 < hf) sy += huber(v - d[o + (size_t)wf * 2]);
+    if (x + 1 < wf) sx += huber(v - d[o + 2]);
+  }
+  const float ty = gg::block_sum_256<float>(sy, red);
+  const float tx = gg::block_sum_256<float>(sx, red);
+  const float tq = gg::block_sum_256<float>(sq, red);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(losses, ty * inv_y + tx * inv_x);
+    unsafeAtomicAdd(losses + 1, tq * inv_all);
+  }
+}
+
+__global__ __launch_bounds__(256) void flow_losses_bwd_kernel(float* __restrict__ gd, const float* __restrict__ d,
+                                                              const float* __restrict__ g_losses, long long total,
+                                                              int hf, int wf, float inv_y, float inv_x,
+                                                              float inv_all) {
+  const float g_tv = g_losses[0], g_id = g_losses[1];
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const long long pix = o >> 1;
+    const int x = (int)(pix % wf);
+    const int y = (int)((pix / wf) % hf);
+    const float v = d[o];
+    float g = 0.f;
+    if (y + 1 < hf) g += huber_grad(v - d[o + (size_t)wf * 2]) * inv_y;
+    if (y > 0) g -= huber_grad(d[o - (size_t)wf * 2] - v) * inv_y;
+    if (x + 1 < wf) g += huber_grad(v - d[o + 2]) * inv_x;
+    if (x > 0) g -= huber_grad(d[o - 2] - v) * inv_x;
+    gd[o] = g_tv * g + g_id * 2.f * v * inv_all;
+  }
+}
+
+}  // namespace
+
+extern "C" int gg_affine_grid_f32(float* grid, const float* theta, int n, int ho, int wo, void* stream) {
+  const long long total = (long long)n * ho * wo;
+  if (total <= 0) return 0;
+  if (!grid || !theta) return gg::fail(-2, "affine_grid: null pointer");
+  affine_grid_kernel<<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(grid, theta, total, ho, wo);
+  return gg::launch_status("affine_grid");
+}
+
+extern "C" int gg_affine_grid_bwd_f32(float* grad_theta, const float* grad_grid, int n, int ho, int wo,
+                                      void* stream) {
+  if (n <= 0) return 0;
+  if (!grad_theta || !grad_grid || n > 65535) return gg::fail(-2, "affine_grid_bwd: bad arguments");
+  hipStream_t st = gg::as_stream(stream);
+  hipError_t e = hipMemsetAsync(grad_theta, 0, sizeof(float) * 6 * (size_t)n, st);
+  if (e != hipSuccess) return gg::fail((int)e, "affine_grid_bwd: memset failed");
+  const long long pix = (long long)ho * wo;
+  if (pix <= 0) return 0;
+  unsigned splits = (unsigned)((pix + 4095) / 4096);
+  if (splits > 64) splits = 64;
+  affine_grid_bwd_kernel<<<dim3(splits, n), 256, 0, st>>>(grad_theta, grad_grid, ho, wo);
+  return gg::launch_status("affine_grid_bwd");
+}
+
+extern "C" int gg_flow_compose_fwd_f32(float* delta, float* flow, const float* low_flow, const float* mask,
+                                       const float* base, int n, int hl, int wl, int ds, void* stream) {
+  if (n <= 0 || hl <= 0 || wl <= 0) return 0;
+  if (!delta || !flow || !low_flow || !mask || ds < 1 || n > 65535) return gg::fail(-2, "flow_compose_fwd: bad arguments");
+  const long long per = (long long)ds * ds * hl * wl;
+  unsigned bx = (unsigned)((per + 255) / 256);
+  if (bx > 1024) bx = 1024;
+  flow_compose_fwd_kernel<<<dim3(bx, n), 256, 0, gg::as_stream(stream)>>>(delta, flow, low_flow, mask, base, hl, wl,
+                                                                         ds);
+  return gg::launch_status("flow_compose_fwd");
+}
+
+extern "C" int gg_flow_compose_bwd_f32(float* grad_low, float* grad_mask, float* grad_base, const float* g_flow,
+                                       const float* g_delta, const float* low_flow, const float* mask,
+                                       const float* base, int n, int hl, int wl, int ds, void* stream) {
+  if (n <= 0 || hl <= 0 || wl <= 0) return 0;
+  if (!grad_low || !grad_mask || !low_flow || !mask || ds < 1 || n > 65535)
+    return gg::fail(-2, "flow_compose_bwd: bad arguments");
+  hipStream_t st = gg::as_stream(stream);
+  hipError_t e = hipMemsetAsync(grad_low, 0, sizeof(float) * 2 * (size_t)n * hl * wl, st);
+  if (e == hipSuccess && base && grad_base) e = hipMemsetAsync(grad_base, 0, sizeof(float) * 6 * (size_t)n, st);
+  if (e != hipSuccess) return gg::fail((int)e, "flow_compose_bwd: memset failed");
+  const long long per = (long long)ds * ds * hl * wl;
+  unsigned bx = (unsigned)((per + 255) / 256);
+  if (bx > 1024) bx = 1024;
+  flow_compose_bwd_kernel<<<dim3(bx, n), 256, 0, st>>>(grad_low, grad_mask, grad_base, g_flow, g_delta, low_flow,
+                                                       mask, base, hl, wl, ds);
+  return gg::launch_status("flow_compose_bwd");
+}
+
+extern "C" int gg_flow_resize_f32(float* out, const float* in, int n, int hi, int wi, int ho, int wo, float scale,
+                                  void* stream) {
+  const long long total = (long long)n * ho * wo;
+  if (total <= 0) return 0;
+  if (!out || !in || hi <= 0 || wi <= 0 || !(scale > 0.f)) return gg::fail(-2, "flow_resize: bad arguments");
+  flow_resize_kernel<false><<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(out, in, total, hi, wi,
+                                                                                           ho, wo, 1.f / scale);
+  return gg::launch_status("flow_resize");
+}
+
+extern "C" int gg_flow_resize_bwd_f32(float* grad_in, const float* grad_out, int n, int hi, int wi, int ho, int wo,
+                                      float scale, void* stream) {
+  const long long total = (long long)n * ho * wo;
+  if (n <= 0 || hi <= 0 || wi <= 0) return 0;
+  if (!grad_in || !grad_out || !(scale > 0.f)) return gg::fail(-2, "flow_resize_bwd: bad arguments");
+  hipStream_t st = gg::as_stream(stream);
+  hipError_t e = hipMemsetAsync(grad_in, 0, sizeof(float) * 2 * (size_t)n * hi * wi, st);
+  if (e != hipSuccess) return gg::fail((int)e, "flow_resize_bwd: memset failed");
+  if (total <= 0) return 0;
+  flow_resize_kernel<true><<<gg::stream_grid(total, 256), 256, 0, st>>>(grad_in, grad_out, total, hi, wi, ho, wo,
+                                                                        1.f / scale);
+  return gg::launch_status("flow_resize_bwd");
+}
+
+extern "C" int gg_bilinear_downsample_f32(float* out, const float* in, int planes, int h, int w, int stride,
+                                          void* stream) {
+  if (planes <= 0) return 0;
+  if (!out || !in || stride < 1 || stride > MAX_STRIDE || h <= stride / 2 || w <= stride / 2)
+    return gg::fail(-2, "bilinear_downsample: bad arguments");
+  const int r = stride / 2;
+  const int oh = (h + 2 * r - 2 * stride) / stride + 1, ow = (w + 2 * r - 2 * stride) / stride + 1;
+  const long long total = (long long)planes * oh * ow;
+  if (total <= 0) return 0;
+  bilinear_down_kernel<<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(out, in, total, h, w, stride);
+  return gg::launch_status("bilinear_downsample");
+}
+
+extern "C" int gg_bilinear_downsample_bwd_f32(float* grad_in, const float* grad_out, int planes, int h, int w,
+                                              int stride, void* stream) {
+  if (planes <= 0) return 0;
+  if (!grad_in || !grad_out || stride < 1 || stride > MAX_STRIDE || h <= stride / 2 || w <= stride / 2)
+    return gg::fail(-2, "bilinear_downsample_bwd: bad arguments");
+  const long long total = (long long)planes * h * w;
+  bilinear_down_bwd_kernel<<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(grad_in, grad_out, total,
+                                                                                          h, w, stride);
+  return gg::launch_status("bilinear_downsample_bwd");
+}
+
+extern "C" int gg_flow_losses_f32(float* losses, const float* delta, int n, int hf, int wf, void* stream) {
+  if (!losses) return gg::fail(-2, "flow_losses: null pointer");
+  hipStream_t st = gg::as_stream(stream);
+  hipError_t e = hipMemsetAsync(losses, 0, sizeof(float) * 2, st);
+  if (e != hipSuccess) return gg::fail((int)e, "flow_losses: memset failed");
+  const long long total = (long long)n * hf * wf * 2;
+  if (total <= 0) return 0;
+  if (!delta) return gg::fail(-2, "flow_losses: null pointer");
+  const float inv_y = hf > 1 ? 1.f / (float)((long long)n * (hf - 1) * wf * 2) : 0.f;
+  const float inv_x = wf > 1 ? 1.f / (float)((long long)n * hf * (wf - 1) * 2) : 0.f;
+  unsigned blocks = gg::stream_grid(total, 256);
+  if (blocks > 256) blocks = 256;
+  flow_losses_kernel<<<blocks, 256, 0, st>>>(losses, delta, total, hf, wf, inv_y, inv_x, 1.f / (float)total);
+  return gg::launch_status("flow_losses");
+}
+
+extern "C" int gg_flow_losses_bwd_f32(float* grad_delta, const float* delta, const float* g_losses, int n, int hf,
+                                      int wf, void* stream) {
+  const long long total = (long long)n * hf * wf * 2;
+  if (total <= 0) return 0;
+  if (!grad_delta || !delta || !g_losses) return gg::fail(-2, "flow_losses_bwd: null pointer");
+  const float inv_y = hf > 1 ? 1.f / (float)((long long)n * (hf - 1) * wf * 2) : 0.f;
+  const float inv_x = wf > 1 ? 1.f / (float)((long long)n * hf * (wf - 1) * 2) : 0.f;
+  flow_losses_bwd_kernel<<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(
+      grad_delta, delta, g_losses, total, hf, wf, inv_y, inv_x, 1.f / (float)total);
+  return gg::launch_status("flow_losses_bwd");
+}

@@ -1,0 +1,212 @@
+"""Autograd wrappers around the implicit-GEMM MFMA convolution (csrc/conv_mfma.hip).
+
+conv2d / conv_transpose2d here are what op/conv2d_gradfix.py exposes under the reference's
+names; `modulated_conv2d` is the shared-weight form of ModulatedConv2d.forward
+(models/stylegan2/networks.py:233-282) used by our generator.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+
+
+def _pair_eq(v, name):
+    if isinstance(v, (tuple, list)):
+        if len(v) != 2 or v[0] != v[1]:
+            raise NotImplementedError(f'conv_mfma: {name} must be square, got {v}')
+        return int(v[0])
+    return int(v)
+
+
+def pack_weight(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0):
+    """-> wmat (groups, cin_g*k*k, cout_g): GEMM layout consumed by gg_conv2d_f32.  `cin_g` is the
+    reduction-channel count and `cout_g` the output-channel count OF THE CONVOLUTION BEING RUN."""
+    wmat = torch.empty((groups, cin_g * k * k, cout_g), dtype=torch.float32, device=weight.device)
+    _lib.call('gg_conv_pack_weight_f32', wmat, weight.contiguous(), groups, cout_g, cin_g, k, k,
+              int(transpose_io), int(flip), scale)
+    return wmat
+
+
+def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in_scale=None, out_scale=None,
+                 bias=None, out_hw=None):
+    h, w = x.shape[-2], x.shape[-1]
+    if mode == 0:
+        oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    else:
+        oh, ow = (h - 1) * stride - 2 * pad + k, (w - 1) * stride - 2 * pad + k
+        if out_hw is not None:
+            oh, ow = out_hw
+    y = torch.empty((batch, groups * cout_g, oh, ow), dtype=torch.float32, device=x.device)
+    if y.numel():
+        _lib.call('gg_conv2d_f32', y, x, wmat, in_scale, out_scale, bias, batch, groups, cin_g, cout_g, h, w,
+                  k, stride, pad, mode, oh if mode == 1 else 0, ow if mode == 1 else 0)
+    return y
+
+
+def conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, pad, scale=1.0):
+    """-> (groups*cout_g, cin_g, k, k) gradient of a mode-0 convolution's weight."""
+    dw = torch.empty((groups * cout_g, cin_g, k, k), dtype=torch.float32, device=x.device)
+    _lib.call('gg_conv2d_wgrad_f32', dw, x, dy, batch, groups, cin_g, cout_g, x.shape[-2], x.shape[-1], k, stride,
+              pad, scale)
+    return dw
+
+
+class _Conv2d(Function):
+    """F.conv2d / F.conv_transpose2d semantics (square 1x1 / 3x3 kernels, stride 1 or 2, dilation 1)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, groups, transposed, output_padding, wscale=1.0):
+        if x.dtype != torch.float32 or weight.dtype != torch.float32:
+            raise TypeError('conv_mfma: float32 only')
+        x = x.contiguous()
+        weight = weight.contiguous()
+        batch, cin = x.shape[0], x.shape[1]
+        k = weight.shape[-1]
+        if weight.shape[-2] != k or k not in (1, 3):
+            raise NotImplementedError(f'conv_mfma: kernel {tuple(weight.shape[-2:])} not supported (1x1 / 3x3)')
+        if stride not in (1, 2):
+            raise NotImplementedError(f'conv_mfma: stride {stride} not supported')
+        cin_g = cin // groups
+        if not transposed:
+            cout_g = weight.shape[0] // groups
+            assert weight.shape[1] == cin_g, 'weight / input channel mismatch'
+            wmat = pack_weight(weight, groups, cout_g, cin_g, k, transpose_io=0, flip=0, scale=wscale)
+            y = conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, padding, 0, bias=bias)
+        else:
+            cout_g = weight.shape[1]
+            assert weight.shape[0] == cin, 'weight / input channel mismatch'
+            if stride == 1:      # transposed stride-1 == correlation with flipped taps
+                wmat = pack_weight(weight, groups, cout_g, cin_g, k, transpose_io=1, flip=1, scale=wscale)
+                y = conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, 1, k - 1 - padding, 0, bias=bias)
+            else:
+                wmat = pack_weight(weight, groups, cout_g, cin_g, k, transpose_io=1, flip=0, scale=wscale)
+                h, w = x.shape[-2:]
+                oh = (h - 1) * 2 - 2 * padding + k + output_padding
+                ow = (w - 1) * 2 - 2 * padding + k + output_padding
+                y = conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, 2, padding, 1, bias=bias, out_hw=(oh, ow))
+        ctx.save_for_backward(x, weight)
+        ctx.conf = (stride, padding, groups, transposed, output_padding, bias is not None, cin_g, cout_g, k, wscale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, padding, groups, transposed, output_padding, has_bias, cin_g, cout_g, k, wscale = ctx.conf
+        dy = dy.contiguous()
+        batch = x.shape[0]
+        h, w = x.shape[-2:]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if not transposed:
+                if stride == 1:
+                    wm = pack_weight(weight, groups, cin_g, cout_g, k, transpose_io=1, flip=1, scale=wscale)
+                    dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, k - 1 - padding, 0)
+                else:
+                    wm = pack_weight(weight, groups, cin_g, cout_g, k, transpose_io=1, flip=0, scale=wscale)
+                    dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 1, out_hw=(h, w))
+            else:
+                if stride == 1:
+                    wm = pack_weight(weight, groups, cin_g, cout_g, k, transpose_io=0, flip=0, scale=wscale)
+                    dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, padding, 0)
+                else:
+                    wm = pack_weight(weight, groups, cin_g, cout_g, k, transpose_io=0, flip=0, scale=wscale)
+                    dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 0)
+                    dx = dx[..., :h, :w].contiguous() if dx.shape[-2:] != (h, w) else dx
+        if ctx.needs_input_grad[1]:
+            if not transposed:
+                dw = conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, padding, wscale)
+            else:
+                # dW[ci,co,ky,kx] = sum x[ci,i] * dy[co, i*s + k - p]: a mode-0 weight gradient with roles swapped
+                dw = conv_wgrad(dy, x, batch, groups, cout_g, cin_g, k, stride, padding, wscale)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=(0, 2, 3))
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, weight_scale=1.0):
+    """weight_scale folds EqualConv2d's runtime `weight * scale` (networks.py:98,112) into the weight
+    packing kernel (and into the weight gradient), saving an elementwise pass per call."""
+    if _pair_eq(dilation, 'dilation') != 1:
+        raise NotImplementedError('conv_mfma: dilation != 1')
+    return _Conv2d.apply(input, weight, bias, _pair_eq(stride, 'stride'), _pair_eq(padding, 'padding'), groups,
+                         False, 0, float(weight_scale))
+
+
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+    if _pair_eq(dilation, 'dilation') != 1:
+        raise NotImplementedError('conv_mfma: dilation != 1')
+    return _Conv2d.apply(input, weight, bias, _pair_eq(stride, 'stride'), _pair_eq(padding, 'padding'), groups,
+                         True, _pair_eq(output_padding, 'output_padding'))
+
+
+def plane_dot(a, b):
+    """(N,C,H,W) x (N,C,H,W) -> (N,C): per-plane dot products."""
+    n, c = a.shape[0], a.shape[1]
+    out = torch.empty((n, c), dtype=torch.float32, device=a.device)
+    _lib.call('gg_plane_dot_f32', out, a.contiguous(), b.contiguous(), n * c, a.numel() // max(n * c, 1))
+    return out
+
+
+class _ModulatedConv(Function):
+    """y[n,co] = demod[n,co] * conv(W*scale, style[n,ci] * x[n,ci])  - one dense conv with shared weights.
+
+    Algebraically identical to the reference's per-sample grouped convolution (networks.py:243-280;
+    SURVEY.md Appendix C.1) but with no (N,Cout,Cin,k,k) weight tensor and no per-sample weight gradient:
+    the style gradient falls out of per-plane dot products.  The generator weights are frozen on this
+    path (train.py:64-65), so no weight gradient is produced.
+      wmat_fwd / wmat_bwd: packed GEMM weights for the forward conv and its dgrad (cached by the caller)
+      wsq: (Cout,Cin) sum over taps of (W*scale)^2, for the demodulation
+    """
+
+    @staticmethod
+    def forward(ctx, x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate):
+        x = x.contiguous()
+        style = style.contiguous()
+        n, cin, h, w = x.shape
+        cout = wmat_fwd.shape[-1]
+        demod = None
+        if demodulate:
+            demod = torch.rsqrt((style * style) @ wsq.t() + 1e-8)
+        if upsample:
+            y = conv_forward(x, wmat_fwd, n, 1, cin, cout, k, 2, 0, 1, in_scale=style, out_scale=demod)
+        else:
+            y = conv_forward(x, wmat_fwd, n, 1, cin, cout, k, 1, k // 2, 0, in_scale=style, out_scale=demod)
+        ctx.save_for_backward(x, style, demod if demod is not None else style.new_empty(0), y, wmat_bwd, wsq)
+        ctx.conf = (k, upsample, demodulate)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, style, demod, y, wmat_bwd, wsq = ctx.saved_tensors
+        k, upsample, demodulate = ctx.conf
+        dy = dy.contiguous()
+        n, cin, h, w = x.shape
+        cout = y.shape[1]
+        dscale = demod if demodulate else None
+        need_style = ctx.needs_input_grad[1]
+        dx = dstyle = None
+        if ctx.needs_input_grad[0] or need_style:
+            # dx~ = dgrad(dy * demod); dx = dx~ * style.  When the style gradient is needed dx~ is kept
+            # un-scaled for the per-plane dot product; otherwise the style scale rides in the epilogue.
+            osc = None if need_style else style
+            if upsample:
+                dxt = conv_forward(dy, wmat_bwd, n, 1, cout, cin, k, 2, 0, 0, in_scale=dscale, out_scale=osc)
+                if dxt.shape[-2:] != (h, w):
+                    dxt = dxt[..., :h, :w].contiguous()
+            else:
+                dxt = conv_forward(dy, wmat_bwd, n, 1, cout, cin, k, 1, k - 1 - k // 2, 0, in_scale=dscale,
+                                   out_scale=osc)
+            if need_style:
+                dstyle = plane_dot(dxt, x)
+                if demodulate:
+                    ddemod = plane_dot(dy, y) / demod                       # d loss / d demod
+                    dsq = ddemod * (-0.5) * demod * demod * demod           # through rsqrt
+                    dstyle = dstyle + 2.0 * style * (dsq @ wsq)
+                dx = dxt * style.view(n, cin, 1, 1) if ctx.needs_input_grad[0] else None
+            else:
+                dx = dxt
+        return dx, dstyle, None, None, None, None, None, None
+
+
+def modulated_conv2d(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample=False, demodulate=True):
+    return _ModulatedConv.apply(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate)

@@ -1,0 +1,87 @@
+"""FusedLeakyReLU / fused_leaky_relu - same names, signatures and parameter layout as
+models/stylegan2/op/fused_act.py:74-97, running csrc/fused_bias_act.hip.
+
+Differences from the reference that do not change results: the backward computes grad_input and
+the bias gradient in ONE kernel (gg_fused_lrelu_bwd); the reference launches the activation
+kernel and then a separate torch reduction (:27-38).  As in the reference the saved tensor is the
+OUTPUT (sign reference), and second-order gradients are supported (:43-49).
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from .. import _lib
+
+_SUFFIX = {torch.float32: 'f32', torch.float64: 'f64'}
+
+
+def _bias_act(x, bias, ref, act, grad, alpha, scale):
+    """Mirror of fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)
+    (fused_bias_act.cpp:11-21); empty tensors / None mean "absent"."""
+    if x.dtype not in _SUFFIX:
+        raise TypeError(f'fused_bias_act: unsupported dtype {x.dtype}')
+    x = x.contiguous()
+    bias = None if bias is None or bias.numel() == 0 else bias.to(x.dtype).contiguous()
+    ref = None if ref is None or ref.numel() == 0 else ref.contiguous()
+    out = torch.empty_like(x)
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    _lib.call('gg_fused_bias_act_' + _SUFFIX[x.dtype], out, x, bias, ref, act, grad, alpha, scale,
+              x.numel(), step_b, 0 if bias is None else bias.numel())
+    return out
+
+
+class FusedLeakyReLUFunctionBackward(Function):
+    @staticmethod
+    def forward(ctx, grad_output, out, negative_slope, scale):
+        ctx.save_for_backward(out)
+        ctx.negative_slope = negative_slope
+        ctx.scale = scale
+        grad_output = grad_output.contiguous()
+        n, c = out.shape[0], out.shape[1]
+        hw = out.numel() // max(n * c, 1)
+        grad_input = torch.empty_like(grad_output)
+        grad_bias = torch.empty(c, dtype=out.dtype, device=out.device)
+        _lib.call('gg_fused_lrelu_bwd_' + _SUFFIX[out.dtype], grad_input, grad_bias, grad_output, out,
+                  negative_slope, scale, n, c, hw)
+        return grad_input, grad_bias
+
+    @staticmethod
+    def backward(ctx, gradgrad_input, gradgrad_bias):
+        (out,) = ctx.saved_tensors
+        gradgrad_out = _bias_act(gradgrad_input, gradgrad_bias, out, 3, 1, ctx.negative_slope, ctx.scale)
+        return gradgrad_out, None, None, None
+
+
+class FusedLeakyReLUFunction(Function):
+    @staticmethod
+    def forward(ctx, input, bias, negative_slope, scale):
+        out = _bias_act(input, bias, None, 3, 0, negative_slope, scale)
+        ctx.save_for_backward(out)
+        ctx.negative_slope = negative_slope
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (out,) = ctx.saved_tensors
+        grad_input, grad_bias = FusedLeakyReLUFunctionBackward.apply(grad_output, out, ctx.negative_slope, ctx.scale)
+        return grad_input, grad_bias, None, None
+
+
+class FusedLeakyReLU(nn.Module):
+    def __init__(self, channel, negative_slope=0.2, scale=2 ** 0.5):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(channel))
+        self.negative_slope = negative_slope
+        self.scale = scale
+
+    def forward(self, input):
+        return fused_leaky_relu(input, self.bias.type(input.dtype), self.negative_slope, self.scale)
+
+
+def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
+    if input.device.type != 'cuda':
+        raise _lib.HipLibraryError('fused_leaky_relu: HIP tensors only (CPU restatement: oracle/np_ops.fused_leaky_relu)')
+    return FusedLeakyReLUFunction.apply(input, bias, negative_slope, scale)

@@ -1,0 +1,185 @@
+"""MipmapWarp / Warp / BilinearDownsample with the class names, constructor arguments, buffers and
+forward signatures of models/spatial_transformers/antialiased_sampling.py, running the fused HIP
+kernels of csrc/mipmap_warp.hip and csrc/stn_ops.hip.
+
+What changes under the hood (results are the same, see tests/test_gpu_parity.py):
+  * no (N, C*D, H, W) Gaussian stack and no `.item()` host sync (antialiased_sampling.py:52): the
+    un-upsampled pyramid (3 small launches) is sampled directly, the per-pixel level is computed in
+    the sampling kernel;
+  * one backward kernel produces the grid gradient, including the term that flows through the
+    fractional mip level; the image gradient is produced only when the input requires it.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from .. import _lib
+
+_PAD_MODES = {'zeros': 0, 'border': 1, 'reflection': 2}
+
+
+def _check(t, name):
+    if t.device.type != 'cuda':
+        raise _lib.HipLibraryError(f'{name}: HIP tensors only (CPU restatement: oracle/np_ops.py)')
+    if t.dtype != torch.float32:
+        raise TypeError(f'{name}: float32 only, got {t.dtype}')
+
+
+def _build_pyramid(base, levels=4):
+    """base (N,C,S,S), S a power of two -> [base, down(base), ...] (un-upsampled Gaussian pyramid)."""
+    pyr = [base]
+    n, c, h, w = base.shape
+    for _ in range(1, levels):
+        nxt = torch.empty((n, c, h // 2, w // 2), dtype=base.dtype, device=base.device)
+        _lib.call('gg_mip_downsample2x_f32', nxt, pyr[-1], n * c, h, w)
+        pyr.append(nxt)
+        h, w = h // 2, w // 2
+    return pyr
+
+
+class _MipmapWarpFn(Function):
+    @staticmethod
+    def forward(ctx, inputs, grid, max_level, min_level, padding_mode, antialias):
+        _check(inputs, 'MipmapWarp')
+        _check(grid, 'MipmapWarp')
+        inputs = inputs.contiguous()
+        grid = grid.contiguous()
+        n, c, h, w = inputs.shape
+        ho, wo = grid.shape[1], grid.shape[2]
+        pad_l = 0
+        base = inputs
+        if antialias:
+            if h != w:
+                raise NotImplementedError('MipmapWarp expects square inputs (as the reference: antialiased_sampling.py:128)')
+            log_size = np.log2(w)
+            if not float(log_size).is_integer():      # reflect-pad to the next power of two (:130-137)
+                target = int(2 ** np.ceil(log_size))
+                total = target - w
+                pad_l = int(total // 2)
+                pad_r = int(total - pad_l)
+                base = F.pad(inputs, (pad_l, pad_r, pad_l, pad_r), mode='reflect').contiguous()
+            pyr = _build_pyramid(base, 4)
+        else:
+            pyr = [base, None, None, None]
+        hp, wp = base.shape[-2:]
+        out = torch.empty((n, c, ho, wo), dtype=inputs.dtype, device=inputs.device)
+        levels = torch.empty((n, ho, wo), dtype=inputs.dtype, device=inputs.device)
+        _lib.call('gg_mipmap_warp_fwd_f32', out, levels, pyr[0], pyr[1], pyr[2], pyr[3], grid, n, c, h, w, hp, wp,
+                  pad_l, ho, wo, max_level, min_level, _PAD_MODES[padding_mode], int(antialias))
+        ctx.save_for_backward(grid, *[p for p in pyr if p is not None])
+        ctx.conf = (n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, _PAD_MODES[padding_mode], int(antialias))
+        ctx.mark_non_differentiable(levels)
+        return out, levels
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_levels):
+        grid, *pyr = ctx.saved_tensors
+        n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, pm, antialias = ctx.conf
+        pyr = list(pyr) + [None] * (4 - len(pyr))
+        grad_out = grad_out.contiguous()
+        grad_grid = torch.empty_like(grid)
+        want_img = ctx.needs_input_grad[0]
+        gp = [None] * 4
+        if want_img:
+            gp = [torch.zeros_like(p) if p is not None else None for p in pyr]
+        _lib.call('gg_mipmap_warp_bwd_f32', grad_grid, gp[0], gp[1], gp[2], gp[3], grad_out, pyr[0], pyr[1], pyr[2],
+                  pyr[3], grid, n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, pm, antialias)
+        grad_in = None
+        if want_img:
+            if antialias:   # fold the pyramid gradients back: g[l-1] += down2x^T(g[l])
+                for lvl in (3, 2, 1):
+                    _lib.call('gg_mip_downsample2x_bwd_f32', gp[lvl - 1], gp[lvl], n * c, hp >> (lvl - 1), wp >> (lvl - 1))
+            grad_in = gp[0]
+            if pad_l or hp != h:
+                # adjoint of the reflect pad: fold the border gradients back onto the image
+                full = grad_in
+                pad_r = hp - h - pad_l
+                grad_in = _reflect_pad_adjoint(full, pad_l, pad_r)
+        return grad_in, grad_grid, None, None, None, None
+
+
+def _reflect_pad_adjoint(g, pad_l, pad_r):
+    """Adjoint of F.pad(x, (l,r,l,r), mode='reflect') via autograd of the pad itself (rare path:
+    non power-of-two inputs only)."""
+    n, c, hp, wp = g.shape
+    h, w = hp - pad_l - pad_r, wp - pad_l - pad_r
+    x = torch.zeros((n, c, h, w), dtype=g.dtype, device=g.device, requires_grad=True)
+    with torch.enable_grad():
+        y = F.pad(x, (pad_l, pad_r, pad_l, pad_r), mode='reflect')
+    (gx,) = torch.autograd.grad(y, x, g)
+    return gx
+
+
+class Warp(nn.Module):
+    """Spatial transform without anti-aliasing == F.grid_sample(..., align_corners=False) (:9-16)."""
+
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, inputs, grid, padding_mode='border'):
+        out, _ = _MipmapWarpFn.apply(inputs, grid, 0.0, 0.0, padding_mode, False)
+        return out
+
+
+class MipmapWarp(nn.Module):
+    """Spatial transform with mipmap anti-aliasing; analogous to grid_sample() (:19-60)."""
+
+    def __init__(self, max_num_levels=8):
+        super().__init__()
+        self.max_num_levels = max_num_levels
+        blur = np.array([1., 3., 3., 1.])
+        blur = torch.Tensor(blur[:, None] * blur[None, :])
+        blur = blur / torch.sum(blur)
+        self.register_buffer('blur_filter', blur[None, None, ...])     # kept for state_dict compatibility
+        self.levels_map = None
+        if max_num_levels - 1.0 > 3.0:
+            raise NotImplementedError('MipmapWarp: the fused kernel keeps 4 pyramid levels (max_num_levels <= 4); '
+                                      'the heads use 3.5 (warping_heads.py:32,170)')
+
+    def forward(self, inputs, grid, min_level=0.0, padding_mode='border'):
+        out, levels = _MipmapWarpFn.apply(inputs, grid, float(self.max_num_levels - 1.0), float(min_level),
+                                          padding_mode, True)
+        self.levels_map = levels / (self.max_num_levels - 1.0)
+        return out
+
+
+class _BilinearDownsampleFn(Function):
+    @staticmethod
+    def forward(ctx, x, stride):
+        _check(x, 'BilinearDownsample')
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        r = stride // 2
+        oh = (h + 2 * r - 2 * stride) // stride + 1
+        ow = (w + 2 * r - 2 * stride) // stride + 1
+        out = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device)
+        _lib.call('gg_bilinear_downsample_f32', out, x, n * c, h, w, stride)
+        ctx.conf = (n, c, h, w, stride)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        n, c, h, w, stride = ctx.conf
+        gx = torch.empty((n, c, h, w), dtype=grad_out.dtype, device=grad_out.device)
+        _lib.call('gg_bilinear_downsample_bwd_f32', gx, grad_out.contiguous(), n * c, h, w, stride)
+        return gx, None
+
+
+class BilinearDownsample(nn.Module):
+    """Tent-filtered strided downsample (:241-256).  Buffers kernel_horz / kernel_vert are kept so
+    reference checkpoints load; the kernel itself recomputes the taps."""
+
+    def __init__(self, stride, channels):
+        super().__init__()
+        self.stride = stride
+        self.channels = channels
+        kernel = np.arange(1, 2 * stride + 1, 2)
+        kernel = np.concatenate((kernel, kernel[::-1]))
+        kernel = torch.Tensor(kernel / np.sum(kernel))
+        self.register_buffer('kernel_horz', kernel[None, None, None, :].repeat((self.channels, 1, 1, 1)))
+        self.register_buffer('kernel_vert', kernel[None, None, :, None].repeat((self.channels, 1, 1, 1)))
+
+    def forward(self, input):
+        return _BilinearDownsampleFn.apply(input, self.stride)

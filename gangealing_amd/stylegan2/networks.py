@@ -1,0 +1,347 @@
+"""StyleGAN2 generator and the conv blocks shared with the STN, built on the HIP operators.
+
+Module / parameter / buffer names follow models/stylegan2/networks.py so that reference
+state_dicts (``g_ema``, ``t``, ``t_ema``; train.py:22-28) load unchanged.  What differs is how the
+layers execute on MI355X:
+
+  * ModulatedConv2d runs ONE dense implicit-GEMM convolution with shared weights: the style scales
+    the activation as it is gathered and the demodulation scales the accumulator in the epilogue
+    (op/conv_mfma.py).  The reference materialises (N,Cout,Cin,k,k) weights
+    and runs a per-sample grouped convolution (networks.py:243-280).
+  * packed GEMM weights and the (Cout,Cin) squared-weight table are cached per weight version: the
+    generator is frozen during GANgealing training (train.py:64-65), so they are built once.
+  * EqualConv2d folds its runtime ``weight * scale`` into the weight-packing kernel.
+The fp16 ``normalize`` branch of the reference (networks.py:237-242) is not implemented: every
+GANgealing recipe runs fp32 (num_fp16_res=0, run_fp32=True; networks.py:406,572).
+"""
+import math
+import random
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from ..op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
+from ..op import conv_mfma
+
+
+class PixelNorm(nn.Module):
+    def forward(self, input):
+        return input * torch.rsqrt(torch.mean(input ** 2, dim=1, keepdim=True) + 1e-8)
+
+
+def make_kernel(k):
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = k[None, :] * k[:, None]
+    k /= k.sum()
+    return k
+
+
+class Upsample(nn.Module):
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer('kernel', make_kernel(kernel) * (factor ** 2))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel.type(input.dtype), up=self.factor, down=1, pad=self.pad)
+
+
+class Downsample(nn.Module):
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer('kernel', make_kernel(kernel))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel.type(input.dtype), up=1, down=self.factor, pad=self.pad)
+
+
+class Blur(nn.Module):
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        kernel = make_kernel(kernel)
+        if upsample_factor > 1:
+            kernel = kernel * (upsample_factor ** 2)
+        self.register_buffer('kernel', kernel)
+        self.pad = pad
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel.type(input.dtype), pad=self.pad)
+
+
+class EqualConv2d(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.stride = stride
+        self.padding = padding
+        self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+    def forward(self, input):
+        return conv_mfma.conv2d(input, self.weight, bias=self.bias, stride=self.stride, padding=self.padding,
+                                weight_scale=self.scale)
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]},'
+                f' {self.weight.shape[2]}, stride={self.stride}, padding={self.padding})')
+
+
+class EqualLinear(nn.Module):
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, input):
+        if self.activation:
+            out = F.linear(input, self.weight * self.scale)
+            return fused_leaky_relu(out, self.bias * self.lr_mul)
+        return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})'
+
+
+class ScaledLeakyReLU(nn.Module):
+    def __init__(self, negative_slope=0.2):
+        super().__init__()
+        self.negative_slope = negative_slope
+
+    def forward(self, input):
+        return F.leaky_relu(input, negative_slope=self.negative_slope) * math.sqrt(2)
+
+
+class ModulatedConv2d(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 downsample=False, blur_kernel=(1, 3, 3, 1), normalize=False):
+        super().__init__()
+        if downsample:
+            raise NotImplementedError('ModulatedConv2d(downsample=True) is not used by the generator')
+        if normalize:
+            raise NotImplementedError('fp16 normalize branch (networks.py:237-242) is off on every GANgealing recipe')
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.upsample = upsample
+        self.downsample = downsample
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(list(blur_kernel), pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+        self._packed = None        # (weight version, device, wmat_fwd, wmat_bwd, wsq)
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, '
+                f'upsample={self.upsample}, downsample={self.downsample})')
+
+    def _weights(self):
+        w = self.weight
+        key = (w._version, w.device, w.data_ptr())
+        if self._packed is None or self._packed[0] != key:
+            if w.requires_grad and torch.is_grad_enabled():
+                raise NotImplementedError('the fused modulated convolution treats the generator weights as frozen '
+                                          '(train.py:64-65); call requires_grad_(False) on the generator')
+            with torch.no_grad():
+                w4 = w[0]
+                k, cin, cout = self.kernel_size, self.in_channel, self.out_channel
+                wmat_fwd = conv_mfma.pack_weight(w4, 1, cout, cin, k, transpose_io=0, flip=0, scale=self.scale)
+                # dgrad: reduce over co.  plain conv -> flipped taps; transposed stride-2 conv -> strided correlation
+                wmat_bwd = conv_mfma.pack_weight(w4, 1, cin, cout, k, transpose_io=1, flip=0 if self.upsample else 1,
+                                                 scale=self.scale)
+                wsq = (w4 * self.scale).pow(2).sum(dim=(2, 3)).contiguous()
+            self._packed = (key, wmat_fwd, wmat_bwd, wsq)
+        return self._packed[1:]
+
+    def forward(self, input, style):
+        style = self.modulation(style)                                  # (N, Cin)
+        wmat_fwd, wmat_bwd, wsq = self._weights()
+        out = conv_mfma.modulated_conv2d(input, style, wmat_fwd, wmat_bwd, wsq, self.kernel_size,
+                                         upsample=self.upsample, demodulate=self.demodulate)
+        if self.upsample:
+            out = self.blur(out)
+        return out
+
+
+class NoiseInjection(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+    def forward(self, image, noise=None):
+        if noise is None:
+            batch, _, height, width = image.shape
+            noise = image.new_empty(batch, 1, height, width).normal_()
+        else:
+            noise = noise.type(image.dtype)
+        return image + self.weight.type(image.dtype) * noise
+
+
+class ConstantInput(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+        self.size = size
+
+    def forward(self, input):
+        return self.input.repeat(input.shape[0], 1, 1, 1)
+
+
+class StyledConv(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=(1, 3, 3, 1),
+                 demodulate=True, normalize=False):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate, normalize=normalize)
+        self.noise = NoiseInjection()
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, input, style, noise=None):
+        out = self.conv(input, style)
+        out = self.noise(out, noise=noise)
+        return self.activate(out)
+
+
+class ToRGB(nn.Module):
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=(1, 3, 3, 1), normalize=False):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(list(blur_kernel))
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False, normalize=normalize)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+    def forward(self, input, style, skip=None):
+        out = self.conv(input, style) + self.bias.type(input.dtype)
+        if skip is not None:
+            out = out.float() + self.upsample(skip)
+        return out
+
+
+class ConvLayer(nn.Sequential):
+    def __init__(self, in_channel, out_channel, kernel_size, downsample=False, blur_kernel=(1, 3, 3, 1), bias=True,
+                 activate=True):
+        layers = []
+        if downsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) + (kernel_size - 1)
+            layers.append(Blur(list(blur_kernel), pad=((p + 1) // 2, p // 2)))
+            stride = 2
+            self.padding = 0
+        else:
+            stride = 1
+            self.padding = kernel_size // 2
+        layers.append(EqualConv2d(in_channel, out_channel, kernel_size, padding=self.padding, stride=stride,
+                                  bias=bias and not activate))
+        if activate:
+            layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
+        super().__init__(*layers)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channel, out_channel, blur_kernel=(1, 3, 3, 1), downsample=True):
+        super().__init__()
+        self.conv1 = ConvLayer(in_channel, in_channel, 3)
+        self.conv2 = ConvLayer(in_channel, out_channel, 3, downsample=downsample)
+        self.skip = ConvLayer(in_channel, out_channel, 1, downsample=downsample, activate=False, bias=False)
+
+    def forward(self, input):
+        out = self.conv2(self.conv1(input))
+        return (out + self.skip(input)) / math.sqrt(2)
+
+
+CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
+
+
+class Generator(nn.Module):
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=(1, 3, 3, 1), lr_mlp=0.01,
+                 num_fp16_res=0, run_fp32=True):
+        super().__init__()
+        if num_fp16_res != 0 and not run_fp32:
+            raise NotImplementedError('fp16 generator layers are not part of the GANgealing recipes')
+        self.size = size
+        self.style_dim = style_dim
+        self.style = nn.Sequential(PixelNorm(), *[
+            EqualLinear(style_dim, style_dim, lr_mul=lr_mlp, activation='fused_lrelu') for _ in range(n_mlp)])
+        self.channels = {r: (c if r <= 32 else c * channel_multiplier) for r, c in CHANNELS.items()}
+        self.input = ConstantInput(self.channels[4])
+        self.conv1 = StyledConv(self.channels[4], self.channels[4], 3, style_dim, blur_kernel=blur_kernel)
+        self.to_rgb1 = ToRGB(self.channels[4], style_dim, upsample=False)
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        self.convs = nn.ModuleList()
+        self.upsamples = nn.ModuleList()
+        self.to_rgbs = nn.ModuleList()
+        self.noises = nn.Module()
+        for layer_idx in range(self.num_layers):
+            res = (layer_idx + 5) // 2
+            self.noises.register_buffer(f'noise_{layer_idx}', torch.randn(1, 1, 2 ** res, 2 ** res))
+        in_channel = self.channels[4]
+        for i in range(3, self.log_size + 1):
+            out_channel = self.channels[2 ** i]
+            self.convs.append(StyledConv(in_channel, out_channel, 3, style_dim, upsample=True, blur_kernel=blur_kernel))
+            self.convs.append(StyledConv(out_channel, out_channel, 3, style_dim, blur_kernel=blur_kernel))
+            self.to_rgbs.append(ToRGB(out_channel, style_dim))
+            in_channel = out_channel
+        self.n_latent = self.log_size * 2 - 2
+        self.num_fp16_res = num_fp16_res
+        self.run_fp32 = run_fp32
+
+    def make_noise(self, batch_size=1):
+        device = self.input.input.device
+        noises = [torch.randn(batch_size, 1, 4, 4, device=device)]
+        for i in range(3, self.log_size + 1):
+            noises += [torch.randn(batch_size, 1, 2 ** i, 2 ** i, device=device) for _ in range(2)]
+        return noises
+
+    def batch_latent(self, n_latent):
+        return self.style(torch.randn(n_latent, self.style_dim, device=self.input.input.device))
+
+    def mean_latent(self, n_latent):
+        return self.batch_latent(n_latent).mean(dim=0, keepdim=True)
+
+    def get_latent(self, input):
+        return self.style(input)
+
+    def forward(self, styles, mapping_only=False, return_latents=False, inject_index=None, truncation=1,
+                truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=True):
+        if not input_is_latent:
+            styles = [self.style(s) for s in styles]
+            if mapping_only:
+                return styles
+        if noise is None:
+            noise = [None] * self.num_layers if randomize_noise else \
+                [getattr(self.noises, f'noise_{i}') for i in range(self.num_layers)]
+        if truncation < 1:
+            styles = [truncation_latent + truncation * (styles[0] - truncation_latent), styles[0]]
+        if len(styles) < 2 or inject_index == self.n_latent:
+            latent = styles[0] if styles[0].ndim >= 3 else styles[0].unsqueeze(1).repeat(1, self.n_latent, 1)
+        else:
+            if inject_index is None:
+                inject_index = random.randint(1, self.n_latent - 1)
+            latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                                styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
+        out = self.conv1(self.input(latent), latent[:, 0], noise=noise[0])
+        skip = self.to_rgb1(out, latent[:, 1])
+        i = 1
+        for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2],
+                                                       self.to_rgbs):
+            out = conv_up(out, latent[:, i], noise=n_up)
+            out = conv(out, latent[:, i + 1], noise=n_conv)
+            skip = to_rgb(out, latent[:, i + 2], skip)
+            i += 2
+        return (skip, latent) if return_latents else (skip, None)

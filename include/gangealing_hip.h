@@ -1,0 +1,218 @@
+/*
+ * gangealing_hip.h - C ABI of the MI355X (gfx950) GANgealing hot-path library
+ * (libgangealing_hip.so, built from gangealing_amd/csrc/ with hipcc --offload-arch=gfx950).
+ *
+ * This is the drop-in boundary.  Every entry point takes plain device pointers, sizes and a
+ * hipStream_t passed as void* (0 = the null stream); there are no torch types in any signature.
+ * Each function cites the reference interface it replaces (paths relative to wpeebles/gangealing).
+ *
+ * Conventions
+ *   - return value: 0 on success; otherwise a hipError_t value (> 0) or a negative argument-error
+ *     code.  gg_last_error() returns a thread-local, NUL-terminated description.
+ *   - all tensors are dense row-major ("contiguous" in torch terms); NCHW unless noted.
+ *   - kernels are enqueued on `stream` and never synchronise; nothing is allocated internally
+ *     (workspaces are caller-provided), so every call is hipGraph-capturable.
+ *   - outputs are fully overwritten unless the comment says "accumulates".
+ */
+#ifndef GANGEALING_HIP_H
+#define GANGEALING_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int gg_abi_version(void);
+const char* gg_last_error(void);
+/* Name of the gfx target the device code was built for ("gfx950"). */
+const char* gg_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * a2  fused bias + activation.
+ * Replaces fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)
+ *   (models/stylegan2/op/fused_bias_act.cpp:11-21, fused_bias_act_kernel.cu:18-99):
+ *   v = x[i] + bias[(i / step_b) % size_b];  y = f(v) * scale, f selected by act*10+grad:
+ *   act 1 = linear, act 3 = leaky relu with slope alpha; grad 1 uses `ref` as sign reference,
+ *   grad 2 yields 0.  bias / ref may be NULL ("empty tensor" in the reference).
+ * ------------------------------------------------------------------------------------------ */
+int gg_fused_bias_act_f32(float* out, const float* x, const float* bias, const float* ref,
+                          int act, int grad, float alpha, float scale,
+                          long long size_x, long long step_b, int size_b, void* stream);
+int gg_fused_bias_act_f64(double* out, const double* x, const double* bias, const double* ref,
+                          int act, int grad, double alpha, double scale,
+                          long long size_x, long long step_b, int size_b, void* stream);
+
+/* Backward of fused_leaky_relu in ONE pass: grad_in = (out > 0 ? g : alpha*g) * scale and
+ * grad_bias[c] = sum_{n,hw} grad_in (the reference re-reads grad_in in a second torch reduction,
+ * models/stylegan2/op/fused_act.py:22-40).  Tensors are (n, c, hw) dense; grad_bias (c,) is
+ * overwritten.  grad_bias may be NULL to skip the reduction. */
+int gg_fused_lrelu_bwd_f32(float* grad_in, float* grad_bias, const float* grad_out, const float* out,
+                           float alpha, float scale, int n, int c, long long hw, void* stream);
+int gg_fused_lrelu_bwd_f64(double* grad_in, double* grad_bias, const double* grad_out, const double* out,
+                           double alpha, double scale, int n, int c, long long hw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a1  upfirdn2d.
+ * Replaces upfirdn2d_op.upfirdn2d(input[M,H,W,1], kernel[kh,kw], up_x, up_y, down_x, down_y,
+ *   pad_x0, pad_x1, pad_y0, pad_y1) -> [M,out_h,out_w,1]
+ *   (models/stylegan2/op/upfirdn2d.cpp:12-23, upfirdn2d_kernel.cu:209-368), minor_dim == 1
+ *   (always, on this path: upfirdn2d.py:101).  out_h = (in_h*up_y + pad_y0 + pad_y1 - kh)/down_y + 1.
+ * `out` must hold major * out_h * out_w elements.  The backward pass is the same entry point with
+ * up<->down, flipped taps and g_pad (upfirdn2d.py:21-62).
+ * ------------------------------------------------------------------------------------------ */
+int gg_upfirdn2d_f32(float* out, const float* in, const float* kernel,
+                     int major, int in_h, int in_w, int kernel_h, int kernel_w,
+                     int up_x, int up_y, int down_x, int down_y,
+                     int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+int gg_upfirdn2d_f64(double* out, const double* in, const double* kernel,
+                     int major, int in_h, int in_w, int kernel_h, int kernel_w,
+                     int up_x, int up_y, int down_x, int down_y,
+                     int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a11  splat2d.
+ * gg_splat_forward_f32 replaces
+ *   extern "C" void SplatForwardGpu(stream, coords, values, sigma, alpha_splats, output,
+ *                                   num_points, channels, height, width, top_count)
+ *   (utils/splat2d_cuda/src/splat_gpu_impl.cuh:11-22, splat_gpu_impl.cu:41-122): accumulates
+ *   Gaussian weights into alpha_splats (N,H,W) and weight*value into output (N,C,H,W).
+ * gg_splat2d_f32 replaces splat_forward_cuda (splat_gpu.c:12-42): output = clone(input) + splats,
+ *   then output /= ((soft_normalize ? max(alpha,1) : alpha) + 1e-8).  alpha_ws is an (N,H,W)
+ *   caller-provided workspace.
+ * ------------------------------------------------------------------------------------------ */
+int gg_splat_forward_f32(const float* coords, const float* values, const float* sigma,
+                         float* alpha_splats, float* output,
+                         int num_points, int channels, int height, int width, int top_count, void* stream);
+int gg_splat2d_f32(float* output, float* alpha_ws, const float* input, const float* coords,
+                   const float* values, const float* sigma, int n, int num_points, int channels,
+                   int height, int width, int soft_normalize, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a6  anti-aliased sampling (MipmapWarp / Warp), models/spatial_transformers/antialiased_sampling.py.
+ * padding_mode: 0 zeros, 1 border, 2 reflection (F.grid_sample, align_corners=False).
+ * ------------------------------------------------------------------------------------------ */
+/* One pyramid step: ReflectionPad2d(1) + depthwise [1,3,3,1]^2/64 stride 2 (:111-117).
+ * in (planes,h,w) -> out (planes,h/2,w/2); h, w even. */
+int gg_mip_downsample2x_f32(float* out, const float* in, int planes, int h, int w, void* stream);
+/* Adjoint of the above: grad_in (planes,h,w) ACCUMULATES (+=) the back-projection of grad_out. */
+int gg_mip_downsample2x_bwd_f32(float* grad_in, const float* grad_out, int planes, int h, int w, void* stream);
+
+/* MipmapWarp.forward (:35-60) without materialising the (N,C*D,H,W) Gaussian stack: per output
+ * pixel the mip level is computed from the grid (:62-97,181-210), the two bracketing levels are
+ * sampled straight from the pyramid (bilinear upsample :155-160 folded into the tap fetch) and
+ * blended (:212-238).
+ *   pyr[l]      level-l image (N,C,hp>>l,wp>>l), l = 0..3; pyr[0] is the (reflect-padded to a power
+ *               of two, :130-137) input; hp, wp its size; pad_l the left/top pad (0 when h is 2^k)
+ *   h, w        size of the ORIGINAL input (sampling coordinates refer to it)
+ *   grid        (N,ho,wo,2) normalised coordinates
+ *   out         (N,C,ho,wo);  levels_out (N,ho,wo) receives the clamped fractional level
+ *   antialias   0 -> plain Warp (:9-16): level 0 everywhere
+ *   max_level   = max_num_levels - 1 (2.5 for the heads, warping_heads.py:32,170)
+ */
+int gg_mipmap_warp_fwd_f32(float* out, float* levels_out,
+                           const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3,
+                           const float* grid, int n, int c, int h, int w, int hp, int wp, int pad_l,
+                           int ho, int wo, float max_level, float min_level,
+                           int padding_mode, int antialias, void* stream);
+/* Backward.  grad_grid (N,ho,wo,2) is overwritten; grad_pyr{0..3} ACCUMULATE (pass NULL for all four
+ * to skip the image gradient).  Includes the gradient that reaches the grid through the fractional
+ * mip level (levels % 1.0 is differentiable in the reference's autograd graph). */
+int gg_mipmap_warp_bwd_f32(float* grad_grid, float* grad_pyr0, float* grad_pyr1, float* grad_pyr2, float* grad_pyr3,
+                           const float* grad_out,
+                           const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3,
+                           const float* grid, int n, int c, int h, int w, int hp, int wp, int pad_l,
+                           int ho, int wo, float max_level, float min_level,
+                           int padding_mode, int antialias, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a7  F.affine_grid(theta (N,2,3), (N,C,ho,wo), align_corners=False) (warping_heads.py:135,176)
+ *     grid[n,i,j] = theta[n] . [x_j, y_i, 1],  x_j = linspace(-1,1,wo)[j]*(wo-1)/wo.
+ * bwd: grad_theta (N,2,3) overwritten.
+ * ------------------------------------------------------------------------------------------ */
+int gg_affine_grid_f32(float* grid, const float* theta, int n, int ho, int wo, void* stream);
+int gg_affine_grid_bwd_f32(float* grad_theta, const float* grad_grid, int n, int ho, int wo, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a8  flow composition of FlowHead.forward (warping_heads.py:180-193,239-243,268-277):
+ *     delta = convex_upsample(low_flow, softmax_9(mask));  flow = identity + delta;
+ *     flow  = [flow,1] @ base^T  (when base != NULL)
+ *   low_flow (N,2,hl,wl)  - the flow_out conv output, channel-major (the reference permutes it to
+ *                           (N,hl,wl,2) first, :198-199; reading NCHW directly removes that copy)
+ *   mask     (N,9*ds*ds,hl,wl), ds = 8
+ *   base     (N,2,3) or NULL
+ *   delta, flow (N,ds*hl,ds*wl,2)
+ * bwd: grad_low, grad_mask overwritten; grad_base (N,2,3) overwritten (NULL when base is NULL);
+ *      g_flow / g_delta may each be NULL (treated as zero).
+ * ------------------------------------------------------------------------------------------ */
+int gg_flow_compose_fwd_f32(float* delta, float* flow, const float* low_flow, const float* mask,
+                            const float* base, int n, int hl, int wl, int ds, void* stream);
+int gg_flow_compose_bwd_f32(float* grad_low, float* grad_mask, float* grad_base,
+                            const float* g_flow, const float* g_delta,
+                            const float* low_flow, const float* mask, const float* base,
+                            int n, int hl, int wl, int ds, void* stream);
+
+/* Bilinear resize of a (N,hi,wi,2) flow field by `scale` = ho/hi (F.interpolate(scale_factor=...,
+ * mode='bilinear', align_corners=False) on the permuted flow, warping_heads.py:250).  bwd accumulates
+ * nothing: grad_in is overwritten. */
+int gg_flow_resize_f32(float* out, const float* in, int n, int hi, int wi, int ho, int wo, float scale, void* stream);
+int gg_flow_resize_bwd_f32(float* grad_in, const float* grad_out, int n, int hi, int wi, int ho, int wo, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a9  BilinearDownsample(stride).forward (antialiased_sampling.py:241-256): reflect-pad stride/2,
+ *     separable tent [1,3,..,3,1]/sum, decimate by stride.  in (planes,h,w) -> out (planes,h/stride,w/stride).
+ * ------------------------------------------------------------------------------------------ */
+int gg_bilinear_downsample_f32(float* out, const float* in, int planes, int h, int w, int stride, void* stream);
+int gg_bilinear_downsample_bwd_f32(float* grad_in, const float* grad_out, int planes, int h, int w, int stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a10  flow regularisers (models/losses/loss.py:4-18) in one pass over delta (N,hf,wf,2):
+ *      losses[0] = total_variation_loss (Huber(1) of forward differences, mean over each difference
+ *      tensor, x + y), losses[1] = flow_identity_loss (mean square).  losses (2,) overwritten.
+ * bwd: grad_delta = g_tv * dTV/ddelta + g_id * dID/ddelta  (g_* are the upstream scalars, on device).
+ * ------------------------------------------------------------------------------------------ */
+int gg_flow_losses_f32(float* losses, const float* delta, int n, int hf, int wf, void* stream);
+int gg_flow_losses_bwd_f32(float* grad_delta, const float* delta, const float* g_losses, int n, int hf, int wf, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a3/a4  convolutions as implicit GEMM on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32).
+ * Replaces conv2d_gradfix.conv2d / conv_transpose2d (models/stylegan2/op/conv2d_gradfix.py:22-75)
+ * and, through in_scale / out_scale, the modulate / demodulate arithmetic of
+ * ModulatedConv2d.forward (models/stylegan2/networks.py:233-282) in its shared-weight form:
+ *     y[n,co] = out_scale[n,co] * sum_{ci,ky,kx} W[co,ci,ky,kx] * (in_scale[n,ci] * x[n,ci,..])
+ *
+ * Weights are consumed in GEMM layout wmat (groups, K, Cout) with K = Cin_g*kh*kw ordered
+ * (ci, ky, kx), produced by gg_conv_pack_weight_f32 from the torch layout.
+ *   x        (batch, groups*cin_g, h, w)
+ *   y        (batch, groups*cout_g, ho, wo)
+ *   in_scale (batch, groups*cin_g) or NULL;  out_scale (batch, groups*cout_g) or NULL
+ *   bias     (groups*cout_g) or NULL, added after out_scale
+ *   mode 0: correlation  ho = (h + 2*pad - k)/stride + 1
+ *   mode 1: transposed   ho = (h-1)*stride - 2*pad + k      (stride 2; stride-1 transposed convolution is
+ *           mode 0 with flipped taps).  out_h / out_w: 0 = natural size; for mode 1 a value up to
+ *           natural + stride - 1 plays the role of output_padding (extra rows / columns are zero).
+ *   ksize in {1, 3}.
+ * ------------------------------------------------------------------------------------------ */
+int gg_conv_pack_weight_f32(float* wmat, const float* w, int groups, int cout_g, int cin_g, int kh, int kw,
+                            int transpose_io, int flip, float scale, void* stream);
+int gg_conv2d_f32(float* y, const float* x, const float* wmat, const float* in_scale, const float* out_scale,
+                  const float* bias, int batch, int groups, int cin_g, int cout_g, int h, int w,
+                  int ksize, int stride, int pad, int mode, int out_h, int out_w, void* stream);
+/* Weight gradient: dw (groups, cout_g, cin_g, k, k) torch layout, overwritten.
+ *   dw[g,co,ci,ky,kx] = sum_{n,oy,ox} dy[n,g*cout_g+co,oy,ox] * x[n,g*cin_g+ci, oy*stride+ky-pad, ox*stride+kx-pad] */
+int gg_conv2d_wgrad_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g, int cout_g,
+                        int h, int w, int ksize, int stride, int pad, float scale, void* stream);
+/* Per-(n,c) dot products over the spatial plane: out[n*c] = sum_hw a*b (style / demod gradients). */
+int gg_plane_dot_f32(float* out, const float* a, const float* b, int planes, long long hw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a13  optimiser step over flat parameter arenas: Adam (torch.optim.Adam semantics, train.py:204-205)
+ *      fused with the EMA update accumulate(t_ema, t, decay) (models/__init__.py:19-24, train.py:134).
+ *      ema may be NULL (Adam only).  step is the 1-based step count (bias correction).
+ * ------------------------------------------------------------------------------------------ */
+int gg_adam_ema_f32(float* param, float* exp_avg, float* exp_avg_sq, float* ema, const float* grad,
+                    long long numel, float lr, float beta1, float beta2, float eps, int step,
+                    float ema_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANGEALING_HIP_H */
