@@ -15,6 +15,13 @@
 #include "../../include/gangealing_hip.h"
 #include "gg_common.h"
 
+// The index / level arithmetic must be the plain IEEE sequence (mul, add, div each rounded once):
+// hipcc's default -ffp-contract=fast would fuse e.g. dx*dx + dy*dy into an FMA, which changes the
+// last bit, and with it floor() results and the arg-max tie-breaking of the level selection.
+// (__fmul_rn & co. compile to ordinary operators unless OCML_BASIC_ROUNDED_OPERATIONS is defined,
+// so they do not prevent contraction by themselves.)
+#pragma clang fp contract(off)
+
 namespace {
 
 using gg::add_rn;

@@ -1,0 +1,171 @@
+"""GPU parity, model level: the HIP generator / STN / training loss against the golden vectors that
+the REFERENCE modules produced on CPU with the same name-keyed weights (oracle/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def close(t, ref, atol=1e-4, rtol=1e-4):
+    np.testing.assert_allclose(t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else t, ref, atol=atol, rtol=rtol)
+
+
+def load_det(module, rules=()):
+    from oracle.det_weights import det_state_dict
+    torch.nn.Module.load_state_dict(module, det_state_dict(module, [tuple(r) for r in rules]), strict=False)
+    return module
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_generator_golden(cuda):
+    from gangealing_amd.stylegan2 import Generator
+    (c,) = load_golden('generator16')
+    g = load_det(Generator(16, 512, 8)).to(cuda).eval().requires_grad_(False)
+    noise = [T(c[f'noise{i}'], cuda) for i in range(c['meta']['num_layers'])]
+    img, latent = g([T(c['z'], cuda)], return_latents=True, noise=noise)
+    close(latent[:, 0], c['w'], 1e-5)
+    close(img, c['img'], 2e-4)
+    w = T(c['w'], cuda).requires_grad_(True)
+    img2, _ = g([w.unsqueeze(1).repeat(1, g.n_latent, 1)], input_is_latent=True, noise=noise)
+    close(img2, c['img_from_w'], 2e-4)
+    img2.backward(T(c['gimg'], cuda))
+    close(w.grad, c['gw'], 2e-3, 1e-3)
+
+
+@pytest.mark.parametrize('case', load_golden('stn'), ids=lambda c: '+'.join(c['meta']['transforms']))
+def test_stn_golden(case, cuda):
+    from gangealing_amd.spatial_transformers.spatial_transformer import get_stn
+    from gangealing_amd.losses import flow_losses
+    m = case['meta']
+    stn = get_stn(m['transforms'], flow_size=m['flow_size'], supersize=m['supersize'], channel_multiplier=0.5,
+                  num_heads=1)
+    stn = load_det(stn, m['scale_rules']).to(cuda)
+    x = T(case['x'], cuda)
+    kw = dict(return_flow=True, padding_mode=m['padding_mode'])
+    if m['supersize'] > m['flow_size']:
+        kw['input_img_for_sampling'] = x
+    out, fm = stn(x, **kw)
+    close(out, case['out'], 2e-4)
+    close(fm, case['flow_or_matrix'], 2e-4)
+    loss = (out ** 2).mean()
+    if 'flow' in m['transforms']:
+        reg = flow_losses(fm)
+        loss = loss + 10.0 * reg[0] + reg[1]
+    close(loss, case['loss'], 1e-5)
+    loss.backward()
+    grads = dict((n, p.grad) for n, p in stn.named_parameters())
+    worst = 0.0
+    for name, ref_norm in m['grad_norms'].items():
+        if ref_norm is None:
+            continue
+        got = float(grads[name].double().norm())
+        worst = max(worst, abs(got - ref_norm) / max(ref_norm, 1e-9))
+    # A similarity warp makes the 4 neighbour distances of MipmapWarp's level selection EXACTLY tied in
+    # real arithmetic (antialiased_sampling.py:62-97); torch.max then routes the level gradient to whichever
+    # neighbour wins by last-ulp rounding noise.  The sampling kernel reproduces that arg-max bit for bit on
+    # identical grids (scripts/mipmap_golden_report.py: 2e-7), but here the grid comes out of our own
+    # affine_grid / conv kernels (1-ulp different from ATen's), so ties break differently: a different,
+    # equally valid sub-gradient.  Hence the looser bound on the similarity stage when it is followed by
+    # level-gradient-carrying stages; the reference's own CUDA path differs from its CPU path the same way.
+    assert worst < (2e-2 if len(m['transforms']) > 1 else 5e-3), worst
+    for key in [k for k in case if k.startswith('grad_')]:
+        name = key[len('grad_'):]
+        match = [n for n in grads if n.replace('.', '_') == name]
+        assert len(match) == 1
+        if len(m['transforms']) > 1 and match[0].startswith('stns.0.'):
+            continue            # see the note above
+        close(grads[match[0]], case[key], 2e-4, 2e-3)
+
+
+def test_train_step_golden(cuda):
+    """gangealing_loss + TV + identity (loss.py:64-75, train.py:117-124) with explicit z / noise."""
+    from oracle.det_weights import det_array
+    from gangealing_amd.stylegan2 import Generator
+    from gangealing_amd.spatial_transformers.spatial_transformer import get_stn
+    from gangealing_amd.latent_learner import DirectionInterpolator
+    from gangealing_amd.losses import flow_losses
+    (c,) = load_golden('train_step')
+    m = c['meta']
+    gen = load_det(Generator(m['gen_size'], 512, 8)).to(cuda).eval().requires_grad_(False)
+    stn = get_stn(['similarity', 'flow'], flow_size=m['flow_size'], supersize=m['gen_size'], channel_multiplier=0.5,
+                  num_heads=1)
+    stn = load_det(stn, m['scale_rules']).to(cuda)
+    ll = DirectionInterpolator(None, m['ndirs'], m['inject'], gen.n_latent).to(cuda)
+    D = lambda name, shape, s=1.0: T(det_array(name, shape, s), cuda)
+    with torch.no_grad():
+        ll.directions.copy_(D('ll.directions', (m['ndirs'], 512)))
+        ll.lat_mean.copy_(D('ll.lat_mean', (1, 512)))
+        ll.coefficients.copy_(D('ll.coefficients', (1, m['ndirs']), 0.3))
+    res = lambda i: 2 ** ((i + 5) // 2)
+    n1 = [D(f'ts.n1.{i}', (2, 1, res(i), res(i))) for i in range(gen.num_layers)]
+    n2 = [D(f'ts.n2.{i}', (2, 1, res(i), res(i))) for i in range(gen.num_layers)]
+    with torch.no_grad():
+        unaligned, w = gen([T(c['z'], cuda)], noise=n1, return_latents=True)
+    target, _ = gen(ll([w[:, 0, :]], psi=m['psi']), input_is_latent=True, noise=n2)
+    pred, delta = stn(unaligned, return_flow=True, padding_mode=m['padding_mode'])
+    close(unaligned, c['unaligned'], 5e-4)
+    close(target, c['target'], 5e-4)
+    close(pred, c['pred'], 5e-4)
+    close(delta, c['delta'], 2e-4)
+    ploss = ((pred - target) ** 2).mean(dim=(1, 2, 3)).mean()
+    reg = flow_losses(delta)
+    total = ploss + m['tv_weight'] * reg[0] + m['flow_identity_weight'] * reg[1]
+    close(total, c['total'], 1e-4)
+    total.backward()
+    close(ll.coefficients.grad, c['g_coefficients'], 1e-4, 2e-3)
+    worst = 0.0
+    grads = dict((n, p.grad) for n, p in stn.named_parameters())
+    for name, ref_norm in m['grad_norms'].items():
+        if name == 'll.coefficients':
+            continue
+        worst = max(worst, abs(float(grads[name].double().norm()) - ref_norm) / max(ref_norm, 1e-9))
+    assert worst < 5e-3, worst
+
+
+def test_trainer_step_runs_and_updates(cuda):
+    from gangealing_amd.train_step import GangealingTrainer
+    tr = GangealingTrainer(cuda, gen_size=64, flow_size=64, batch=2, inject=3, ndirs=2, perturb_heads=0.02)
+    p0 = tr.stn_arena.param.clone()
+    e0 = tr.ema_arena.param.clone()
+    parts = tr.step(psi=0.5)
+    g = tr.stn_arena.grad
+    assert torch.isfinite(parts['p']) and torch.isfinite(g).all() and float(g.abs().max()) > 0
+    # Adam's first step moves every parameter with a non-zero gradient by ~lr
+    moved = (tr.stn_arena.param - p0).abs()
+    nz = g.abs() > 1e-5          # |g| >> eps, so the first Adam step has magnitude lr
+    assert float(moved[nz].max()) <= 1.001e-3 and float(moved[nz].min()) > 0.9e-3 * 0.5
+    # EMA: ema = decay * ema + (1 - decay) * p
+    d = tr.ema_decay
+    torch.testing.assert_close(tr.ema_arena.param, e0 * d + tr.stn_arena.param * (1 - d), atol=1e-6, rtol=1e-5)
+    # module parameters are views of the arena
+    first = next(tr.stn.parameters())
+    assert first.data_ptr() == tr.stn_arena.param.data_ptr()
+    parts = tr.step(psi=0.4)
+    assert torch.isfinite(parts['p'])
+
+
+def test_adam_ema_kernel_vs_torch(cuda):
+    from gangealing_amd import _lib
+    torch.manual_seed(0)
+    n = 100003
+    p = torch.randn(n, device=cuda)
+    g = torch.randn(n, device=cuda)
+    ema = p.clone()
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    m = torch.zeros(n, device=cuda)
+    v = torch.zeros(n, device=cuda)
+    ema_ref = ema.clone()
+    for step in range(1, 4):
+        ref.grad = g.clone() * step
+        opt.step()
+        ema_ref.mul_(0.99).add_(ref.detach(), alpha=0.01)
+        _lib.call('gg_adam_ema_f32', p, m, v, ema, (g * step).contiguous(), n, 1e-3, 0.9, 0.999, 1e-8, step, 0.99, 1.0)
+    torch.testing.assert_close(p, ref.detach(), atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(ema, ema_ref, atol=1e-6, rtol=1e-5)

@@ -248,7 +248,7 @@ CONV_CASES = [
     (2, 3, 64, 16, 1, 1, 0, 1, False),
     (1, 512, 3, 8, 1, 1, 0, 1, False),          # ToRGB shape (narrow tile)
     (2, 12, 10, 4, 3, 2, 0, 1, True),           # generator up-conv
-    (1, 24, 16, 8, 3, 1, 1, 3, False),          # grouped
+    (1, 24, 18, 8, 3, 1, 1, 3, False),          # grouped
     (1, 24, 16, 5, 3, 2, 0, 2, True),           # grouped transposed (per-sample form)
     (2, 8, 8, 6, 3, 1, 1, 1, True),             # transposed stride 1
     (2, 130, 140, 20, 3, 1, 1, 1, False),       # ragged tiles in both dims

@@ -105,3 +105,88 @@ def test_splat2d_selfcheck(case):
     out = O.splat2d(case['input'], case['coords'], case['values'], case['sigma'], case['meta']['soft_normalize'])
     close(out, case['out'], 1e-6)
     assert np.isfinite(out).all()
+
+
+# ------------------------------------------------------------------ model-level oracle (torch_ref) vs reference
+
+def _det_sd(module, rules=()):
+    from oracle.det_weights import det_state_dict
+    return det_state_dict(module, [tuple(r) for r in rules])
+
+
+def test_torch_ref_generator_matches_reference():
+    import torch
+    from oracle import torch_ref as R
+    from gangealing_amd.stylegan2 import Generator
+    (c,) = load_golden('generator16')
+    g = Generator(16, 512, 8)
+    sd = _det_sd(g)
+    noise = [torch.from_numpy(c[f'noise{i}']) for i in range(c['meta']['num_layers'])]
+    with torch.no_grad():
+        img, latent = R.generator(sd, torch.from_numpy(c['z']), 16, noise)
+    close(latent[:, 0].numpy(), c['w'], 1e-5)
+    close(img.numpy(), c['img'], 2e-4, 1e-4)
+    w = torch.from_numpy(c['w']).requires_grad_(True)
+    img2 = R.generator_synthesis(sd, w.unsqueeze(1).repeat(1, g.n_latent, 1), 16, noise)
+    img2.backward(torch.from_numpy(c['gimg']))
+    close(w.grad.numpy(), c['gw'], 2e-3, 1e-3)
+
+
+@pytest.mark.parametrize('case', load_golden('stn'), ids=lambda c: '+'.join(c['meta']['transforms']))
+def test_torch_ref_stn_matches_reference(case):
+    import torch
+    from oracle import torch_ref as R
+    from gangealing_amd.spatial_transformers.spatial_transformer import get_stn
+    m = case['meta']
+    stn = get_stn(m['transforms'], flow_size=m['flow_size'], supersize=m['supersize'], channel_multiplier=0.5, num_heads=1)
+    sd = {k: v.clone().requires_grad_(True) for k, v in _det_sd(stn, m['scale_rules']).items()}
+    x = torch.from_numpy(case['x'])
+    src = x if m['supersize'] > m['flow_size'] else None
+    out, fm = R.composed_stn(sd, x, m['flow_size'], m['supersize'], m['padding_mode'], tuple(m['transforms']), source=src)
+    close(out.detach().numpy(), case['out'], 2e-4, 1e-4)
+    close(fm.detach().numpy(), case['flow_or_matrix'], 2e-4, 1e-4)
+    loss = (out ** 2).mean()
+    if 'flow' in m['transforms']:
+        loss = loss + 10.0 * R.total_variation_loss(fm) + fm.pow(2).mean()
+    close(loss.detach().numpy(), case['loss'], 1e-5, 1e-4)
+    loss.backward()
+    for name, ref_norm in m['grad_norms'].items():
+        if ref_norm is None:
+            continue
+        got = float(sd[name].grad.double().norm())
+        assert abs(got - ref_norm) <= 2e-3 * max(ref_norm, 1e-6) + 1e-7, (name, got, ref_norm)
+
+
+def test_torch_ref_train_step_matches_reference():
+    import torch
+    from oracle import torch_ref as R
+    from oracle.det_weights import det_array
+    from gangealing_amd.stylegan2 import Generator
+    from gangealing_amd.spatial_transformers.spatial_transformer import get_stn
+    (c,) = load_golden('train_step')
+    m = c['meta']
+    g_sd = _det_sd(Generator(m['gen_size'], 512, 8))
+    stn = get_stn(['similarity', 'flow'], flow_size=m['flow_size'], supersize=m['gen_size'], channel_multiplier=0.5, num_heads=1)
+    stn_sd = {k: v.clone().requires_grad_(True) for k, v in _det_sd(stn, m['scale_rules']).items()}
+    T = lambda name, shape, s=1.0: torch.from_numpy(det_array(name, shape, s))
+    ll_sd = dict(directions=T('ll.directions', (m['ndirs'], 512)), lat_mean=T('ll.lat_mean', (1, 512)),
+                 coefficients=T('ll.coefficients', (1, m['ndirs']), 0.3).requires_grad_(True))
+    nl = (int(np.log2(m['gen_size'])) - 2) * 2 + 1
+    res = lambda i: 2 ** ((i + 5) // 2)
+    n1 = [T(f'ts.n1.{i}', (2, 1, res(i), res(i))) for i in range(nl)]
+    n2 = [T(f'ts.n2.{i}', (2, 1, res(i), res(i))) for i in range(nl)]
+    total, parts = R.train_loss(g_sd, stn_sd, ll_sd, torch.from_numpy(c['z']), m['gen_size'], m['flow_size'], m['psi'],
+                                m['inject'], m['padding_mode'], ('similarity', 'flow'), R.mse_loss_fn,
+                                m['tv_weight'], m['flow_identity_weight'], n1, n2)
+    close(parts['unaligned'].numpy(), c['unaligned'], 5e-4, 1e-4)
+    close(parts['pred'].detach().numpy(), c['pred'], 5e-4, 1e-4)
+    close(total.detach().numpy(), c['total'], 1e-4, 1e-4)
+    total.backward()
+    close(ll_sd['coefficients'].grad.numpy(), c['g_coefficients'], 1e-4, 2e-3)
+    worst = 0.0
+    for name, ref_norm in m['grad_norms'].items():
+        if name == 'll.coefficients':
+            continue
+        got = float(stn_sd[name].grad.double().norm())
+        worst = max(worst, abs(got - ref_norm) / max(ref_norm, 1e-9))
+    assert worst < 5e-3, worst
