@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""Headline benchmark: GANgealing train-step images/sec (BASELINE.json metric) on N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = loss forward (G x2, STN, perceptual loss, regularisers), backward (incl. the G pass-2
+backward), gradient all-reduce over the flat arena, Adam x2 and the EMA update (train.py:106-134),
+on random-latent batches with inputs already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: LSUN Cats 256x256, similarity+flow STN (flow_size=128), batch 16 per GPU
+    'c2': dict(gen_size=256, flow_size=128, batch=16, transform=('similarity', 'flow'), num_heads=1, flips=False,
+               inject=5, ndirs=1, padding_mode='reflection', sample_from_full_res=False),
+    # configs[0]: plumbing (64x64, similarity only)
+    'c1': dict(gen_size=64, flow_size=64, batch=4, transform=('similarity',), num_heads=1, flips=False, inject=5,
+               ndirs=1, padding_mode='reflection', sample_from_full_res=False, tv_weight=0.0, flow_identity_weight=0.0),
+}
+
+FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def cpu_baseline(budget_s=20.0):
+    """The oracle's torch-CPU restatement of the reference's CPU op fallback (kind "port"), config C1
+    (gen 64, similarity-only STN at 64, batch 4), full loss forward + backward + Adam + EMA, MSE stand-in
+    for the VGG loss (torchvision is absent), on the host cores of this box.  Bounded sample: whole
+    steps until ~budget_s seconds have elapsed (at least 1)."""
+    from oracle import torch_ref as R
+    from oracle.det_weights import det_state_dict
+    from gangealing_amd.stylegan2 import Generator
+    from gangealing_amd.spatial_transformers.spatial_transformer import get_stn
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    wl = WORKLOADS['c1']
+    g_sd = det_state_dict(Generator(wl['gen_size'], 512, 8))
+    stn = get_stn(list(wl['transform']), flow_size=wl['flow_size'], supersize=wl['gen_size'], channel_multiplier=0.5)
+    stn_sd = {k: v.clone().requires_grad_(True) for k, v in
+              det_state_dict(stn, (('warp_head.linear', 0.02),)).items()}
+    ll_sd = dict(directions=torch.randn(1, 512), lat_mean=torch.randn(1, 512),
+                 coefficients=torch.zeros(1, 1, requires_grad=True))
+    params = list(stn_sd.values()) + [ll_sd['coefficients']]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    ema = [p.detach().clone() for p in stn_sd.values()]
+    decay = 0.5 ** (32 / 10000)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        z = torch.randn(wl['batch'], 512)
+        total, _ = R.train_loss(g_sd, stn_sd, ll_sd, z, wl['gen_size'], wl['flow_size'], 0.5, wl['inject'],
+                                wl['padding_mode'], wl['transform'], R.mse_loss_fn, 0.0, 0.0)
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        with torch.no_grad():
+            for e, p in zip(ema, stn_sd.values()):
+                e.mul_(decay).add_(p, alpha=1 - decay)
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or steps >= 50:
+            break
+    return dict(value=round(steps * wl['batch'] / dt, 3), unit='images/sec', cores=threads, kind='port',
+                sample=f'{steps} full train steps of config C1 (gen 64, similarity STN@64, batch {wl["batch"]}, '
+                       f'MSE stand-in loss) in {dt:.1f} s via oracle/torch_ref.py on {threads} of {cores} host cores')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=20.0)
+    args = ap.parse_args()
+
+    from gangealing_amd import _lib
+    _lib.load()                      # fail loudly when the HIP library is missing
+    from gangealing_amd import distributed as gdist
+    from gangealing_amd.op import conv_mfma
+    from gangealing_amd.train_step import GangealingTrainer
+
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    gdist.setup_distributed('nccl')
+    rank = gdist.get_rank()
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl['batch'] = args.batch
+    trainer = GangealingTrainer(device, perturb_heads=0.02, seed=0, **wl)
+
+    def barrier():
+        torch.cuda.synchronize()
+        gdist.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(psi=0.5)
+    barrier()
+    conv_mfma.PROFILER = prof = conv_mfma.LaunchProfiler()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        parts = trainer.step(psi=0.5)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    conv_mfma.PROFILER = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(parts['p']).all(), 'non-finite loss'
+
+    if rank == 0:
+        psum = prof.summary()
+        images = world * wl['batch'] * args.steps
+        achieved = psum['total_flops'] / (psum['total_ms'] * 1e-3) / 1e12 if psum['total_ms'] > 0 else 0.0
+        out = {
+            'metric': 'train-step images/sec, LSUN-Cats 256^2 STN+StyleGAN2',
+            'value': round(images / elapsed, 3),
+            'unit': 'images/sec',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': f'{args.workload}: gen {wl["gen_size"]}^2, STN {"+".join(wl["transform"])} @ '
+                                   f'{wl["flow_size"]}^2, per-GPU batch {wl["batch"]}, VGG16-topology perceptual loss '
+                                   f'(random weights), random-init frozen G, psi 0.5',
+                       'global_batch': world * wl['batch'], 'parallelism': f'dp{world}',
+                       'loss': float(parts['p'])},
+            'roofline': {
+                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                'kernel': 'conv_igemm_kernel<3,0,2,2,2,2> (3x3 correlation, 128co x 128pix tile, fp32 MFMA)',
+                'launches': psum['launches'],
+                'avg_launch_ms': round(psum['total_ms'] / max(psum['launches'], 1), 4),
+                'avg_launch_gflop': round(psum['total_flops'] / max(psum['launches'], 1) / 1e9, 3),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        gdist.synchronize()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -76,7 +76,7 @@ __device__ __forceinline__ void decode_k(const ConvArgs& a, int k, int& ci, int&
   }
 }
 
-template <int KS, int MODE, int WCO, int WPIX, int MI, int NJ>
+template <int KS, int MODE, int WCO, int WPIX, int MI, int NJ, bool IN_SCALE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int TCO = WCO * MI * 32;
   constexpr int TPIX = WPIX * NJ * 32;
@@ -114,52 +114,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
   const int chan0 = (pn * a.groups + g) * a.cin_g;           // first input channel of this (sample, group)
   const float* xg = a.x + (size_t)chan0 * hw;
-  const float* sg = a.in_scale ? a.in_scale + chan0 : nullptr;
+  const float* sg = IN_SCALE ? a.in_scale + chan0 : nullptr;
   // ---- per-thread weight column ----
   const int ccol = tid % TCO, crow = tid / TCO;
   const bool c_ok = (co0 + ccol) < a.cout_g;
-  const float* wg = a.wmat + (size_t)g * ((size_t)a.cin_g * KK) * a.cout_g + co0 + ccol;
+  const float* wg_safe = a.wmat + (size_t)g * ((size_t)a.cin_g * KK) * a.cout_g + (c_ok ? co0 + ccol : 0);
 
   const int slab0 = split * a.slabs_per_split;
   int slab1 = slab0 + a.slabs_per_split;
   if (slab1 > a.nslabs) slab1 = a.nslabs;
 
-  float ra[PASS_A], rb[PASS_B];
+  // Register staging of the next slab.  Loads are unconditional (addresses clamped to a legal
+  // element, validity kept in a bit mask) so that all of a slab's global loads are issued back to
+  // back and retire under the MFMAs of the current slab; masking and the style scale are applied
+  // when the registers are written to LDS.
+  float ra[PASS_A], rs[PASS_A], rb[PASS_B];
+  unsigned mask_a = 0, mask_b = 0;
 
   auto load_slab = [&](int slab) {
     const int kbase = slab * BK;
+    mask_a = 0;
+    mask_b = 0;
 #pragma unroll
     for (int p = 0; p < PASS_A; ++p) {
       const int k = kbase + prow + p * ROWS_A;
-      float v = 0.f;
-      if (m_ok && k < a.ktot) {
-        int ci, ky, kx, dy, dx;
-        decode_k<KS, MODE>(a, k, ci, ky, kx, dy, dx);
-        const int iy = base_y + dy, ix = base_x + dx;
-        if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) {
-          v = xg[(size_t)ci * hw + iy * a.w + ix];
-          if (sg) v *= sg[ci];
-        }
-      }
-      ra[p] = v;
+      int ci, ky, kx, dy, dx;
+      decode_k<KS, MODE>(a, min(k, a.ktot - 1), ci, ky, kx, dy, dx);
+      const int iy = base_y + dy, ix = base_x + dx;
+      // branch-free validity: unsigned compares fold the >= 0 tests
+      const unsigned ok = (unsigned)m_ok & (unsigned)(k < a.ktot) & (unsigned)((unsigned)iy < (unsigned)a.h) &
+                          (unsigned)((unsigned)ix < (unsigned)a.w);
+      const int off = (ci * hw + iy * a.w + ix) * (int)ok;
+      ra[p] = xg[off];
+      if (IN_SCALE) rs[p] = sg[ci];
+      mask_a |= ok << p;
     }
 #pragma unroll
     for (int p = 0; p < PASS_B; ++p) {
       const int k = kbase + crow + p * ROWS_B;
-      float v = 0.f;
-      if (c_ok && k < a.ktot) {
-        int ci, ky, kx, dy, dx;
-        decode_k<KS, MODE>(a, k, ci, ky, kx, dy, dx);
-        v = wg[(size_t)(ci * KK + ky * KS + kx) * a.cout_g];
-      }
-      rb[p] = v;
+      int ci, ky, kx, dy, dx;
+      decode_k<KS, MODE>(a, min(k, a.ktot - 1), ci, ky, kx, dy, dx);
+      const unsigned ok = (unsigned)c_ok & (unsigned)(k < a.ktot);
+      rb[p] = wg_safe[(size_t)(ci * KK + ky * KS + kx) * a.cout_g];
+      mask_b |= ok << p;
     }
   };
   auto store_slab = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < PASS_A; ++p) sX[buf][prow + p * ROWS_A][pcol] = ra[p];
+    for (int p = 0; p < PASS_A; ++p) sX[buf][prow + p * ROWS_A][pcol] = ((mask_a >> p) & 1u) ? (IN_SCALE ? ra[p] * rs[p] : ra[p]) : 0.f;
 #pragma unroll
-    for (int p = 0; p < PASS_B; ++p) sW[buf][crow + p * ROWS_B][ccol] = rb[p];
+    for (int p = 0; p < PASS_B; ++p) sW[buf][crow + p * ROWS_B][ccol] = ((mask_b >> p) & 1u) ? rb[p] : 0.f;
   };
 
   f32x16 acc[MI][NJ];
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   }
 
   float rd[16], rx[16];
+  unsigned mask_d = 0, mask_x = 0;
   auto load_slab = [&](long long k0) {
     const long long k = k0 + kl;
     const bool ok = k < kend;
@@ -303,23 +308,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const float* dyp = a.dy + ((size_t)(n * a.groups + g) * a.cout_g) * ohw + (size_t)oy * a.ow + ox;
     const float* xp = a.x + ((size_t)(n * a.groups + g) * a.cin_g) * hw;
     const int by = oy * a.stride, bx = ox * a.stride;
+    mask_d = 0;
+    mask_x = 0;
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
       const int co = co0 + r0 + 8 * p;
-      rd[p] = (ok && co < a.cout_g) ? dyp[(size_t)co * ohw] : 0.f;
-      float v = 0.f;
-      if (ok && jci[p] >= 0) {
-        const int iy = by + jdy[p], ix = bx + jdx[p];
-        if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) v = xp[(size_t)jci[p] * hw + iy * a.w + ix];
-      }
-      rx[p] = v;
+      const unsigned okd = (unsigned)ok & (unsigned)(co < a.cout_g);
+      rd[p] = dyp[(size_t)co * ohw * okd];
+      mask_d |= okd << p;
+      const int iy = by + jdy[p], ix = bx + jdx[p];
+      const unsigned okx = (unsigned)ok & (unsigned)(jci[p] >= 0) & (unsigned)((unsigned)iy < (unsigned)a.h) &
+                           (unsigned)((unsigned)ix < (unsigned)a.w);
+      rx[p] = xp[(size_t)((jci[p] * hw + iy * a.w + ix) * (int)okx)];
+      mask_x |= okx << p;
     }
   };
   auto store_slab = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-      sD[buf][kl][r0 + 8 * p] = rd[p];
-      sXg[buf][kl][r0 + 8 * p] = rx[p];
+      sD[buf][kl][r0 + 8 * p] = ((mask_d >> p) & 1u) ? rd[p] : 0.f;
+      sXg[buf][kl][r0 + 8 * p] = ((mask_x >> p) & 1u) ? rx[p] : 0.f;
     }
   };
 
@@ -446,10 +454,14 @@ template <int KS, int MODE>
 int launch_conv(const ConvArgs& a, bool narrow, hipStream_t st) {
   if ((long long)a.tiles_pix * a.tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
-  if (narrow)
-    conv_igemm_kernel<KS, MODE, 1, 4, 1, 2><<<grid, 256, 0, st>>>(a);
-  else
-    conv_igemm_kernel<KS, MODE, 2, 2, 2, 2><<<grid, 256, 0, st>>>(a);
+  const bool sc = a.in_scale != nullptr;
+  if (narrow) {
+    if (sc) conv_igemm_kernel<KS, MODE, 1, 4, 1, 2, true><<<grid, 256, 0, st>>>(a);
+    else conv_igemm_kernel<KS, MODE, 1, 4, 1, 2, false><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (sc) conv_igemm_kernel<KS, MODE, 2, 2, 2, 2, true><<<grid, 256, 0, st>>>(a);
+    else conv_igemm_kernel<KS, MODE, 2, 2, 2, 2, false><<<grid, 256, 0, st>>>(a);
+  }
   return gg::launch_status("conv_igemm");
 }
 

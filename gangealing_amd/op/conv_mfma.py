@@ -10,6 +10,24 @@ from torch.autograd import Function
 from .. import _lib
 
 
+class LaunchProfiler:
+    """Optional per-launch timing of the dominant kernel instantiation (3x3 correlation, 128x128 tile):
+    HIP events recorded on the stream the kernel is launched on (torch's current stream).  Used by
+    bench.py for the roofline entry; None (the default) costs nothing."""
+
+    def __init__(self):
+        self.records = []          # (start_event, end_event, flops)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = [s.elapsed_time(e) for s, e, _ in self.records]
+        flops = [f for _, _, f in self.records]
+        return dict(launches=len(ms), total_ms=sum(ms), total_flops=float(sum(flops)))
+
+
+PROFILER = None
+
+
 def _pair_eq(v, name):
     if isinstance(v, (tuple, list)):
         if len(v) != 2 or v[0] != v[1]:
@@ -38,8 +56,15 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             oh, ow = out_hw
     y = torch.empty((batch, groups * cout_g, oh, ow), dtype=torch.float32, device=x.device)
     if y.numel():
+        prof = PROFILER if (PROFILER is not None and k == 3 and mode == 0 and cout_g > 32) else None
+        if prof is not None:
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
         _lib.call('gg_conv2d_f32', y, x, wmat, in_scale, out_scale, bias, batch, groups, cin_g, cout_g, h, w,
                   k, stride, pad, mode, oh if mode == 1 else 0, ow if mode == 1 else 0)
+        if prof is not None:
+            end.record()
+            prof.records.append((start, end, 2.0 * batch * groups * cout_g * cin_g * k * k * oh * ow))
     return y
 
 
