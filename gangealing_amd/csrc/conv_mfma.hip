@@ -131,33 +131,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   float ra[PASS_A], rs[PASS_A], rb[PASS_B];
   unsigned mask_a = 0, mask_b = 0;
 
+  auto load_a = [&](int kbase, int p) {
+    const int k = kbase + prow + p * ROWS_A;
+    int ci, ky, kx, dy, dx;
+    decode_k<KS, MODE>(a, min(k, a.ktot - 1), ci, ky, kx, dy, dx);
+    const int iy = base_y + dy, ix = base_x + dx;
+    // branch-free validity: unsigned compares fold the >= 0 tests
+    const unsigned ok = (unsigned)m_ok & (unsigned)(k < a.ktot) & (unsigned)((unsigned)iy < (unsigned)a.h) &
+                        (unsigned)((unsigned)ix < (unsigned)a.w);
+    const int off = (ci * hw + iy * a.w + ix) * (int)ok;
+    ra[p] = xg[off];
+    if (IN_SCALE) rs[p] = sg[ci];
+    mask_a |= ok << p;
+  };
+  auto load_b = [&](int kbase, int p) {
+    const int k = kbase + crow + p * ROWS_B;
+    int ci, ky, kx, dy, dx;
+    decode_k<KS, MODE>(a, min(k, a.ktot - 1), ci, ky, kx, dy, dx);
+    const unsigned ok = (unsigned)c_ok & (unsigned)(k < a.ktot);
+    rb[p] = wg_safe[(size_t)(ci * KK + ky * KS + kx) * a.cout_g];
+    mask_b |= ok << p;
+  };
   auto load_slab = [&](int slab) {
     const int kbase = slab * BK;
     mask_a = 0;
     mask_b = 0;
 #pragma unroll
-    for (int p = 0; p < PASS_A; ++p) {
-      const int k = kbase + prow + p * ROWS_A;
-      int ci, ky, kx, dy, dx;
-      decode_k<KS, MODE>(a, min(k, a.ktot - 1), ci, ky, kx, dy, dx);
-      const int iy = base_y + dy, ix = base_x + dx;
-      // branch-free validity: unsigned compares fold the >= 0 tests
-      const unsigned ok = (unsigned)m_ok & (unsigned)(k < a.ktot) & (unsigned)((unsigned)iy < (unsigned)a.h) &
-                          (unsigned)((unsigned)ix < (unsigned)a.w);
-      const int off = (ci * hw + iy * a.w + ix) * (int)ok;
-      ra[p] = xg[off];
-      if (IN_SCALE) rs[p] = sg[ci];
-      mask_a |= ok << p;
-    }
+    for (int p = 0; p < PASS_A; ++p) load_a(kbase, p);
 #pragma unroll
-    for (int p = 0; p < PASS_B; ++p) {
-      const int k = kbase + crow + p * ROWS_B;
-      int ci, ky, kx, dy, dx;
-      decode_k<KS, MODE>(a, min(k, a.ktot - 1), ci, ky, kx, dy, dx);
-      const unsigned ok = (unsigned)c_ok & (unsigned)(k < a.ktot);
-      rb[p] = wg_safe[(size_t)(ci * KK + ky * KS + kx) * a.cout_g];
-      mask_b |= ok << p;
-    }
+    for (int p = 0; p < PASS_B; ++p) load_b(kbase, p);
   };
   auto store_slab = [&](int buf) {
 #pragma unroll
@@ -182,6 +184,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int kh = lane >> 5, l31 = lane & 31;
     for (int slab = slab0; slab < slab1; ++slab) {
       const bool more = slab + 1 < slab1;
+      // global loads of slab t+1 are issued first and retire under the 32 MFMAs of slab t (measured:
+      // spreading them between the MFMAs with sched_barrier pinning was 4 % slower)
       if (more) load_slab(slab + 1);
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
@@ -428,8 +432,9 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(float* __restrict__ out,
 }
 
 // Fill in tiling / split-K for one launch.  Returns false when the launch is empty.
-bool plan_conv(ConvArgs& a, bool narrow) {
-  const int tco = narrow ? 32 : 128, tpix = narrow ? 256 : 128;
+// tile: 0 = 128co x 128pix, 1 = 32co x 256pix, 2 = 64co x 256pix
+bool plan_conv(ConvArgs& a, int tile) {
+  const int tco = tile == 0 ? 128 : (tile == 1 ? 32 : 64), tpix = tile == 0 ? 128 : 256;
   const long long mtot = (long long)a.batch * a.mh * a.mw;
   if (mtot <= 0) return false;
   a.tiles_co = (a.cout_g + tco - 1) / tco;
@@ -451,13 +456,16 @@ bool plan_conv(ConvArgs& a, bool narrow) {
 }
 
 template <int KS, int MODE>
-int launch_conv(const ConvArgs& a, bool narrow, hipStream_t st) {
+int launch_conv(const ConvArgs& a, int tile, hipStream_t st) {
   if ((long long)a.tiles_pix * a.tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
-  if (narrow) {
+  if (tile == 1) {
     if (sc) conv_igemm_kernel<KS, MODE, 1, 4, 1, 2, true><<<grid, 256, 0, st>>>(a);
     else conv_igemm_kernel<KS, MODE, 1, 4, 1, 2, false><<<grid, 256, 0, st>>>(a);
+  } else if (tile == 2) {
+    if (sc) conv_igemm_kernel<KS, MODE, 1, 4, 2, 2, true><<<grid, 256, 0, st>>>(a);
+    else conv_igemm_kernel<KS, MODE, 1, 4, 2, 2, false><<<grid, 256, 0, st>>>(a);
   } else {
     if (sc) conv_igemm_kernel<KS, MODE, 2, 2, 2, 2, true><<<grid, 256, 0, st>>>(a);
     else conv_igemm_kernel<KS, MODE, 2, 2, 2, 2, false><<<grid, 256, 0, st>>>(a);
@@ -467,7 +475,7 @@ int launch_conv(const ConvArgs& a, bool narrow, hipStream_t st) {
 
 template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st) {
-  const bool narrow = a.cout_g <= 32;
+  const int narrow = a.cout_g <= 32 ? 1 : (a.cout_g <= 64 ? 2 : 0);      // tile selector
   ConvArgs plans[4];
   int nplans = 0;
   bool needs_zero = false;
