@@ -1,0 +1,77 @@
+"""Run an UNMODIFIED reference script (e.g. wpeebles/gangealing train.py) on the MI355X operators.
+
+    python -m gangealing_amd.launch /path/to/gangealing/train.py --exp-name cats --ckpt cat ...
+    torchrun --nproc_per_node=8 -m gangealing_amd.launch /path/to/gangealing/train.py ...
+
+Before the script is imported, the reference's operator packages are pre-populated in sys.modules
+with this package's drop-ins, so `from models.stylegan2.op import ...` (networks.py:6),
+`from utils.splat2d_cuda import splat2d` (helpers.py:8, spatial_transformer.py:299) and
+`from models.spatial_transformers.antialiased_sampling import ...` (warping_heads.py:10,
+models/__init__.py:6) resolve to the HIP implementations.  The reference's own op modules JIT-compile
+CUDA at import time (upfirdn2d.py:12-18, fused_act.py:11-17) and are therefore never imported.
+Optional python dependencies that are absent offline (torchvision, lmdb, tensorboard) are stubbed
+only when missing.
+"""
+import importlib
+import os
+import runpy
+import sys
+import types
+
+OP_MODULES = {
+    'models.stylegan2.op': 'gangealing_amd.op',
+    'models.stylegan2.op.upfirdn2d': 'gangealing_amd.op.upfirdn2d',
+    'models.stylegan2.op.fused_act': 'gangealing_amd.op.fused_act',
+    'models.stylegan2.op.conv2d_gradfix': 'gangealing_amd.op.conv2d_gradfix',
+    'utils.splat2d_cuda': 'gangealing_amd.splat2d_cuda',
+    'utils.splat2d_cuda.functional': 'gangealing_amd.splat2d_cuda.functional',
+    'utils.splat2d_cuda.splat': 'gangealing_amd.splat2d_cuda.splat',
+    'models.spatial_transformers.antialiased_sampling': 'gangealing_amd.spatial_transformers.antialiased_sampling',
+}
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, item):
+        if item.startswith('__'):
+            raise AttributeError(item)
+        return type(item, (), {'__init__': lambda self, *a, **k: None, '__call__': lambda self, *a, **k: None})
+
+
+def stub_missing(names=('torchvision', 'torchvision.models', 'torchvision.datasets', 'torchvision.datasets.utils',
+                        'torchvision.transforms', 'torchvision.utils', 'lmdb', 'tensorboard',
+                        'torch.utils.tensorboard')):
+    for name in names:
+        if name in sys.modules:
+            continue
+        try:
+            importlib.import_module(name)
+        except Exception:
+            m = _Stub(name)
+            m.__path__ = []
+            sys.modules[name] = m
+
+
+def inject(reference_root):
+    """Make `reference_root` importable with the HIP operator modules standing in for its own."""
+    reference_root = os.path.abspath(reference_root)
+    if reference_root not in sys.path:
+        sys.path.insert(0, reference_root)
+    stub_missing()
+    # parent packages must exist as real packages of the reference so that sibling modules import normally
+    for target, ours in OP_MODULES.items():
+        sys.modules[target] = importlib.import_module(ours)
+    return sorted(OP_MODULES)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    if not argv:
+        raise SystemExit(__doc__)
+    script = os.path.abspath(argv[0])
+    inject(os.path.dirname(script))
+    sys.argv = [script] + list(argv[1:])
+    runpy.run_path(script, run_name='__main__')
+
+
+if __name__ == '__main__':
+    main()
