@@ -187,18 +187,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       // global loads of slab t+1 are issued first and retire under the 32 MFMAs of slab t (measured:
       // spreading them between the MFMAs with sched_barrier pinning was 4 % slower)
       if (more) load_slab(slab + 1);
+      // fragments are double-buffered in registers: the LDS reads of k-step kk+1 are issued before the
+      // MFMAs of k-step kk, so their latency hides under 4 x 64 cycles of matrix pipe
+      float wa[2][MI], xb[2][NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) wa[0][i] = sW[cur][kh][(wco * MI + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) xb[0][j] = sX[cur][kh][(wpix * NJ + j) * 32 + l31];
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
-        float wa[MI], xb[NJ];
+        const int c = kk & 1, nx = c ^ 1;
+        if (kk + 1 < BK / 2) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) wa[i] = sW[cur][kk * 2 + kh][(wco * MI + i) * 32 + l31];
+          for (int i = 0; i < MI; ++i) wa[nx][i] = sW[cur][(kk + 1) * 2 + kh][(wco * MI + i) * 32 + l31];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) xb[j] = sX[cur][kk * 2 + kh][(wpix * NJ + j) * 32 + l31];
+          for (int j = 0; j < NJ; ++j) xb[nx][j] = sX[cur][(kk + 1) * 2 + kh][(wpix * NJ + j) * 32 + l31];
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i], xb[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c][i], xb[c][j], acc[i][j], 0, 0, 0);
+        // pin the issue order: this step's LDS reads (for the NEXT k-step) first, then its MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);
       }
       if (more) store_slab(cur ^ 1);
       __syncthreads();

@@ -69,3 +69,10 @@ N = 2 * N
 for (name, cin, cout, h) in [('VGG 128 3->64', 3, 64, 128), ('VGG 128 64->64', 64, 64, 128), ('VGG 64 128', 128, 128, 64),
                              ('VGG 32 256', 256, 256, 32), ('VGG 16 512', 512, 512, 16), ('VGG 8 512', 512, 512, 8)]:
     layer(name, cin, cout, h, 3, 1, 1, 0, scale=False, only=only)
+if only == 'probe':
+    N = 16
+    layer('probe 1x1 K=1152 @256', 1152, 128, 256, 1, 1, 0, 0, scale=False, only='probe')
+    layer('probe 1x1 K=1152 @256 scaled', 1152, 128, 256, 1, 1, 0, 0, scale=True, only='probe')
+    layer('probe 3x3 128 @256 noscale', 128, 128, 256, 3, 1, 1, 0, scale=False, only='probe')
+    layer('probe 3x3 128 @256 scaled', 128, 128, 256, 3, 1, 1, 0, scale=True, only='probe')
+    layer('probe 3x3 512->512 @64 noscale', 512, 512, 64, 3, 1, 1, 0, scale=False, only='probe')

@@ -169,3 +169,40 @@ def test_adam_ema_kernel_vs_torch(cuda):
         _lib.call('gg_adam_ema_f32', p, m, v, ema, (g * step).contiguous(), n, 1e-3, 0.9, 0.999, 1e-8, step, 0.99, 1.0)
     torch.testing.assert_close(p, ref.detach(), atol=1e-6, rtol=1e-5)
     torch.testing.assert_close(ema, ema_ref, atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(name='c5-clustering', gen_size=64, flow_size=64, batch=2, num_heads=4, flips=True, inject=6, ndirs=5,
+         sample_from_full_res=True),
+    dict(name='c4-fullres', gen_size=128, flow_size=64, batch=2, inject=6, ndirs=8, padding_mode='border',
+         sample_from_full_res=True),
+    dict(name='c1-similarity', gen_size=64, flow_size=64, batch=4, transform=('similarity',), tv_weight=0.0,
+         flow_identity_weight=0.0),
+], ids=lambda c: c['name'])
+def test_trainer_other_configs(cfg, cuda):
+    """BASELINE.json configs 0/3/4 in miniature: K=4 clustering with flips (cartesian heads, min over 2K),
+    full-resolution sampling through the mip pyramid, similarity-only STN."""
+    from gangealing_amd.train_step import GangealingTrainer
+    cfg = dict(cfg)
+    cfg.pop('name')
+    tr = GangealingTrainer(cuda, perturb_heads=0.02, **cfg)
+    p0 = tr.stn_arena.param.clone()
+    for psi in (0.6, 0.5):
+        parts = tr.step(psi=psi)
+    torch.cuda.synchronize()
+    assert torch.isfinite(parts['p']).all()
+    assert torch.isfinite(tr.stn_arena.grad).all() and torch.isfinite(tr.stn_arena.param).all()
+    assert float((tr.stn_arena.param - p0).abs().max()) > 0
+    assert float(tr.ll_arena.grad.abs().max()) > 0          # the latent learner receives a gradient through G
+
+
+def test_cluster_stn_shapes(cuda):
+    from gangealing_amd.spatial_transformers.spatial_transformer import get_stn
+    stn = get_stn(['similarity', 'flow'], flow_size=64, supersize=64, channel_multiplier=0.5, num_heads=3).to(cuda)
+    x = torch.randn(2, 3, 64, 64, device=cuda)
+    out, flow = stn(x, return_flow=True, padding_mode='reflection')
+    assert out.shape == (6, 3, 64, 64) and flow.shape == (6, 64, 64, 2)
+    # zero-initialised heads -> identity warp for every head (warping_heads.py:28-30,163-165)
+    torch.testing.assert_close(out, x.repeat_interleave(3, dim=0), atol=1e-5, rtol=1e-5)
+    out_u = stn(x, unfold=True, padding_mode='border')
+    assert out_u.shape == (2, 3, 3, 64, 64)
