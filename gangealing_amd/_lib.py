@@ -20,6 +20,7 @@ _PROTOS = {
     'gg_fused_bias_act_f64': 'ppppiiddqqis',
     'gg_fused_lrelu_bwd_f32': 'ppppffiiqs',
     'gg_fused_lrelu_bwd_f64': 'ppppddiiqs',
+    'gg_noise_bias_act_f32': 'pppppffiiqs',
     'gg_upfirdn2d_f32': 'pppiiiiiiiiiiiiis',
     'gg_upfirdn2d_f64': 'pppiiiiiiiiiiiiis',
     'gg_splat_forward_f32': 'pppppiiiiis',

@@ -77,12 +77,13 @@ __device__ __forceinline__ void decode_k(const ConvArgs& a, int k, int& ci, int&
 }
 
 template <int KS, int MODE, int WCO, int WPIX, int MI, int NJ, bool IN_SCALE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WCO * WPIX * 64) void conv_igemm_kernel(const ConvArgs a) {
+  constexpr int NT = WCO * WPIX * 64;           // threads per block
   constexpr int TCO = WCO * MI * 32;
   constexpr int TPIX = WPIX * NJ * 32;
-  constexpr int ROWS_A = 256 / TPIX;            // k rows covered per pass by the pixel gather
+  constexpr int ROWS_A = NT / TPIX;             // k rows covered per pass by the pixel gather
   constexpr int PASS_A = BK / ROWS_A;
-  constexpr int ROWS_B = 256 / TCO;
+  constexpr int ROWS_B = NT / TCO;
   constexpr int PASS_B = BK / ROWS_B;
   constexpr int KK = KS * KS;
   __shared__ float sX[2][BK][TPIX];
@@ -487,7 +488,9 @@ int launch_conv(const ConvArgs& a, int tile, hipStream_t st) {
 
 template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st) {
-  const int narrow = a.cout_g <= 32 ? 1 : (a.cout_g <= 64 ? 2 : 0);      // tile selector
+  // tile selector.  (Measured on the 128->128 @256^2 layer: an 8-wave 128x128 variant, a 128co x 256pix
+  // variant with 8 accumulators per wave and BK = 32 are all within -20..+1 % of this 4-wave tile.)
+  const int narrow = a.cout_g <= 32 ? 1 : (a.cout_g <= 64 ? 2 : 0);
   ConvArgs plans[4];
   int nplans = 0;
   bool needs_zero = false;

@@ -27,7 +27,8 @@ def sample_gan_supervised_pairs(generator, ll, resize_fake2stn, psi, batch, dim_
         unaligned_in, w_noise = generator([z], noise=None, return_latents=True)
     with torch.set_grad_enabled(not freeze_ll):
         w_aligned = ll([w_noise[:, 0, :]], psi=psi)
-        aligned_target, _ = generator(w_aligned, input_is_latent=True, noise=None)
+        aligned_target, _ = generator(w_aligned, input_is_latent=True, noise=None,
+                                      grad_latents=getattr(ll, 'inject_index', None))
         aligned_target = resize_fake2stn(aligned_target)
     return unaligned_in, aligned_target
 

@@ -66,8 +66,52 @@ class FusedLeakyReLUFunction(Function):
     @staticmethod
     def backward(ctx, grad_output):
         (out,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[1] and not torch.is_grad_enabled():
+            # frozen bias, first-order only: skip the bias reduction (atomics) altogether
+            grad_output = grad_output.contiguous()
+            n, c = out.shape[0], out.shape[1]
+            grad_input = torch.empty_like(grad_output)
+            _lib.call('gg_fused_lrelu_bwd_' + _SUFFIX[out.dtype], grad_input, None, grad_output, out,
+                      ctx.negative_slope, ctx.scale, n, c, out.numel() // max(n * c, 1))
+            return grad_input, None, None, None
         grad_input, grad_bias = FusedLeakyReLUFunctionBackward.apply(grad_output, out, ctx.negative_slope, ctx.scale)
         return grad_input, grad_bias, None, None
+
+
+class NoiseBiasLeakyReLUFunction(Function):
+    """lrelu(x + noise_weight * noise + bias) * scale in one kernel (StyledConv's NoiseInjection +
+    FusedLeakyReLU, networks.py:291-298,344-350).  Gradients: input always; bias / noise weight only if
+    they require grad (they do not on the frozen generator)."""
+
+    @staticmethod
+    def forward(ctx, input, noise, noise_weight, bias, negative_slope, scale):
+        input = input.contiguous()
+        n, c = input.shape[0], input.shape[1]
+        hw = input.numel() // max(n * c, 1)
+        out = torch.empty_like(input)
+        _lib.call('gg_noise_bias_act_f32', out, input, noise.contiguous(), noise_weight.contiguous(),
+                  bias.contiguous(), negative_slope, scale, n, c, hw)
+        ctx.save_for_backward(out, noise)
+        ctx.conf = (negative_slope, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        out, noise = ctx.saved_tensors
+        negative_slope, scale = ctx.conf
+        grad_output = grad_output.contiguous()
+        n, c = out.shape[0], out.shape[1]
+        hw = out.numel() // max(n * c, 1)
+        need_bias, need_nw = ctx.needs_input_grad[3], ctx.needs_input_grad[2]
+        grad_input = torch.empty_like(grad_output)
+        grad_bias = torch.empty(c, dtype=out.dtype, device=out.device) if need_bias else None
+        _lib.call('gg_fused_lrelu_bwd_f32', grad_input, grad_bias, grad_output, out, negative_slope, scale, n, c, hw)
+        grad_nw = (grad_input.sum(dim=1, keepdim=True) * noise).sum().reshape(1) if need_nw else None
+        return grad_input, None, grad_nw, grad_bias, None, None
+
+
+def noise_bias_leaky_relu(input, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):
+    return NoiseBiasLeakyReLUFunction.apply(input, noise, noise_weight, bias, negative_slope, scale)
 
 
 class FusedLeakyReLU(nn.Module):

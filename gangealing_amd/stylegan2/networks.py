@@ -22,6 +22,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ..op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
+from ..op.fused_act import noise_bias_leaky_relu
 from ..op import conv_mfma
 
 
@@ -213,6 +214,15 @@ class StyledConv(nn.Module):
 
     def forward(self, input, style, noise=None):
         out = self.conv(input, style)
+        n, _, h, w = out.shape
+        if out.dtype == torch.float32 and (h * w) % 4 == 0:
+            # NoiseInjection + FusedLeakyReLU in one pass over the activation (csrc/fused_bias_act.hip)
+            if noise is None:
+                noise = out.new_empty(n, 1, h, w).normal_()
+            elif noise.shape[0] != n:
+                noise = noise.expand(n, -1, -1, -1)
+            return noise_bias_leaky_relu(out, noise.type(out.dtype), self.noise.weight, self.activate.bias,
+                                         self.activate.negative_slope, self.activate.scale)
         out = self.noise(out, noise=noise)
         return self.activate(out)
 
@@ -318,7 +328,11 @@ class Generator(nn.Module):
         return self.style(input)
 
     def forward(self, styles, mapping_only=False, return_latents=False, inject_index=None, truncation=1,
-                truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=True):
+                truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=True, grad_latents=None):
+        """Reference signature (networks.py:514-525) plus `grad_latents`: when given, only the first
+        `grad_latents` W+ slots can carry a gradient (the DirectionInterpolator only writes the first
+        `inject` slots, latent_learner.py:64-67; the rest is a copy of w that needs no gradient), so the
+        style-gradient reductions of all later layers are skipped.  None = reference behaviour."""
         if not input_is_latent:
             styles = [self.style(s) for s in styles]
             if mapping_only:
@@ -335,13 +349,17 @@ class Generator(nn.Module):
                 inject_index = random.randint(1, self.n_latent - 1)
             latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
                                 styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
-        out = self.conv1(self.input(latent), latent[:, 0], noise=noise[0])
-        skip = self.to_rgb1(out, latent[:, 1])
+        if grad_latents is not None and latent.requires_grad:
+            lat = [latent[:, j] if j < grad_latents else latent[:, j].detach() for j in range(self.n_latent)]
+        else:
+            lat = [latent[:, j] for j in range(self.n_latent)]
+        out = self.conv1(self.input(latent), lat[0], noise=noise[0])
+        skip = self.to_rgb1(out, lat[1])
         i = 1
         for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2],
                                                        self.to_rgbs):
-            out = conv_up(out, latent[:, i], noise=n_up)
-            out = conv(out, latent[:, i + 1], noise=n_conv)
-            skip = to_rgb(out, latent[:, i + 2], skip)
+            out = conv_up(out, lat[i], noise=n_up)
+            out = conv(out, lat[i + 1], noise=n_conv)
+            skip = to_rgb(out, lat[i + 2], skip)
             i += 2
         return (skip, latent) if return_latents else (skip, None)

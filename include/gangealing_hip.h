@@ -50,6 +50,13 @@ int gg_fused_lrelu_bwd_f32(float* grad_in, float* grad_bias, const float* grad_o
 int gg_fused_lrelu_bwd_f64(double* grad_in, double* grad_bias, const double* grad_out, const double* out,
                            double alpha, double scale, int n, int c, long long hw, void* stream);
 
+/* StyledConv tail (networks.py:291-298,344-350) in one pass:
+ *   out = lrelu(x + noise_weight[0] * noise[n,0,hw] + bias[c], alpha) * scale
+ * x/out (n,c,hw), noise (n,1,hw), noise_weight: device scalar (NoiseInjection.weight), hw % 4 == 0.
+ * The backward is gg_fused_lrelu_bwd (the sign reference is `out`, as for fused_leaky_relu). */
+int gg_noise_bias_act_f32(float* out, const float* x, const float* noise, const float* noise_weight,
+                          const float* bias, float alpha, float scale, int n, int c, long long hw, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * a1  upfirdn2d.
  * Replaces upfirdn2d_op.upfirdn2d(input[M,H,W,1], kernel[kh,kw], up_x, up_y, down_x, down_y,
