@@ -29,7 +29,17 @@ WORKLOADS = {
                ndirs=1, padding_mode='reflection', sample_from_full_res=False, tv_weight=0.0, flow_identity_weight=0.0),
 }
 
-FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks
+MFMA_PEAK_TFLOPS = {'fp32': 157.3, 'bf16x3': 2500.0, 'bf16x6': 2500.0}
+KERNEL_NAME = {
+    'fp32': 'conv_igemm_kernel<3,0,2,2,2,2,*> (3x3 correlation, 128co x 128pix tile, v_mfma_f32_32x32x2_f32)',
+    'bf16x3': 'conv_split_kernel<3,0,2,*> (3x3 correlation, 128co x 128pix tile, v_mfma_f32_32x32x16_bf16, '
+              '2 bf16 limbs per fp32 operand = 3 MFMA products per algorithmic product)',
+    'bf16x6': 'conv_split_kernel<3,0,3,*> (3x3 correlation, 128co x 128pix tile, v_mfma_f32_32x32x16_bf16, '
+              '3 bf16 limbs per fp32 operand = 6 MFMA products per algorithmic product)',
+}
+DTYPE = {'fp32': 'f32', 'bf16x3': 'bf16x3 (fp32 operands split into 2 bf16 limbs, fp32 accumulate)',
+         'bf16x6': 'bf16x6 (fp32 operands split into 3 bf16 limbs, fp32 accumulate)'}
 
 
 def cpu_baseline(budget_s=20.0):
@@ -82,6 +92,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
+    ap.add_argument('--precision', default=os.environ.get('GANGEALING_CONV_PRECISION', 'bf16x3'),
+                    choices=['fp32', 'bf16x3', 'bf16x6'],
+                    help='arithmetic of the implicit-GEMM convolutions (fp32 = exact fp32 MFMA parity mode)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
@@ -91,6 +104,7 @@ def main():
     from gangealing_amd import distributed as gdist
     from gangealing_amd.op import conv_mfma
     from gangealing_amd.train_step import GangealingTrainer
+    conv_mfma.set_precision(args.precision)
 
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -142,7 +156,7 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': DTYPE[args.precision],
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: gen {wl["gen_size"]}^2, STN {"+".join(wl["transform"])} @ '
                                    f'{wl["flow_size"]}^2, per-GPU batch {wl["batch"]}, VGG16-topology perceptual loss '
@@ -150,9 +164,11 @@ def main():
                        'global_batch': world * wl['batch'], 'parallelism': f'dp{world}',
                        'loss': float(parts['p'])},
             'roofline': {
-                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
-                'kernel': 'conv_igemm_kernel<3,0,2,2,2,2> (3x3 correlation, 128co x 128pix tile, fp32 MFMA)',
+                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS[args.precision],
+                'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS[args.precision], 4), 'traffic': None,
+                'kernel': KERNEL_NAME[args.precision],
+                'note': 'achieved = algorithmic conv FLOPs (2*N*Cin*Cout*9*OH*OW per launch) / HIP-event time; '
+                        'peak = dense MFMA peak of the instruction used',
                 'launches': psum['launches'],
                 'avg_launch_ms': round(psum['total_ms'] / max(psum['launches'], 1), 4),
                 'avg_launch_gflop': round(psum['total_flops'] / max(psum['launches'], 1) / 1e9, 3),

@@ -41,6 +41,8 @@ _PROTOS = {
     'gg_flow_losses_bwd_f32': 'pppiiis',
     'gg_conv_pack_weight_f32': 'ppiiiiiiifs',
     'gg_conv2d_f32': 'ppppppiiiiiiiiiiiis',
+    'gg_conv_pack_weight_split': 'ppiiiiiiifis',
+    'gg_conv2d_split_f32': 'pppqipppiiiiiiiiiiiis',
     'gg_conv2d_wgrad_f32': 'pppiiiiiiiiifs',
     'gg_plane_dot_f32': 'pppiqs',
     'gg_adam_ema_f32': 'pppppqffffiffs',

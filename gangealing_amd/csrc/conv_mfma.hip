@@ -49,6 +49,8 @@ struct ConvArgs {
   int ktot;              // cin_g * ntaps
   int tiles_co, tiles_pix;
   int splitk, slabs_per_split, nslabs;
+  const unsigned short* wsplit;   // bf16 limb planes [limb][g][co][k = (tap, ci)]  (split-precision path)
+  long long wsplit_stride;        // elements between limb planes
 };
 
 // k -> (ci, ky, kx, dy, dx).  MODE 0: correlation taps; MODE 1: taps of one parity class.
@@ -252,6 +254,250 @@ __global__ __launch_bounds__(WCO * WPIX * 64) void conv_igemm_kernel(const ConvA
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-precision variant: the same implicit GEMM on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16,
+// 16x the fp32 MFMA rate).  Every fp32 operand is split into LIMBS bf16 limbs (x = x0 + x1 (+ x2),
+// each limb the bf16 rounding of the remaining residual) and the product is assembled from the limb
+// pairs (i, j) with i + j < LIMBS, accumulated in fp32:
+//     LIMBS = 2 -> 3 MFMAs per tile step, |error| ~ 2^-16 |a||b| per product  ("bf16x3")
+//     LIMBS = 3 -> 6 MFMAs per tile step, |error| ~ 2^-23 |a||b|: fp32-class ("bf16x6")
+// K is ordered (tap, ci) with ci fastest, so a 32-wide K slab is ONE tap and 32 consecutive input
+// channels: one bounds test and one base address per thread per slab, 16 loads at a constant channel
+// stride (each wave-load is 64 consecutive pixels), then cvt_pk splits.  LDS tiles are [row][k] with
+// k contiguous (80-byte rows: 5 x 16 B slots, odd -> conflict-free ds_read_b128 / ds_write_b128);
+// a fragment is one 16-byte read.  Single LDS buffer + register prefetch, two barriers per slab.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BKS = 32;                 // K per slab
+constexpr int EPT = BKS / 2;            // gathered elements (and weight k's) per thread per slab
+constexpr int ROWB = BKS * 2 + 16;      // bytes per LDS row
+
+struct U4 { unsigned x, y, z, w; };
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+template <int KS, int MODE, int LIMBS, bool IN_SCALE>
+__global__ __launch_bounds__(256) void conv_split_kernel(const ConvArgs a) {
+  constexpr int TCO = 128, TPIX = 128, MI = 2, NJ = 2;
+  __shared__ __attribute__((aligned(16))) unsigned char sW[LIMBS][TCO * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char sX[LIMBS][TPIX * ROWB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wco = wid >> 1, wpix = wid & 1;
+  const unsigned ntiles = (unsigned)a.tiles_co * a.tiles_pix;
+  const unsigned logical = gg::xcd_remap(blockIdx.x, ntiles);
+  const int tile_co = logical % a.tiles_co, tile_pix = logical / a.tiles_co;
+  const int split = blockIdx.y, g = blockIdx.z;
+  const int co0 = tile_co * TCO;
+  const long long m0 = (long long)tile_pix * TPIX;
+  const long long mtot = (long long)a.batch * a.mh * a.mw;
+  const int hw = a.h * a.w;
+
+  // ---- gather column: pixel (tid & 127), channel half (tid >> 7) -> 16 consecutive ci of the slab
+  const int pcol = tid & 127, khalf = tid >> 7;
+  const long long m = m0 + pcol;
+  const bool m_ok = m < mtot;
+  int pn = 0, base_y = 0, base_x = 0;
+  if (m_ok) {
+    const int per = a.mh * a.mw;
+    pn = (int)(m / per);
+    const int rem = (int)(m - (long long)pn * per);
+    const int qy = rem / a.mw, qx = rem - qy * a.mw;
+    base_y = qy * a.bs + a.byo;
+    base_x = qx * a.bs + a.bxo;
+  }
+  const int chan0 = (pn * a.groups + g) * a.cin_g;
+  const float* xg = a.x + (size_t)chan0 * hw;
+  const float* sg = IN_SCALE ? a.in_scale + chan0 : nullptr;
+  // ---- weight rows: row (tid >> 1), 16-k part (tid & 1)
+  const int wrow = tid >> 1, wpart = tid & 1;
+  const bool w_ok = (co0 + wrow) < a.cout_g;
+  const int kfull = KS * KS * a.cin_g;
+  const unsigned short* wrow_ptr = a.wsplit + ((size_t)g * a.cout_g + (w_ok ? co0 + wrow : 0)) * kfull + wpart * EPT;
+
+  const int cslabs = a.cin_g / BKS;                 // slabs per tap
+  const int slab0 = split * a.slabs_per_split;
+  int slab1 = slab0 + a.slabs_per_split;
+  if (slab1 > a.nslabs) slab1 = a.nslabs;
+
+  float xa[EPT];
+  float4 rs4[EPT / 4];
+  U4 wv[LIMBS][EPT / 8];
+  bool x_ok = false;
+
+  auto load_slab = [&](int slab) {
+    const int t = slab / cslabs;
+    const int ci0 = (slab - t * cslabs) * BKS;
+    int ky, kx, dy, dx;
+    if (MODE == 0) {
+      ky = t / KS; kx = t - ky * KS; dy = ky; dx = kx;
+    } else {
+      const int jy = (a.ntx == 2) ? (t >> 1) : t;
+      const int jx = (a.ntx == 2) ? (t & 1) : 0;
+      ky = a.py + 2 * jy; kx = a.px + 2 * jx; dy = -jy; dx = -jx;
+    }
+    const int iy = base_y + dy, ix = base_x + dx;
+    x_ok = m_ok & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
+    const int cbase = ci0 + khalf * EPT;
+    const float* src = xg + (x_ok ? (size_t)cbase * hw + iy * a.w + ix : 0);
+    const int step = x_ok ? hw : 0;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) xa[j] = src[(size_t)j * step];
+    if (IN_SCALE) {
+      const float4* s4 = reinterpret_cast<const float4*>(sg + cbase);
+#pragma unroll
+      for (int j = 0; j < EPT / 4; ++j) rs4[j] = s4[j];
+    }
+    const unsigned short* wsrc = wrow_ptr + (size_t)(ky * KS + kx) * a.cin_g + ci0;
+#pragma unroll
+    for (int l = 0; l < LIMBS; ++l) {
+      const U4* w4 = reinterpret_cast<const U4*>(wsrc + (size_t)l * a.wsplit_stride);
+#pragma unroll
+      for (int q = 0; q < EPT / 8; ++q) wv[l][q] = w4[q];
+    }
+  };
+  auto store_slab = [&]() {
+    float v[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) v[j] = x_ok ? xa[j] : 0.f;
+    if (IN_SCALE) {
+      const float* rs = reinterpret_cast<const float*>(rs4);
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) v[j] *= rs[j];
+    }
+#pragma unroll
+    for (int l = 0; l < LIMBS; ++l) {
+      unsigned pk[EPT / 2];
+#pragma unroll
+      for (int j = 0; j < EPT / 2; ++j) {
+        pk[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+        if (l + 1 < LIMBS) {                       // residual for the next limb
+          v[2 * j] -= bf16_lo(pk[j]);
+          v[2 * j + 1] -= bf16_hi(pk[j]);
+        }
+      }
+      U4* dst = reinterpret_cast<U4*>(&sX[l][pcol * ROWB + khalf * EPT * 2]);
+      U4* wd = reinterpret_cast<U4*>(&sW[l][wrow * ROWB + wpart * EPT * 2]);
+      const U4 z{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int q = 0; q < EPT / 8; ++q) {
+        dst[q] = U4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
+        wd[q] = w_ok ? wv[l][q] : z;
+      }
+    }
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (slab0 < slab1) {
+    const int kh = lane >> 5, l31 = lane & 31;
+    load_slab(slab0);
+    for (int slab = slab0; slab < slab1; ++slab) {
+      store_slab();
+      __syncthreads();
+      if (slab + 1 < slab1) load_slab(slab + 1);
+#pragma unroll
+      for (int ks = 0; ks < BKS / 16; ++ks) {
+        bf16x8 fa[LIMBS][MI], fb[LIMBS][NJ];
+#pragma unroll
+        for (int l = 0; l < LIMBS; ++l) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+            fa[l][i] = *reinterpret_cast<const bf16x8*>(&sW[l][((wco * MI + i) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            fb[l][j] = *reinterpret_cast<const bf16x8*>(&sX[l][((wpix * NJ + j) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
+        }
+        // smallest terms first
+#pragma unroll
+        for (int sum = LIMBS - 1; sum >= 0; --sum)
+#pragma unroll
+          for (int la = 0; la <= sum; ++la) {
+            const int lb = sum - la;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la][i], fb[lb][j], acc[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+  }
+
+  const int ohw = a.oh * a.ow;
+  const bool atomic = a.splitk > 1;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const long long mm = m0 + (wpix * NJ + j) * 32 + (lane & 31);
+    if (mm >= mtot) continue;
+    const int per = a.mh * a.mw;
+    const int on = (int)(mm / per);
+    const int rem = (int)(mm - (long long)on * per);
+    const int qy = rem / a.mw, qx = rem - qy * a.mw;
+    const int oy = qy * a.ys + a.yo, ox = qx * a.xs + a.xo;
+    const int ochan0 = (on * a.groups + g) * a.cout_g;
+    float* yp = a.y + (size_t)ochan0 * ohw + (size_t)oy * a.ow + ox;
+    const float* osc = a.out_scale ? a.out_scale + ochan0 : nullptr;
+    const float* bia = (a.bias && split == 0) ? a.bias + g * a.cout_g : nullptr;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wco * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co >= a.cout_g) continue;
+        float v = acc[i][j][r];
+        if (osc) v *= osc[co];
+        if (bia) v += bia[co];
+        if (atomic) unsafeAtomicAdd(yp + (size_t)co * ohw, v);
+        else yp[(size_t)co * ohw] = v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_weight_split_kernel(unsigned short* __restrict__ wl,
+                                                                const float* __restrict__ w, long long total,
+                                                                long long limb_stride, int cout_g, int cin_g, int kh,
+                                                                int kw, int transpose_io, int flip, float scale,
+                                                                int limbs) {
+  // wl[limb][g][c][(tap, r)], r (reduction channel) fastest
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int kk = kh * kw;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const int r = (int)(o % cin_g);
+    long long q = o / cin_g;
+    const int tap = (int)(q % kk);
+    q /= kk;
+    const int c = (int)(q % cout_g);
+    const int g = (int)(q / cout_g);
+    int ky = tap / kw, kx = tap % kw;
+    if (flip) { ky = kh - 1 - ky; kx = kw - 1 - kx; }
+    const size_t src = transpose_io ? (((size_t)g * cin_g + r) * cout_g + c) * kk + ky * kw + kx
+                                    : (((size_t)g * cout_g + c) * cin_g + r) * kk + ky * kw + kx;
+    float v = w[src] * scale;
+    for (int l = 0; l < limbs; ++l) {
+      const __bf16 h = (__bf16)v;
+      wl[(size_t)l * limb_stride + o] = __builtin_bit_cast(unsigned short, h);
+      v -= (float)h;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient:  dW[co, j] = sum_{pix} dy[n, co, pix] * x[n, ci(j), pix*stride + tap(j) - pad]
 //   D[i = co][j = (ci,ky,kx)], reduction index k = pixel.  Both global operands are contiguous
 //   along the pixel axis, so they are loaded lane-along-k (128 B rows) and stored to LDS as
@@ -446,19 +692,19 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(float* __restrict__ out,
 
 // Fill in tiling / split-K for one launch.  Returns false when the launch is empty.
 // tile: 0 = 128co x 128pix, 1 = 32co x 256pix, 2 = 64co x 256pix
-bool plan_conv(ConvArgs& a, int tile) {
+bool plan_conv(ConvArgs& a, int tile, int bk = BK) {
   const int tco = tile == 0 ? 128 : (tile == 1 ? 32 : 64), tpix = tile == 0 ? 128 : 256;
   const long long mtot = (long long)a.batch * a.mh * a.mw;
   if (mtot <= 0) return false;
   a.tiles_co = (a.cout_g + tco - 1) / tco;
   const long long tp = (mtot + tpix - 1) / tpix;
   a.tiles_pix = (int)tp;
-  a.nslabs = (a.ktot + BK - 1) / BK;
+  a.nslabs = (a.ktot + bk - 1) / bk;
   const long long blocks = tp * a.tiles_co * a.groups;
   int splitk = 1;
   if (blocks < 2 * gg::kNumCu) {
     splitk = (int)((2 * gg::kNumCu + blocks - 1) / blocks);
-    const int max_split = (a.nslabs + 7) / 8;      // keep >= 8 slabs (128 k) per split
+    const int max_split = (a.nslabs * bk + 127) / 128;      // keep >= 128 k per split
     if (splitk > max_split) splitk = max_split;
     if (splitk < 1) splitk = 1;
   }
@@ -486,8 +732,23 @@ int launch_conv(const ConvArgs& a, int tile, hipStream_t st) {
   return gg::launch_status("conv_igemm");
 }
 
+template <int KS, int MODE>
+int launch_conv_split(const ConvArgs& a, int limbs, hipStream_t st) {
+  if ((long long)a.tiles_pix * a.tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
+  dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
+  const bool sc = a.in_scale != nullptr;
+  if (limbs == 2) {
+    if (sc) conv_split_kernel<KS, MODE, 2, true><<<grid, 256, 0, st>>>(a);
+    else conv_split_kernel<KS, MODE, 2, false><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (sc) conv_split_kernel<KS, MODE, 3, true><<<grid, 256, 0, st>>>(a);
+    else conv_split_kernel<KS, MODE, 3, false><<<grid, 256, 0, st>>>(a);
+  }
+  return gg::launch_status("conv_split");
+}
+
 template <int KS>
-int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st) {
+int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {
   // tile selector.  (Measured on the 128->128 @256^2 layer: an 8-wave 128x128 variant, a 128co x 256pix
   // variant with 8 accumulators per wave and BK = 32 are all within -20..+1 % of this 4-wave tile.)
   const int narrow = a.cout_g <= 32 ? 1 : (a.cout_g <= 64 ? 2 : 0);
@@ -500,7 +761,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st) {
     a.bs = stride; a.byo = -pad; a.bxo = -pad;
     a.py = a.px = 0; a.nty = a.ntx = KS;
     a.ktot = a.cin_g * KS * KS;
-    if (plan_conv(a, narrow)) plans[nplans++] = a;
+    if (plan_conv(a, limbs ? 0 : narrow, limbs ? BKS : BK)) plans[nplans++] = a;
   } else {
     // transposed, stride 2: one dense sub-problem per parity class of u = y + pad
     for (int py = 0; py < 2; ++py) {
@@ -523,7 +784,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st) {
         c.bs = 1; c.byo = qy0; c.bxo = qx0;
         c.py = py; c.px = px; c.nty = nty; c.ntx = ntx;
         c.ktot = a.cin_g * nty * ntx;
-        if (plan_conv(c, narrow)) plans[nplans++] = c;
+        if (plan_conv(c, limbs ? 0 : narrow, limbs ? BKS : BK)) plans[nplans++] = c;
       }
     }
   }
@@ -534,7 +795,9 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st) {
     if (e != hipSuccess) return gg::fail((int)e, "conv2d: memset failed");
   }
   for (int i = 0; i < nplans; ++i) {
-    const int rc = (mode == 0) ? launch_conv<KS, 0>(plans[i], narrow, st) : launch_conv<KS, 1>(plans[i], narrow, st);
+    int rc;
+    if (limbs) rc = (mode == 0) ? launch_conv_split<KS, 0>(plans[i], limbs, st) : launch_conv_split<KS, 1>(plans[i], limbs, st);
+    else rc = (mode == 0) ? launch_conv<KS, 0>(plans[i], narrow, st) : launch_conv<KS, 1>(plans[i], narrow, st);
     if (rc) return rc;
   }
   return 0;
@@ -553,12 +816,13 @@ extern "C" int gg_conv_pack_weight_f32(float* wmat, const float* w, int groups, 
   return gg::launch_status("conv_pack_weight");
 }
 
-extern "C" int gg_conv2d_f32(float* y, const float* x, const float* wmat, const float* in_scale,
-                             const float* out_scale, const float* bias, int batch, int groups, int cin_g, int cout_g,
-                             int h, int w, int ksize, int stride, int pad, int mode, int out_h, int out_w,
-                             void* stream) {
+namespace {
+int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned short* wsplit, long long wsplit_stride,
+                 int limbs, const float* in_scale, const float* out_scale, const float* bias, int batch, int groups,
+                 int cin_g, int cout_g, int h, int w, int ksize, int stride, int pad, int mode, int out_h, int out_w,
+                 void* stream) {
   if (batch <= 0 || groups <= 0 || cin_g <= 0 || cout_g <= 0) return 0;
-  if (!y || !x || !wmat || h <= 0 || w <= 0) return gg::fail(-2, "conv2d: bad arguments");
+  if (!y || !x || (!wmat && !wsplit) || h <= 0 || w <= 0) return gg::fail(-2, "conv2d: bad arguments");
   if (ksize != 1 && ksize != 3) return gg::fail(-2, "conv2d: kernel size %d not supported (1 or 3)", ksize);
   if (groups > 65535) return gg::fail(-2, "conv2d: too many groups");
   if (mode != 0 && mode != 1) return gg::fail(-2, "conv2d: mode must be 0 or 1");
@@ -566,8 +830,15 @@ extern "C" int gg_conv2d_f32(float* y, const float* x, const float* wmat, const 
   if (mode == 0 && (stride < 1 || stride > 2)) return gg::fail(-2, "conv2d: stride must be 1 or 2");
   if (mode == 1 && stride != 2)
     return gg::fail(-2, "conv2d: transposed mode is implemented for stride 2 (stride 1 = mode 0 with flipped taps)");
+  if (limbs) {
+    if (limbs != 2 && limbs != 3) return gg::fail(-2, "conv2d_split: limbs must be 2 or 3");
+    if (cin_g % BKS != 0) return gg::fail(-2, "conv2d_split: cin per group must be a multiple of %d", BKS);
+    if (in_scale && (reinterpret_cast<uintptr_t>(in_scale) & 15)) return gg::fail(-2, "conv2d_split: in_scale must be 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(wsplit) & 15) return gg::fail(-2, "conv2d_split: weights must be 16-byte aligned");
+  }
   ConvArgs a;
   a.y = y; a.x = x; a.wmat = wmat; a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
+  a.wsplit = wsplit; a.wsplit_stride = wsplit_stride;
   a.batch = batch; a.groups = groups; a.cin_g = cin_g; a.cout_g = cout_g; a.h = h; a.w = w;
   if (mode == 0) {
     a.oh = (h + 2 * pad - ksize) / stride + 1;
@@ -582,7 +853,35 @@ extern "C" int gg_conv2d_f32(float* y, const float* x, const float* wmat, const 
   }
   if (a.oh <= 0 || a.ow <= 0) return 0;
   hipStream_t st = gg::as_stream(stream);
-  return ksize == 3 ? conv_dispatch<3>(a, stride, pad, mode, st) : conv_dispatch<1>(a, stride, pad, mode, st);
+  return ksize == 3 ? conv_dispatch<3>(a, stride, pad, mode, st, limbs) : conv_dispatch<1>(a, stride, pad, mode, st, limbs);
+}
+}  // namespace
+
+extern "C" int gg_conv2d_f32(float* y, const float* x, const float* wmat, const float* in_scale,
+                             const float* out_scale, const float* bias, int batch, int groups, int cin_g, int cout_g,
+                             int h, int w, int ksize, int stride, int pad, int mode, int out_h, int out_w,
+                             void* stream) {
+  return conv2d_entry(y, x, wmat, nullptr, 0, 0, in_scale, out_scale, bias, batch, groups, cin_g, cout_g, h, w, ksize,
+                      stride, pad, mode, out_h, out_w, stream);
+}
+
+extern "C" int gg_conv2d_split_f32(float* y, const float* x, const unsigned short* wsplit, long long limb_stride,
+                                   int limbs, const float* in_scale, const float* out_scale, const float* bias,
+                                   int batch, int groups, int cin_g, int cout_g, int h, int w, int ksize, int stride,
+                                   int pad, int mode, int out_h, int out_w, void* stream) {
+  return conv2d_entry(y, x, nullptr, wsplit, limb_stride, limbs, in_scale, out_scale, bias, batch, groups, cin_g,
+                      cout_g, h, w, ksize, stride, pad, mode, out_h, out_w, stream);
+}
+
+extern "C" int gg_conv_pack_weight_split(unsigned short* wsplit, const float* w, int groups, int cout_g, int cin_g,
+                                         int kh, int kw, int transpose_io, int flip, float scale, int limbs,
+                                         void* stream) {
+  const long long total = (long long)groups * cout_g * cin_g * kh * kw;
+  if (total <= 0) return 0;
+  if (!wsplit || !w || limbs < 1 || limbs > 3) return gg::fail(-2, "conv_pack_weight_split: bad arguments");
+  pack_weight_split_kernel<<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(
+      wsplit, w, total, total, cout_g, cin_g, kh, kw, transpose_io, flip, scale, limbs);
+  return gg::launch_status("conv_pack_weight_split");
 }
 
 extern "C" int gg_conv2d_wgrad_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g,

@@ -27,6 +27,51 @@ class LaunchProfiler:
 
 PROFILER = None
 
+# Arithmetic of the implicit-GEMM convolutions:
+#   'fp32'   v_mfma_f32_32x32x2_f32 - exact fp32 products (the parity mode, default)
+#   'bf16x3' / 'bf16x6'  bf16 matrix pipe with 2 / 3 bf16 limbs per fp32 operand (3 / 6 MFMAs per tile step,
+#            fp32 accumulation): ~2^-16 / ~2^-23 relative error per product.  Layers whose input-channel
+#            count is not a multiple of 32 (3-channel stems) or with <= 32 outputs stay on the fp32 kernel.
+import os as _os
+PRECISION = _os.environ.get('GANGEALING_CONV_PRECISION', 'fp32')
+_LIMBS = {'fp32': 0, 'bf16x3': 2, 'bf16x6': 3}
+
+
+def set_precision(mode):
+    global PRECISION
+    if mode not in _LIMBS:
+        raise ValueError(f'unknown conv precision {mode!r}; choose from {sorted(_LIMBS)}')
+    PRECISION = mode
+
+
+class PackedWeight:
+    """GEMM-layout view(s) of one convolution weight, built lazily per arithmetic mode.
+    (cout_g, cin_g) are those OF THE CONVOLUTION BEING RUN (reduction channels = cin_g)."""
+
+    def __init__(self, weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0):
+        self.weight, self.groups, self.cout_g, self.cin_g, self.k = weight, groups, cout_g, cin_g, k
+        self.transpose_io, self.flip, self.scale = int(transpose_io), int(flip), float(scale)
+        self._fp32 = None
+        self._split = {}
+
+    def fp32(self):
+        if self._fp32 is None:
+            self._fp32 = pack_weight(self.weight, self.groups, self.cout_g, self.cin_g, self.k, self.transpose_io,
+                                     self.flip, self.scale)
+        return self._fp32
+
+    def split_ok(self):
+        return self.cin_g % 32 == 0 and self.cout_g > 32
+
+    def split(self, limbs):
+        if limbs not in self._split:
+            n = self.groups * self.cout_g * self.cin_g * self.k * self.k
+            buf = torch.empty((limbs, n), dtype=torch.int16, device=self.weight.device)
+            _lib.call('gg_conv_pack_weight_split', buf, self.weight.contiguous(), self.groups, self.cout_g,
+                      self.cin_g, self.k, self.k, self.transpose_io, self.flip, self.scale, limbs)
+            self._split[limbs] = (buf, n)
+        return self._split[limbs]
+
 
 def _pair_eq(v, name):
     if isinstance(v, (tuple, list)):
@@ -56,12 +101,20 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             oh, ow = out_hw
     y = torch.empty((batch, groups * cout_g, oh, ow), dtype=torch.float32, device=x.device)
     if y.numel():
-        prof = PROFILER if (PROFILER is not None and k == 3 and mode == 0 and cout_g > 32) else None
+        limbs = _LIMBS[PRECISION]
+        use_split = limbs > 0 and isinstance(wmat, PackedWeight) and wmat.split_ok()
+        prof = PROFILER if (PROFILER is not None and k == 3 and mode == 0 and cout_g > 64) else None
         if prof is not None:
             start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record()
-        _lib.call('gg_conv2d_f32', y, x, wmat, in_scale, out_scale, bias, batch, groups, cin_g, cout_g, h, w,
-                  k, stride, pad, mode, oh if mode == 1 else 0, ow if mode == 1 else 0)
+        if use_split:
+            wbuf, stride_l = wmat.split(limbs)
+            _lib.call('gg_conv2d_split_f32', y, x, wbuf, stride_l, limbs, in_scale, out_scale, bias, batch, groups,
+                      cin_g, cout_g, h, w, k, stride, pad, mode, oh if mode == 1 else 0, ow if mode == 1 else 0)
+        else:
+            wm = wmat.fp32() if isinstance(wmat, PackedWeight) else wmat
+            _lib.call('gg_conv2d_f32', y, x, wm, in_scale, out_scale, bias, batch, groups, cin_g, cout_g, h, w,
+                      k, stride, pad, mode, oh if mode == 1 else 0, ow if mode == 1 else 0)
         if prof is not None:
             end.record()
             prof.records.append((start, end, 2.0 * batch * groups * cout_g * cin_g * k * k * oh * ow))
@@ -95,16 +148,16 @@ class _Conv2d(Function):
         if not transposed:
             cout_g = weight.shape[0] // groups
             assert weight.shape[1] == cin_g, 'weight / input channel mismatch'
-            wmat = pack_weight(weight, groups, cout_g, cin_g, k, transpose_io=0, flip=0, scale=wscale)
+            wmat = PackedWeight(weight, groups, cout_g, cin_g, k, 0, 0, wscale)
             y = conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, padding, 0, bias=bias)
         else:
             cout_g = weight.shape[1]
             assert weight.shape[0] == cin, 'weight / input channel mismatch'
             if stride == 1:      # transposed stride-1 == correlation with flipped taps
-                wmat = pack_weight(weight, groups, cout_g, cin_g, k, transpose_io=1, flip=1, scale=wscale)
+                wmat = PackedWeight(weight, groups, cout_g, cin_g, k, 1, 1, wscale)
                 y = conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, 1, k - 1 - padding, 0, bias=bias)
             else:
-                wmat = pack_weight(weight, groups, cout_g, cin_g, k, transpose_io=1, flip=0, scale=wscale)
+                wmat = PackedWeight(weight, groups, cout_g, cin_g, k, 1, 0, wscale)
                 h, w = x.shape[-2:]
                 oh = (h - 1) * 2 - 2 * padding + k + output_padding
                 ow = (w - 1) * 2 - 2 * padding + k + output_padding
@@ -124,17 +177,17 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0]:
             if not transposed:
                 if stride == 1:
-                    wm = pack_weight(weight, groups, cin_g, cout_g, k, transpose_io=1, flip=1, scale=wscale)
+                    wm = PackedWeight(weight, groups, cin_g, cout_g, k, 1, 1, wscale)
                     dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, k - 1 - padding, 0)
                 else:
-                    wm = pack_weight(weight, groups, cin_g, cout_g, k, transpose_io=1, flip=0, scale=wscale)
+                    wm = PackedWeight(weight, groups, cin_g, cout_g, k, 1, 0, wscale)
                     dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 1, out_hw=(h, w))
             else:
                 if stride == 1:
-                    wm = pack_weight(weight, groups, cin_g, cout_g, k, transpose_io=0, flip=0, scale=wscale)
+                    wm = PackedWeight(weight, groups, cin_g, cout_g, k, 0, 0, wscale)
                     dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, padding, 0)
                 else:
-                    wm = pack_weight(weight, groups, cin_g, cout_g, k, transpose_io=0, flip=0, scale=wscale)
+                    wm = PackedWeight(weight, groups, cin_g, cout_g, k, 0, 0, wscale)
                     dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 0)
                     dx = dx[..., :h, :w].contiguous() if dx.shape[-2:] != (h, w) else dx
         if ctx.needs_input_grad[1]:
@@ -188,7 +241,7 @@ class _ModulatedConv(Function):
         x = x.contiguous()
         style = style.contiguous()
         n, cin, h, w = x.shape
-        cout = wmat_fwd.shape[-1]
+        cout = wmat_fwd.cout_g
         demod = None
         if demodulate:
             demod = torch.rsqrt((style * style) @ wsq.t() + 1e-8)
@@ -196,13 +249,15 @@ class _ModulatedConv(Function):
             y = conv_forward(x, wmat_fwd, n, 1, cin, cout, k, 2, 0, 1, in_scale=style, out_scale=demod)
         else:
             y = conv_forward(x, wmat_fwd, n, 1, cin, cout, k, 1, k // 2, 0, in_scale=style, out_scale=demod)
-        ctx.save_for_backward(x, style, demod if demod is not None else style.new_empty(0), y, wmat_bwd, wsq)
+        ctx.save_for_backward(x, style, demod if demod is not None else style.new_empty(0), y, wsq)
+        ctx.wmat_bwd = wmat_bwd
         ctx.conf = (k, upsample, demodulate)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, style, demod, y, wmat_bwd, wsq = ctx.saved_tensors
+        x, style, demod, y, wsq = ctx.saved_tensors
+        wmat_bwd = ctx.wmat_bwd
         k, upsample, demodulate = ctx.conf
         dy = dy.contiguous()
         n, cin, h, w = x.shape

@@ -161,10 +161,10 @@ class ModulatedConv2d(nn.Module):
             with torch.no_grad():
                 w4 = w[0]
                 k, cin, cout = self.kernel_size, self.in_channel, self.out_channel
-                wmat_fwd = conv_mfma.pack_weight(w4, 1, cout, cin, k, transpose_io=0, flip=0, scale=self.scale)
+                w4 = w4.detach().clone()          # the packs are built lazily per arithmetic mode
+                wmat_fwd = conv_mfma.PackedWeight(w4, 1, cout, cin, k, 0, 0, self.scale)
                 # dgrad: reduce over co.  plain conv -> flipped taps; transposed stride-2 conv -> strided correlation
-                wmat_bwd = conv_mfma.pack_weight(w4, 1, cin, cout, k, transpose_io=1, flip=0 if self.upsample else 1,
-                                                 scale=self.scale)
+                wmat_bwd = conv_mfma.PackedWeight(w4, 1, cin, cout, k, 1, 0 if self.upsample else 1, self.scale)
                 wsq = (w4 * self.scale).pow(2).sum(dim=(2, 3)).contiguous()
             self._packed = (key, wmat_fwd, wmat_bwd, wsq)
         return self._packed[1:]

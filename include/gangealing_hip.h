@@ -203,6 +203,18 @@ int gg_conv_pack_weight_f32(float* wmat, const float* w, int groups, int cout_g,
 int gg_conv2d_f32(float* y, const float* x, const float* wmat, const float* in_scale, const float* out_scale,
                   const float* bias, int batch, int groups, int cin_g, int cout_g, int h, int w,
                   int ksize, int stride, int pad, int mode, int out_h, int out_w, void* stream);
+/* Split-precision variant of gg_conv2d_f32 on the bf16 matrix pipe (16x the fp32 MFMA rate): every fp32
+ * operand is split into `limbs` bf16 limbs and the product is assembled from the limb pairs (i,j), i+j <
+ * limbs, accumulated in fp32.  limbs = 2: 3 MFMAs, error ~2^-16 per product; limbs = 3: 6 MFMAs, fp32-class.
+ * Weights come pre-split from gg_conv_pack_weight_split: bf16 planes wsplit[limb][g][co][k], K ordered
+ * (tap, ci) with ci fastest, limb planes `limb_stride` elements apart (= groups*cout_g*cin_g*kh*kw).
+ * Requires cin_g % 32 == 0; every other argument as gg_conv2d_f32. */
+int gg_conv_pack_weight_split(unsigned short* wsplit, const float* w, int groups, int cout_g, int cin_g, int kh,
+                              int kw, int transpose_io, int flip, float scale, int limbs, void* stream);
+int gg_conv2d_split_f32(float* y, const float* x, const unsigned short* wsplit, long long limb_stride, int limbs,
+                        const float* in_scale, const float* out_scale, const float* bias, int batch, int groups,
+                        int cin_g, int cout_g, int h, int w, int ksize, int stride, int pad, int mode, int out_h,
+                        int out_w, void* stream);
 /* Weight gradient: dw (groups, cout_g, cin_g, k, k) torch layout, overwritten.
  *   dw[g,co,ci,ky,kx] = sum_{n,oy,ox} dy[n,g*cout_g+co,oy,ox] * x[n,g*cin_g+ci, oy*stride+ky-pad, ox*stride+kx-pad] */
 int gg_conv2d_wgrad_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g, int cout_g,

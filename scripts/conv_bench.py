@@ -31,13 +31,18 @@ def layer(name, cin, cout, h, k, stride, pad, mode, scale=True, only=None):
         return
     x = torch.randn(N, cin, h, h, device=dev)
     w = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
-    wm = cm.pack_weight(w, 1, cout, cin, k, 0, 0)
+    wm = cm.PackedWeight(w, 1, cout, cin, k, 0, 0)
     s_in = torch.rand(N, cin, device=dev) + 0.5 if scale else None
     s_out = torch.rand(N, cout, device=dev) + 0.5 if scale else None
     y = cm.conv_forward(x, wm, N, 1, cin, cout, k, stride, pad, mode, in_scale=s_in, out_scale=s_out)
     oh = y.shape[-1]
     flops = 2.0 * N * cin * cout * k * k * (oh * oh if mode == 0 else h * h)
     t = timeit(lambda: cm.conv_forward(x, wm, N, 1, cin, cout, k, stride, pad, mode, in_scale=s_in, out_scale=s_out))
+    if cm.PRECISION != 'fp32':
+        cm.set_precision('fp32'); yref = cm.conv_forward(x, wm, N, 1, cin, cout, k, stride, pad, mode, in_scale=s_in, out_scale=s_out)
+        cm.set_precision(os.environ['GANGEALING_CONV_PRECISION'])
+        err = float((y - yref).abs().max() / yref.abs().max())
+        name = name + f' [relerr {err:.1e}]'
     line = f'{name:34s} {cin:4d}->{cout:4d} {h:4d}->{oh:4d} k{k} s{stride} m{mode}  fwd {t:8.3f} ms {flops / t / 1e9:7.1f} TF'
     if mode == 0 and not scale:
         dy = torch.randn_like(y)

@@ -23,7 +23,7 @@ def T(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-def test_generator_golden(cuda):
+def test_generator_golden(cuda, grad_tol=(2e-3, 1e-3)):
     from gangealing_amd.stylegan2 import Generator
     (c,) = load_golden('generator16')
     g = load_det(Generator(16, 512, 8)).to(cuda).eval().requires_grad_(False)
@@ -35,7 +35,7 @@ def test_generator_golden(cuda):
     img2, _ = g([w.unsqueeze(1).repeat(1, g.n_latent, 1)], input_is_latent=True, noise=noise)
     close(img2, c['img_from_w'], 2e-4)
     img2.backward(T(c['gimg'], cuda))
-    close(w.grad, c['gw'], 2e-3, 1e-3)
+    close(w.grad, c['gw'], *grad_tol)
 
 
 @pytest.mark.parametrize('case', load_golden('stn'), ids=lambda c: '+'.join(c['meta']['transforms']))
@@ -83,7 +83,7 @@ def test_stn_golden(case, cuda):
         close(grads[match[0]], case[key], 2e-4, 2e-3)
 
 
-def test_train_step_golden(cuda):
+def test_train_step_golden(cuda, grad_rel=5e-3):
     """gangealing_loss + TV + identity (loss.py:64-75, train.py:117-124) with explicit z / noise."""
     from oracle.det_weights import det_array
     from gangealing_amd.stylegan2 import Generator
@@ -118,14 +118,14 @@ def test_train_step_golden(cuda):
     total = ploss + m['tv_weight'] * reg[0] + m['flow_identity_weight'] * reg[1]
     close(total, c['total'], 1e-4)
     total.backward()
-    close(ll.coefficients.grad, c['g_coefficients'], 1e-4, 2e-3)
+    close(ll.coefficients.grad, c['g_coefficients'], 1e-4 * grad_rel / 5e-3, 2e-3 * grad_rel / 5e-3)
     worst = 0.0
     grads = dict((n, p.grad) for n, p in stn.named_parameters())
     for name, ref_norm in m['grad_norms'].items():
         if name == 'll.coefficients':
             continue
         worst = max(worst, abs(float(grads[name].double().norm()) - ref_norm) / max(ref_norm, 1e-9))
-    assert worst < 5e-3, worst
+    assert worst < grad_rel, worst
 
 
 def test_trainer_step_runs_and_updates(cuda):
