@@ -81,6 +81,23 @@ def _pair_eq(v, name):
     return int(v)
 
 
+_FROZEN_PACKS = {}
+
+
+def packed(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0):
+    """PackedWeight for `weight`; weights that do not require grad (frozen VGG / generator) keep their
+    packs across steps, keyed by storage + version so an in-place update invalidates them."""
+    if weight.requires_grad:
+        return PackedWeight(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale)
+    key = (weight.data_ptr(), weight._version, groups, cout_g, cin_g, k, int(transpose_io), int(flip), float(scale))
+    pw = _FROZEN_PACKS.get(key)
+    if pw is None:
+        if len(_FROZEN_PACKS) > 512:
+            _FROZEN_PACKS.clear()
+        pw = _FROZEN_PACKS[key] = PackedWeight(weight.detach(), groups, cout_g, cin_g, k, transpose_io, flip, scale)
+    return pw
+
+
 def pack_weight(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0):
     """-> wmat (groups, cin_g*k*k, cout_g): GEMM layout consumed by gg_conv2d_f32.  `cin_g` is the
     reduction-channel count and `cout_g` the output-channel count OF THE CONVOLUTION BEING RUN."""
@@ -148,16 +165,16 @@ class _Conv2d(Function):
         if not transposed:
             cout_g = weight.shape[0] // groups
             assert weight.shape[1] == cin_g, 'weight / input channel mismatch'
-            wmat = PackedWeight(weight, groups, cout_g, cin_g, k, 0, 0, wscale)
+            wmat = packed(weight, groups, cout_g, cin_g, k, 0, 0, wscale)
             y = conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, padding, 0, bias=bias)
         else:
             cout_g = weight.shape[1]
             assert weight.shape[0] == cin, 'weight / input channel mismatch'
             if stride == 1:      # transposed stride-1 == correlation with flipped taps
-                wmat = PackedWeight(weight, groups, cout_g, cin_g, k, 1, 1, wscale)
+                wmat = packed(weight, groups, cout_g, cin_g, k, 1, 1, wscale)
                 y = conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, 1, k - 1 - padding, 0, bias=bias)
             else:
-                wmat = PackedWeight(weight, groups, cout_g, cin_g, k, 1, 0, wscale)
+                wmat = packed(weight, groups, cout_g, cin_g, k, 1, 0, wscale)
                 h, w = x.shape[-2:]
                 oh = (h - 1) * 2 - 2 * padding + k + output_padding
                 ow = (w - 1) * 2 - 2 * padding + k + output_padding
@@ -177,17 +194,17 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0]:
             if not transposed:
                 if stride == 1:
-                    wm = PackedWeight(weight, groups, cin_g, cout_g, k, 1, 1, wscale)
+                    wm = packed(weight, groups, cin_g, cout_g, k, 1, 1, wscale)
                     dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, k - 1 - padding, 0)
                 else:
-                    wm = PackedWeight(weight, groups, cin_g, cout_g, k, 1, 0, wscale)
+                    wm = packed(weight, groups, cin_g, cout_g, k, 1, 0, wscale)
                     dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 1, out_hw=(h, w))
             else:
                 if stride == 1:
-                    wm = PackedWeight(weight, groups, cin_g, cout_g, k, 0, 0, wscale)
+                    wm = packed(weight, groups, cin_g, cout_g, k, 0, 0, wscale)
                     dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, padding, 0)
                 else:
-                    wm = PackedWeight(weight, groups, cin_g, cout_g, k, 0, 0, wscale)
+                    wm = packed(weight, groups, cin_g, cout_g, k, 0, 0, wscale)
                     dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 0)
                     dx = dx[..., :h, :w].contiguous() if dx.shape[-2:] != (h, w) else dx
         if ctx.needs_input_grad[1]:
