@@ -44,6 +44,7 @@ _PROTOS = {
     'gg_conv_pack_weight_split': 'ppiiiiiiifis',
     'gg_conv2d_split_f32': 'pppqipppiiiiiiiiiiiis',
     'gg_conv2d_wgrad_f32': 'pppiiiiiiiiifs',
+    'gg_conv2d_wgrad_split_f32': 'pppiiiiiiiiifis',
     'gg_plane_dot_f32': 'pppiqs',
     'gg_adam_ema_f32': 'pppppqffffiffs',
 }

@@ -871,6 +871,160 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 
+// ------------------------------------------------------------------------------------------------
+// Split-precision weight gradient: D[co][j = (ci,tap)] = sum_pix dy[co,pix] * x[ci, pix*s + tap - p] on the
+// bf16 matrix pipe.  The reduction index (pixels) is the contiguous axis of BOTH global operands, which
+// is exactly the k-contiguous [row][k] LDS layout the bf16 fragments want: a thread loads 4 consecutive
+// pixels of one row (16 B; 8 lanes cover a 128 B line), splits them into limbs and writes 8 B per limb.
+// K (= N*OH*OW) is split across blockIdx.y; partial tiles are combined with fp32 atomics.
+// ------------------------------------------------------------------------------------------------
+template <int KS, int LIMBS>
+__global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradArgs a) {
+  constexpr int KK = KS * KS, MI = 2, NJ = 2;
+  __shared__ __attribute__((aligned(16))) unsigned char sD[LIMBS][WT * ROWB];   // dy  [co][pix]
+  __shared__ __attribute__((aligned(16))) unsigned char sXg[LIMBS][WT * ROWB];  // x   [j][pix]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wco = wid >> 1, wj = wid & 1;
+  const unsigned ntiles = (unsigned)a.tiles_co * a.tiles_j;
+  const unsigned logical = gg::xcd_remap(blockIdx.x, ntiles);
+  const int tile_co = logical % a.tiles_co, tile_j = logical / a.tiles_co;
+  const int g = blockIdx.z;
+  const int co0 = tile_co * WT, j0 = tile_j * WT;
+  const long long kbeg = (long long)blockIdx.y * a.k_per_split;
+  long long kend = kbeg + a.k_per_split;
+  if (kend > a.ktot) kend = a.ktot;
+  const int ohw = a.oh * a.ow, hw = a.h * a.w;
+
+  const int grp = tid & 7;          // 4-pixel group inside the 32-pixel slab
+  const int r0 = tid >> 3;          // rows r0 + 32*q, q < 4
+  int jci[4], jdy[4], jdx[4];
+  bool cok[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = j0 + r0 + 32 * q;
+    if (j < a.jtot) {
+      const int ci = j / KK, tap = j - ci * KK;
+      jci[q] = ci; jdy[q] = tap / KS - a.pad; jdx[q] = tap % KS - a.pad;
+    } else {
+      jci[q] = -1; jdy[q] = 0; jdx[q] = 0;
+    }
+    cok[q] = (co0 + r0 + 32 * q) < a.cout_g;
+  }
+
+  float4 rd[4];
+  float rx[4][4];
+  unsigned mx = 0;                 // validity bits of rx
+  auto load_slab = [&](long long k0) {
+    const long long k = k0 + grp * 4;                 // first of this thread's 4 pixels (same image row)
+    const bool ok = k < kend;
+    int n = 0, oy = 0, ox = 0;
+    if (ok) {
+      n = (int)(k / ohw);
+      const int rem = (int)(k - (long long)n * ohw);
+      oy = rem / a.ow;
+      ox = rem - oy * a.ow;
+    }
+    const float* dyp = a.dy + ((size_t)(n * a.groups + g) * a.cout_g) * ohw + (size_t)oy * a.ow + ox;
+    const float* xp = a.x + ((size_t)(n * a.groups + g) * a.cin_g) * hw;
+    mx = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = co0 + r0 + 32 * q;
+      const bool okd = ok & cok[q];
+      rd[q] = *reinterpret_cast<const float4*>(dyp + (okd ? (size_t)co * ohw : 0));
+      if (!okd) rd[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int iy = oy * a.stride + jdy[q];
+      const bool rowok = ok & (jci[q] >= 0) & ((unsigned)iy < (unsigned)a.h);
+      const float* xr = xp + (rowok ? (size_t)jci[q] * hw + (size_t)iy * a.w : 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ix = (ox + e) * a.stride + jdx[q];
+        const unsigned v = (unsigned)rowok & (unsigned)((unsigned)ix < (unsigned)a.w);
+        rx[q][e] = xr[v ? ix : 0];
+        mx |= v << (q * 4 + e);
+      }
+    }
+  };
+  auto store_slab = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float d[4] = {rd[q].x, rd[q].y, rd[q].z, rd[q].w};
+      float x[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = ((mx >> (q * 4 + e)) & 1u) ? rx[q][e] : 0.f;
+#pragma unroll
+      for (int l = 0; l < LIMBS; ++l) {
+        const unsigned d0 = pack_bf16x2(d[0], d[1]), d1 = pack_bf16x2(d[2], d[3]);
+        const unsigned x0 = pack_bf16x2(x[0], x[1]), x1 = pack_bf16x2(x[2], x[3]);
+        if (l + 1 < LIMBS) {
+          d[0] -= bf16_lo(d0); d[1] -= bf16_hi(d0); d[2] -= bf16_lo(d1); d[3] -= bf16_hi(d1);
+          x[0] -= bf16_lo(x0); x[1] -= bf16_hi(x0); x[2] -= bf16_lo(x1); x[3] -= bf16_hi(x1);
+        }
+        *reinterpret_cast<uint2*>(&sD[l][(r0 + 32 * q) * ROWB + grp * 8]) = make_uint2(d0, d1);
+        *reinterpret_cast<uint2*>(&sXg[l][(r0 + 32 * q) * ROWB + grp * 8]) = make_uint2(x0, x1);
+      }
+    }
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kbeg < kend) {
+    const int kh = lane >> 5, l31 = lane & 31;
+    load_slab(kbeg);
+    for (long long k0 = kbeg; k0 < kend; k0 += BKS) {
+      store_slab();
+      __syncthreads();
+      if (k0 + BKS < kend) load_slab(k0 + BKS);
+#pragma unroll
+      for (int ks = 0; ks < BKS / 16; ++ks) {
+        bf16x8 fa[LIMBS][MI], fb[LIMBS][NJ];
+#pragma unroll
+        for (int l = 0; l < LIMBS; ++l) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+            fa[l][i] = *reinterpret_cast<const bf16x8*>(&sD[l][((wco * MI + i) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            fb[l][j] = *reinterpret_cast<const bf16x8*>(&sXg[l][((wj * NJ + j) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
+        }
+#pragma unroll
+        for (int sum = LIMBS - 1; sum >= 0; --sum)
+#pragma unroll
+          for (int la = 0; la <= sum; ++la) {
+            const int lb = sum - la;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la][i], fb[lb][j], acc[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+  }
+  float* dwg = a.dw + (size_t)g * a.cout_g * a.jtot;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int jj = j0 + (wj * NJ + j) * 32 + (lane & 31);
+    if (jj >= a.jtot) continue;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wco * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co >= a.cout_g) continue;
+        unsafeAtomicAdd(dwg + (size_t)co * a.jtot + jj, acc[i][j][r] * a.scale);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_weight_kernel(float* __restrict__ wmat, const float* __restrict__ w,
                                                           long long total, int cout_g, int cin_g, int kh, int kw,
                                                           int transpose_io, int flip, float scale) {
@@ -1155,9 +1309,9 @@ extern "C" int gg_conv_pack_weight_split(unsigned short* wsplit, const float* w,
   return gg::launch_status("conv_pack_weight_split");
 }
 
-extern "C" int gg_conv2d_wgrad_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g,
-                                   int cout_g, int h, int w, int ksize, int stride, int pad, float scale,
-                                   void* stream) {
+namespace {
+int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g, int cout_g, int h,
+                int w, int ksize, int stride, int pad, float scale, int limbs, void* stream) {
   if (groups <= 0 || cin_g <= 0 || cout_g <= 0) return 0;
   if (!dw || !x || !dy) return gg::fail(-2, "conv2d_wgrad: null pointer");
   if (ksize != 1 && ksize != 3) return gg::fail(-2, "conv2d_wgrad: kernel size must be 1 or 3");
@@ -1173,25 +1327,51 @@ extern "C" int gg_conv2d_wgrad_f32(float* dw, const float* x, const float* dy, i
   hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)groups * cout_g * a.jtot, st);
   if (e != hipSuccess) return gg::fail((int)e, "conv2d_wgrad: memset failed");
   if (batch <= 0 || a.oh <= 0 || a.ow <= 0) return 0;
+  if (limbs) {
+    if (limbs != 2 && limbs != 3) return gg::fail(-2, "conv2d_wgrad_split: limbs must be 2 or 3");
+    if ((a.oh * a.ow) % BKS != 0 || a.ow % 4 != 0 || (reinterpret_cast<uintptr_t>(dy) & 15))
+      return gg::fail(-2, "conv2d_wgrad_split: needs OH*OW %% 32 == 0, OW %% 4 == 0 and 16-byte aligned dy");
+  }
   a.ktot = (long long)batch * a.oh * a.ow;
   a.tiles_co = (cout_g + WT - 1) / WT;
   a.tiles_j = (a.jtot + WT - 1) / WT;
   const long long tiles = (long long)a.tiles_co * a.tiles_j * groups;
+  const int slab = limbs ? BKS : WBK;
   long long splits = (4LL * gg::kNumCu + tiles - 1) / tiles;
-  const long long max_splits = (a.ktot + 8 * WBK - 1) / (8 * WBK);       // >= 8 slabs per split
+  const long long max_splits = (a.ktot + 8 * slab - 1) / (8 * slab);       // >= 8 slabs per split
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (splits > 65535) splits = 65535;
   long long kps = (a.ktot + splits - 1) / splits;
-  kps = (kps + WBK - 1) / WBK * WBK;
+  kps = (kps + slab - 1) / slab * slab;
   splits = (a.ktot + kps - 1) / kps;
   a.k_per_split = kps;
   dim3 grid((unsigned)(a.tiles_co * a.tiles_j), (unsigned)splits, (unsigned)groups);
-  if (ksize == 3)
+  if (limbs == 2) {
+    if (ksize == 3) conv_wgrad_split_kernel<3, 2><<<grid, 256, 0, st>>>(a);
+    else conv_wgrad_split_kernel<1, 2><<<grid, 256, 0, st>>>(a);
+  } else if (limbs == 3) {
+    if (ksize == 3) conv_wgrad_split_kernel<3, 3><<<grid, 256, 0, st>>>(a);
+    else conv_wgrad_split_kernel<1, 3><<<grid, 256, 0, st>>>(a);
+  } else if (ksize == 3) {
     conv_wgrad_kernel<3><<<grid, 256, 0, st>>>(a);
-  else
+  } else {
     conv_wgrad_kernel<1><<<grid, 256, 0, st>>>(a);
+  }
   return gg::launch_status("conv2d_wgrad");
+}
+}  // namespace
+
+extern "C" int gg_conv2d_wgrad_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g,
+                                   int cout_g, int h, int w, int ksize, int stride, int pad, float scale,
+                                   void* stream) {
+  return wgrad_entry(dw, x, dy, batch, groups, cin_g, cout_g, h, w, ksize, stride, pad, scale, 0, stream);
+}
+
+extern "C" int gg_conv2d_wgrad_split_f32(float* dw, const float* x, const float* dy, int batch, int groups,
+                                         int cin_g, int cout_g, int h, int w, int ksize, int stride, int pad,
+                                         float scale, int limbs, void* stream) {
+  return wgrad_entry(dw, x, dy, batch, groups, cin_g, cout_g, h, w, ksize, stride, pad, scale, limbs, stream);
 }
 
 extern "C" int gg_plane_dot_f32(float* out, const float* a, const float* b, int planes, long long hw, void* stream) {

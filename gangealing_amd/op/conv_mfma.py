@@ -141,8 +141,14 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
 def conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, pad, scale=1.0):
     """-> (groups*cout_g, cin_g, k, k) gradient of a mode-0 convolution's weight."""
     dw = torch.empty((groups * cout_g, cin_g, k, k), dtype=torch.float32, device=x.device)
-    _lib.call('gg_conv2d_wgrad_f32', dw, x, dy, batch, groups, cin_g, cout_g, x.shape[-2], x.shape[-1], k, stride,
-              pad, scale)
+    h, w = x.shape[-2], x.shape[-1]
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    limbs = _LIMBS[PRECISION]
+    if limbs and (oh * ow) % 32 == 0 and ow % 4 == 0 and cout_g >= 32 and cin_g * k * k >= 32 and dy.data_ptr() % 16 == 0:
+        _lib.call('gg_conv2d_wgrad_split_f32', dw, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale,
+                  limbs)
+    else:
+        _lib.call('gg_conv2d_wgrad_f32', dw, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale)
     return dw
 
 

@@ -219,6 +219,11 @@ int gg_conv2d_split_f32(float* y, const float* x, const unsigned short* wsplit, 
  *   dw[g,co,ci,ky,kx] = sum_{n,oy,ox} dy[n,g*cout_g+co,oy,ox] * x[n,g*cin_g+ci, oy*stride+ky-pad, ox*stride+kx-pad] */
 int gg_conv2d_wgrad_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g, int cout_g,
                         int h, int w, int ksize, int stride, int pad, float scale, void* stream);
+/* Split-precision weight gradient (bf16 matrix pipe, `limbs` bf16 limbs per operand; see gg_conv2d_split_f32).
+ * Requires OH*OW % 32 == 0, OW % 4 == 0 and a 16-byte aligned dy. */
+int gg_conv2d_wgrad_split_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g,
+                              int cout_g, int h, int w, int ksize, int stride, int pad, float scale, int limbs,
+                              void* stream);
 /* Per-(n,c) dot products over the spatial plane: out[n*c] = sum_hw a*b (style / demod gradients). */
 int gg_plane_dot_f32(float* out, const float* a, const float* b, int planes, long long hw, void* stream);
 
