@@ -670,26 +670,64 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvArgs a,
   const int ochan0 = (pn * a.groups + g) * a.cout_g;
   const float* osc = a.out_scale ? a.out_scale + ochan0 : nullptr;
   const float* bia = (a.bias && split == 0) ? a.bias + g * a.cout_g : nullptr;
+  if (atomic) {
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int p = (wpix * NJ + j) * 32 + (lane & 31);
-    const int oy = y0 + (p >> tw_log2), ox = x0 + (p & (TW - 1));
-    float* yp = a.y + (size_t)ochan0 * hw + (size_t)oy * a.w + ox;
+    for (int j = 0; j < NJ; ++j) {
+      const int p = (wpix * NJ + j) * 32 + (lane & 31);
+      const int oy = y0 + (p >> tw_log2), ox = x0 + (p & (TW - 1));
+      float* yp = a.y + (size_t)ochan0 * hw + (size_t)oy * a.w + ox;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+      for (int i = 0; i < MI; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + (wco * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (co >= a.cout_g) continue;
-        float v = acc[i][j][r];
-        if (osc) v *= osc[co];
-        if (bia) v += bia[co];
-        if (atomic) unsafeAtomicAdd(yp + (size_t)co * hw, v);
-        else yp[(size_t)co * hw] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + (wco * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (co >= a.cout_g) continue;
+          float v = acc[i][j][r];
+          if (osc) v *= osc[co];
+          if (bia) v += bia[co];
+          unsafeAtomicAdd(yp + (size_t)co * hw, v);
+        }
       }
     }
+    return;
+  }
+  // Direct stores: the accumulator layout gives each lane ONE pixel x 16 channels, i.e. 4-byte stores that
+  // reach HBM as partial lines (measured WRITE_SIZE = 4x the tensor).  Transpose each wave's 32co x 64pix
+  // sub-tile through LDS and store 16 B per lane: every store instruction writes 4 full 256 B pixel runs.
+  __syncthreads();                                          // sP / sW are dead from here on
+  float* stage = reinterpret_cast<float*>(&sP[0][0]) + wid * (32 * 64);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int co = co0 + (wco * MI + i) * 32 + row;
+        float v = acc[i][j][r];
+        if (co < a.cout_g) {
+          if (osc) v *= osc[co];
+          if (bia) v += bia[co];
+        }
+        stage[row * 64 + j * 32 + (lane & 31)] = v;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx >> 4, c4 = idx & 15;
+      const int co = co0 + (wco * MI + i) * 32 + row;
+      const int p = wpix * 64 + c4 * 4;
+      const int oy = y0 + (p >> tw_log2), ox = x0 + (p & (TW - 1));
+      if (co < a.cout_g) {
+        const float4 v4 = *reinterpret_cast<const float4*>(stage + row * 64 + c4 * 4);
+        *reinterpret_cast<float4*>(a.y + (size_t)(ochan0 + co) * hw + (size_t)oy * a.w + ox) = v4;
+      }
+    }
+    __syncthreads();
   }
 }
+
 
 __global__ __launch_bounds__(256) void pack_weight_split_kernel(unsigned short* __restrict__ wl,
                                                                 const float* __restrict__ w, long long total,
