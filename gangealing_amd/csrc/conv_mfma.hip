@@ -479,16 +479,20 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvArgs a) {
 // style, and the 9 taps read their B fragments from that patch at shifted pixel offsets.  The next
 // chunk's patch is prefetched into registers while the 9 tap slabs of the current chunk run.
 // ------------------------------------------------------------------------------------------------
-constexpr int PATCH_MAX = 4 * 66;       // (TH+2)*(TW+2) for TW = 64
+// pixels per tile: 128 (4 waves) or 256 (8 waves: half the weight traffic per output, the dominant L2 stream)
+constexpr int patch_pixels(int tpix) { return (tpix / 64 + 2) * 66; }    // (TH+2)*(TW+2) for TW = 64
 
-template <int LIMBS, bool IN_SCALE>
-__global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvArgs a, int tw_log2) {
-  constexpr int TCO = 128, TPIX = 128, MI = 2, NJ = 2;
-  __shared__ __attribute__((aligned(16))) unsigned char sW[LIMBS][TCO * ROWB];
-  __shared__ __attribute__((aligned(16))) unsigned char sP[LIMBS][PATCH_MAX * ROWB];
+template <int LIMBS, bool IN_SCALE, int TPIX>
+__global__ __launch_bounds__(TPIX * 2) void conv3x3_patch_kernel(const ConvArgs a, int tw_log2) {
+  constexpr int TCO = 128, MI = 2, NJ = 2, NT = TPIX * 2, PWAVES = TPIX / 64;
+  constexpr int PATCH_MAX = patch_pixels(TPIX);
+  // one LDS arena: [limb][patch rows] then [limb][weight rows]; reused as the epilogue staging buffer
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LIMBS * (PATCH_MAX + TCO) * ROWB];
+  unsigned char (*sP)[PATCH_MAX * ROWB] = reinterpret_cast<unsigned char (*)[PATCH_MAX * ROWB]>(smem);
+  unsigned char (*sW)[TCO * ROWB] = reinterpret_cast<unsigned char (*)[TCO * ROWB]>(smem + LIMBS * PATCH_MAX * ROWB);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wco = wid >> 1, wpix = wid & 1;
+  const int wco = wid / PWAVES, wpix = wid % PWAVES;
   const int TW = 1 << tw_log2, TH = TPIX >> tw_log2, PW = TW + 2, PP = (TH + 2) * PW;
   const unsigned ntiles = (unsigned)a.tiles_co * a.tiles_pix;
   const unsigned logical = gg::xcd_remap(blockIdx.x, ntiles);
@@ -518,8 +522,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvArgs a,
     pok = pin & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
     poff = pok ? iy * a.w + ix : 0;
   }
-  const int lpp = 256 + (tid & 7), lci = tid >> 3;          // left-over element
-  const bool lin = lpp < PP;
+  const int lpp = NT + (tid & 7), lci = (tid >> 3) & (BKS - 1);     // left-over element (128-pixel tile, TW = 64 only)
+  const bool lin = (NT == 256) && lpp < PP;
   bool lok;
   int loff;
   {
@@ -529,7 +533,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvArgs a,
     loff = lok ? lci * hw + iy * a.w + ix : 0;
   }
   // ---- weight rows
-  const int wrow = tid >> 1, wpart = tid & 1;
+  const int wrow = (tid >> 1) & (TCO - 1), wpart = tid & 1;
+  const bool w_thr = tid < 2 * TCO;                       // the first 256 threads move the weight slab
   const bool w_ok = (co0 + wrow) < a.cout_g;
   const int kfull = 9 * a.cin_g;
   const unsigned short* wrow_ptr = a.wsplit + ((size_t)g * a.cout_g + (w_ok ? co0 + wrow : 0)) * kfull + wpart * EPT;
@@ -586,6 +591,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvArgs a,
     }
   };
   auto load_w = [&](int chunk, int t) {
+    if (!w_thr) return;
     const unsigned short* wsrc = wrow_ptr + (size_t)t * a.cin_g + chunk * BKS;
 #pragma unroll
     for (int l = 0; l < LIMBS; ++l) {
@@ -595,6 +601,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvArgs a,
     }
   };
   auto store_w = [&]() {
+    if (!w_thr) return;
     const U4 z{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int l = 0; l < LIMBS; ++l) {
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvArgs a,
   // reach HBM as partial lines (measured WRITE_SIZE = 4x the tensor).  Transpose each wave's 32co x 64pix
   // sub-tile through LDS and store 16 B per lane: every store instruction writes 4 full 256 B pixel runs.
   __syncthreads();                                          // sP / sW are dead from here on
-  float* stage = reinterpret_cast<float*>(&sP[0][0]) + wid * (32 * 64);
+  float* stage = reinterpret_cast<float*>(smem) + wid * (32 * 64);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -1162,21 +1169,21 @@ int launch_conv_split(const ConvArgs& a, int limbs, hipStream_t st) {
 }
 
 // 3x3 / stride 1 / pad 1 with a power-of-two width >= 16 whose 128-pixel tiles fit the image
-bool patch_geometry(const ConvArgs& a, int& tw_log2) {
+bool patch_geometry(const ConvArgs& a, int tpix, int& tw_log2) {
   const int w = a.w, h = a.h;
   if (w < 16 || (w & (w - 1)) != 0) return false;
   int tw = w < 64 ? w : 64;
   tw_log2 = 0;
   while ((1 << tw_log2) < tw) ++tw_log2;
-  const int th = 128 >> tw_log2;
-  return h % th == 0;
+  const int th = tpix >> tw_log2;
+  return th <= h && h % th == 0;
 }
 
-int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, hipStream_t st) {
+int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t st) {
   // plan in units of 32-channel chunks
   a.mh = a.oh; a.mw = a.ow;
   a.tiles_co = (a.cout_g + 127) / 128;
-  const long long tp = (long long)a.batch * a.oh * a.ow / 128;
+  const long long tp = (long long)a.batch * a.oh * a.ow / tpix;
   if (tp * a.tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
   a.tiles_pix = (int)tp;
   a.nslabs = a.cin_g / BKS;
@@ -1196,12 +1203,15 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, hipStream_t st) {
   }
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
-  if (limbs == 2) {
-    if (sc) conv3x3_patch_kernel<2, true><<<grid, 256, 0, st>>>(a, tw_log2);
-    else conv3x3_patch_kernel<2, false><<<grid, 256, 0, st>>>(a, tw_log2);
+  if (limbs == 2 && tpix == 256) {
+    if (sc) conv3x3_patch_kernel<2, true, 256><<<grid, 512, 0, st>>>(a, tw_log2);
+    else conv3x3_patch_kernel<2, false, 256><<<grid, 512, 0, st>>>(a, tw_log2);
+  } else if (limbs == 2) {
+    if (sc) conv3x3_patch_kernel<2, true, 128><<<grid, 256, 0, st>>>(a, tw_log2);
+    else conv3x3_patch_kernel<2, false, 128><<<grid, 256, 0, st>>>(a, tw_log2);
   } else {
-    if (sc) conv3x3_patch_kernel<3, true><<<grid, 256, 0, st>>>(a, tw_log2);
-    else conv3x3_patch_kernel<3, false><<<grid, 256, 0, st>>>(a, tw_log2);
+    if (sc) conv3x3_patch_kernel<3, true, 128><<<grid, 256, 0, st>>>(a, tw_log2);
+    else conv3x3_patch_kernel<3, false, 128><<<grid, 256, 0, st>>>(a, tw_log2);
   }
   return gg::launch_status("conv3x3_patch");
 }
@@ -1210,7 +1220,11 @@ template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {
   if (limbs && KS == 3 && mode == 0 && stride == 1 && pad == 1) {
     int tw_log2;
-    if (patch_geometry(a, tw_log2)) return launch_conv_patch(a, limbs, tw_log2, st);
+    // 256-pixel tiles when they still fill the chip (>= 2 blocks per CU), else 128-pixel tiles
+    const long long tiles256 = (long long)a.batch * a.oh * a.ow / 256 * ((a.cout_g + 127) / 128) * a.groups;
+    if (limbs == 2 && tiles256 >= 2 * gg::kNumCu && patch_geometry(a, 256, tw_log2))
+      return launch_conv_patch(a, limbs, tw_log2, 256, st);
+    if (patch_geometry(a, 128, tw_log2)) return launch_conv_patch(a, limbs, tw_log2, 128, st);
   }
   // tile selector.  (Measured on the 128->128 @256^2 layer: an 8-wave 128x128 variant, a 128co x 256pix
   // variant with 8 accumulators per wave and BK = 32 are all within -20..+1 % of this 4-wave tile.)
