@@ -49,6 +49,7 @@ struct ConvArgs {
   int ktot;              // cin_g * ntaps
   int tiles_co, tiles_pix;
   int splitk, slabs_per_split, nslabs;
+  int tile_pixels;                // pixels per block tile chosen by plan_conv
   const unsigned short* wsplit;   // bf16 limb planes [limb][g][co][k = (tap, ci)]  (split-precision path)
   long long wsplit_stride;        // elements between limb planes
 };
@@ -283,14 +284,14 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 __device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
-template <int KS, int MODE, int LIMBS, bool IN_SCALE>
-__global__ __launch_bounds__(256) void conv_split_kernel(const ConvArgs a) {
-  constexpr int TCO = 128, TPIX = 128, MI = 2, NJ = 2;
+template <int KS, int MODE, int LIMBS, bool IN_SCALE, int TPIX>
+__global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs a) {
+  constexpr int TCO = 128, MI = 2, NJ = 2, PWAVES = TPIX / 64;
   __shared__ __attribute__((aligned(16))) unsigned char sW[LIMBS][TCO * ROWB];
   __shared__ __attribute__((aligned(16))) unsigned char sX[LIMBS][TPIX * ROWB];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wco = wid >> 1, wpix = wid & 1;
+  const int wco = wid / PWAVES, wpix = wid % PWAVES;
   const unsigned ntiles = (unsigned)a.tiles_co * a.tiles_pix;
   const unsigned logical = gg::xcd_remap(blockIdx.x, ntiles);
   const int tile_co = logical % a.tiles_co, tile_pix = logical / a.tiles_co;
@@ -300,8 +301,8 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvArgs a) {
   const long long mtot = (long long)a.batch * a.mh * a.mw;
   const int hw = a.h * a.w;
 
-  // ---- gather column: pixel (tid & 127), channel half (tid >> 7) -> 16 consecutive ci of the slab
-  const int pcol = tid & 127, khalf = tid >> 7;
+  // ---- gather column: pixel (tid % TPIX), channel half (tid / TPIX) -> 16 consecutive ci of the slab
+  const int pcol = tid % TPIX, khalf = tid / TPIX;
   const long long m = m0 + pcol;
   const bool m_ok = m < mtot;
   int pn = 0, base_y = 0, base_x = 0;
@@ -317,7 +318,8 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvArgs a) {
   const float* xg = a.x + (size_t)chan0 * hw;
   const float* sg = IN_SCALE ? a.in_scale + chan0 : nullptr;
   // ---- weight rows: row (tid >> 1), 16-k part (tid & 1)
-  const int wrow = tid >> 1, wpart = tid & 1;
+  const int wrow = (tid >> 1) & (TCO - 1), wpart = tid & 1;
+  const bool w_thr = tid < 2 * TCO;                 // the first 256 threads move the weight slab
   const bool w_ok = (co0 + wrow) < a.cout_g;
   const int kfull = KS * KS * a.cin_g;
   const unsigned short* wrow_ptr = a.wsplit + ((size_t)g * a.cout_g + (w_ok ? co0 + wrow : 0)) * kfull + wpart * EPT;
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvArgs a) {
     }
     const unsigned short* wsrc = wrow_ptr + (size_t)(ky * KS + kx) * a.cin_g + ci0;
 #pragma unroll
-    for (int l = 0; l < LIMBS; ++l) {
+    for (int l = 0; l < LIMBS && w_thr; ++l) {
       const U4* w4 = reinterpret_cast<const U4*>(wsrc + (size_t)l * a.wsplit_stride);
 #pragma unroll
       for (int q = 0; q < EPT / 8; ++q) wv[l][q] = w4[q];
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvArgs a) {
 #pragma unroll
       for (int q = 0; q < EPT / 8; ++q) {
         dst[q] = U4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
-        wd[q] = w_ok ? wv[l][q] : z;
+        if (w_thr) wd[q] = w_ok ? wv[l][q] : z;
       }
     }
   };
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const ConvArgs a) {
 constexpr int patch_pixels(int tpix) { return (tpix / 64 + 2) * 66; }    // (TH+2)*(TW+2) for TW = 64
 
 template <int LIMBS, bool IN_SCALE, int TPIX>
-__global__ __launch_bounds__(TPIX * 2) void conv3x3_patch_kernel(const ConvArgs a, int tw_log2) {
+__global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvArgs a, int tw_log2) {
   constexpr int TCO = 128, MI = 2, NJ = 2, NT = TPIX * 2, PWAVES = TPIX / 64;
   constexpr int PATCH_MAX = patch_pixels(TPIX);
   // one LDS arena: [limb][patch rows] then [limb][weight rows]; reused as the epilogue staging buffer
@@ -1112,9 +1114,10 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(float* __restrict__ out,
 }
 
 // Fill in tiling / split-K for one launch.  Returns false when the launch is empty.
-// tile: 0 = 128co x 128pix, 1 = 32co x 256pix, 2 = 64co x 256pix
+// tile: 0 = 128co x 128pix, 1 = 32co x 256pix, 2 = 64co x 256pix, 4 = 128co x 256pix (split kernels)
 bool plan_conv(ConvArgs& a, int tile, int bk = BK) {
-  const int tco = tile == 0 ? 128 : (tile == 1 ? 32 : 64), tpix = tile == 0 ? 128 : 256;
+  const int tco = (tile == 0 || tile == 4) ? 128 : (tile == 1 ? 32 : 64), tpix = tile == 0 ? 128 : 256;
+  a.tile_pixels = tpix;
   const long long mtot = (long long)a.batch * a.mh * a.mw;
   if (mtot <= 0) return false;
   a.tiles_co = (a.cout_g + tco - 1) / tco;
@@ -1153,17 +1156,26 @@ int launch_conv(const ConvArgs& a, int tile, hipStream_t st) {
   return gg::launch_status("conv_igemm");
 }
 
+// 256-pixel tiles (8 waves) halve the weight stream per output; use them while they still give >= 2 blocks per CU
+int split_tile(const ConvArgs& a, int limbs) {
+  const long long tiles256 = ((long long)a.batch * a.mh * a.mw + 255) / 256 * ((a.cout_g + 127) / 128) * a.groups;
+  return (limbs == 2 && tiles256 >= 2 * gg::kNumCu) ? 4 : 0;
+}
+
 template <int KS, int MODE>
 int launch_conv_split(const ConvArgs& a, int limbs, hipStream_t st) {
   if ((long long)a.tiles_pix * a.tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
-  if (limbs == 2) {
-    if (sc) conv_split_kernel<KS, MODE, 2, true><<<grid, 256, 0, st>>>(a);
-    else conv_split_kernel<KS, MODE, 2, false><<<grid, 256, 0, st>>>(a);
+  if (limbs == 2 && a.tile_pixels == 256) {
+    if (sc) conv_split_kernel<KS, MODE, 2, true, 256><<<grid, 512, 0, st>>>(a);
+    else conv_split_kernel<KS, MODE, 2, false, 256><<<grid, 512, 0, st>>>(a);
+  } else if (limbs == 2) {
+    if (sc) conv_split_kernel<KS, MODE, 2, true, 128><<<grid, 256, 0, st>>>(a);
+    else conv_split_kernel<KS, MODE, 2, false, 128><<<grid, 256, 0, st>>>(a);
   } else {
-    if (sc) conv_split_kernel<KS, MODE, 3, true><<<grid, 256, 0, st>>>(a);
-    else conv_split_kernel<KS, MODE, 3, false><<<grid, 256, 0, st>>>(a);
+    if (sc) conv_split_kernel<KS, MODE, 3, true, 128><<<grid, 256, 0, st>>>(a);
+    else conv_split_kernel<KS, MODE, 3, false, 128><<<grid, 256, 0, st>>>(a);
   }
   return gg::launch_status("conv_split");
 }
@@ -1238,7 +1250,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     a.bs = stride; a.byo = -pad; a.bxo = -pad;
     a.py = a.px = 0; a.nty = a.ntx = KS;
     a.ktot = a.cin_g * KS * KS;
-    if (plan_conv(a, limbs ? 0 : narrow, limbs ? BKS : BK)) plans[nplans++] = a;
+    if (plan_conv(a, limbs ? split_tile(a, limbs) : narrow, limbs ? BKS : BK)) plans[nplans++] = a;
   } else {
     // transposed, stride 2: one dense sub-problem per parity class of u = y + pad
     for (int py = 0; py < 2; ++py) {
@@ -1261,7 +1273,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
         c.bs = 1; c.byo = qy0; c.bxo = qx0;
         c.py = py; c.px = px; c.nty = nty; c.ntx = ntx;
         c.ktot = a.cin_g * nty * ntx;
-        if (plan_conv(c, limbs ? 0 : narrow, limbs ? BKS : BK)) plans[nplans++] = c;
+        if (plan_conv(c, limbs ? split_tile(c, limbs) : narrow, limbs ? BKS : BK)) plans[nplans++] = c;
       }
     }
   }
