@@ -120,7 +120,18 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
     if y.numel():
         limbs = _LIMBS[PRECISION]
         use_split = limbs > 0 and isinstance(wmat, PackedWeight) and wmat.split_ok()
-        prof = PROFILER if (PROFILER is not None and k == 3 and mode == 0 and cout_g > 64) else None
+        prof = None
+        if PROFILER is not None and k == 3 and mode == 0 and cout_g > 64:
+            if use_split:
+                # exactly the launches that run conv3x3_patch_kernel<2, true, 256> (csrc/conv_mfma.hip: patch_geometry
+                # + the 256-pixel-tile rule): the generator's style-scaled 3x3 stride-1 layers that fill the chip
+                tiles256 = (batch * oh * ow + 255) // 256 * ((cout_g + 127) // 128) * groups
+                pow2 = ow >= 16 and (ow & (ow - 1)) == 0
+                if (limbs == 2 and stride == 1 and pad == 1 and in_scale is not None and pow2 and tiles256 >= 512
+                        and oh % (256 // min(ow, 64)) == 0):
+                    prof = PROFILER
+            else:
+                prof = PROFILER
         if prof is not None:
             start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record()
