@@ -130,8 +130,8 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
                 if (limbs == 2 and stride == 1 and pad == 1 and in_scale is not None and pow2 and tiles256 >= 512
                         and oh % (256 // min(ow, 64)) == 0):
                     prof = PROFILER
-            else:
-                prof = PROFILER
+            elif limbs == 0 and cout_g > 64 and batch * oh * ow >= 4096:
+                prof = PROFILER          # fp32 mode: conv_igemm_kernel<3,0,2,2,2,2,*> launches without split-K
         if prof is not None:
             start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record()
