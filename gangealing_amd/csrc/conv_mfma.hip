@@ -272,7 +272,23 @@ constexpr int BKS = 32;                 // K per slab
 constexpr int EPT = BKS / 2;            // gathered elements (and weight k's) per thread per slab
 constexpr int ROWB = BKS * 2 + 16;      // bytes per LDS row
 
-struct U4 { unsigned x, y, z, w; };
+typedef unsigned U4 __attribute__((ext_vector_type(4)));
+
+// raw buffer load of one float: address = resource base + voffset (per lane) + soffset (scalar); an offset at or
+// beyond the resource's num_records returns 0.  kOobOffset selects that for masked lanes (resources are < 2 GiB).
+constexpr unsigned kOobOffset = 0x80000000u;
+// The descriptor inputs go through readfirstlane so that the compiler can PROVE they are wave-uniform; otherwise
+// every buffer op is wrapped in a waterfall loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* p, int bytes) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                           __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ float buffer_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voffset, int soffset) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voffset, soffset, 0));
+}   // a native vector: a struct here is kept in scratch by the compiler
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -510,29 +526,30 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   const int y0 = ty * TH, x0 = tx * TW;
 
   const int chan0 = (pn * a.groups + g) * a.cin_g;
-  const float* xg = a.x + (size_t)chan0 * hw;
   const float* sg = IN_SCALE ? a.in_scale + chan0 : nullptr;
+  // the image-group's input slab as a buffer resource: the gather is `scalar base + 32-bit lane offset + scalar
+  // channel offset` (one address VGPR instead of 32 64-bit pointers), and lanes outside the image use an offset
+  // beyond num_records, which the hardware range check turns into 0.0 (the zero padding) without a select
+  const __amdgpu_buffer_rsrc_t xr = uniform_rsrc(a.x + (size_t)chan0 * hw, a.cin_g * hw * 4);
 
   // ---- patch gather: thread -> patch pixel `tid` (all 32 channels of the chunk); for TW = 64 the patch has
   //      264 pixels: the 8 left-over pixels x 32 channels are exactly one extra element per thread
   const bool pin = tid < PP;
-  bool pok;
-  int poff;
+  unsigned pvoff;
   {
     const int pr = tid / PW, pc = tid - pr * PW;
     const int iy = y0 + pr - 1, ix = x0 + pc - 1;
-    pok = pin & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
-    poff = pok ? iy * a.w + ix : 0;
+    const bool pok = pin & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
+    pvoff = pok ? (unsigned)(iy * a.w + ix) * 4u : kOobOffset;
   }
   const int lpp = NT + (tid & 7), lci = (tid >> 3) & (BKS - 1);     // left-over element (128-pixel tile, TW = 64 only)
   const bool lin = (NT == 256) && lpp < PP;
-  bool lok;
-  int loff;
+  unsigned lvoff;
   {
     const int pr = lpp / PW, pc = lpp - pr * PW;
     const int iy = y0 + pr - 1, ix = x0 + pc - 1;
-    lok = lin & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
-    loff = lok ? lci * hw + iy * a.w + ix : 0;
+    const bool lok = lin & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
+    lvoff = lok ? (unsigned)(lci * hw + iy * a.w + ix) * 4u : kOobOffset;
   }
   // ---- weight rows
   const int wrow = (tid >> 1) & (TCO - 1), wpart = tid & 1;
@@ -549,18 +566,16 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   U4 wv[LIMBS][EPT / 8];
 
   auto load_patch = [&](int chunk) {
-    const float* src = xg + (size_t)chunk * BKS * hw;
-    const int step = pok ? hw : 0;
+    const int cbase = __builtin_amdgcn_readfirstlane(chunk * BKS * hw * 4);
 #pragma unroll
-    for (int j = 0; j < BKS; ++j) xa[j] = src[(size_t)j * step + poff];
-    xl = src[loff];
+    for (int j = 0; j < BKS; ++j) xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
+    xl = buffer_load_f32(xr, lvoff, cbase);
   };
   auto store_patch = [&](int chunk) {
     if (pin) {
+      if (IN_SCALE) {
 #pragma unroll
-      for (int j = 0; j < BKS; ++j) {
-        xa[j] = pok ? xa[j] : 0.f;
-        if (IN_SCALE) xa[j] *= sg[chunk * BKS + j];
+        for (int j = 0; j < BKS; ++j) xa[j] *= sg[chunk * BKS + j];
       }
 #pragma unroll
       for (int l = 0; l < LIMBS; ++l) {
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       }
     }
     if (lin) {
-      float v = lok ? xl : 0.f;
+      float v = xl;
       if (IN_SCALE) v *= sg[chunk * BKS + lci];
 #pragma unroll
       for (int l = 0; l < LIMBS; ++l) {
@@ -734,6 +749,282 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       }
     }
     __syncthreads();
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 2 TRANSPOSED convolution, all four output parity classes in one pass.
+// (StyleGAN2's up-sampling ModulatedConv2d, reference models/stylegan2/networks.py:268-281, and the
+// data gradient of every stride-2 convolution.)
+//   out[co, 2q + p - pad] = sum_{ci, j} x[ci, q - j] * W[co, ci, k = p + 2j],   p in {0,1}, k < 3
+// A tile is TQ "q" positions (TH x TW of the (H+1) x (W+1) q-grid); each 3x3 tap belongs to exactly one
+// parity class (ky & 1, kx & 1), so per 32-channel chunk the block stages the (TH+1) x (TW+1) input patch in
+// LDS once (split into bf16 limbs, style-scaled) and runs the 9 tap slabs, tap t accumulating into the
+// accumulator set of ITS class.  The MFMA work equals a 3x3 convolution at the input resolution - no
+// zero-stuffed taps - and the four classes leave through an LDS transpose that interleaves them, so the
+// (2H+1)-wide rows are written as contiguous runs.  (The four-launch formulation wrote stride-2 dwords: 3x
+// write amplification, and re-gathered the input once per tap.)
+// The q-grid has one more row / column than the input; the extra row is an ordinary tile row, the extra
+// column is covered by "edge" tiles of shape TQ x 1.
+// ------------------------------------------------------------------------------------------------
+template <int LIMBS, bool IN_SCALE, int TQ>
+__global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvArgs a, int tw_log2_in, int tiles_y,
+                                                                     int edge_tiles, int pad) {
+  constexpr int TCO = 128, NJ = 2, PWAVES = TQ / 64;
+  constexpr int PATCH_MAX = 2 * TQ + 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LIMBS * (PATCH_MAX + TCO) * ROWB];
+  unsigned char (*sP)[PATCH_MAX * ROWB] = reinterpret_cast<unsigned char (*)[PATCH_MAX * ROWB]>(smem);
+  unsigned char (*sW)[TCO * ROWB] = reinterpret_cast<unsigned char (*)[TCO * ROWB]>(smem + LIMBS * PATCH_MAX * ROWB);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wco = wid / PWAVES, wpix = wid % PWAVES;
+  const unsigned ntiles = (unsigned)a.tiles_co * a.tiles_pix;
+  const unsigned logical = gg::xcd_remap(blockIdx.x, ntiles);
+  const int tile_co = logical % a.tiles_co, tile_pix = logical / a.tiles_co;
+  const int split = blockIdx.y, g = blockIdx.z;
+  const int co0 = tile_co * TCO;
+  const int hw = a.h * a.w;
+  // tile -> (image, q-tile origin, tile shape)
+  const int tiles_x = a.w >> tw_log2_in;
+  const int interior = tiles_x * tiles_y, per_img = interior + edge_tiles;
+  const int pn = tile_pix / per_img;
+  const int trem = tile_pix - pn * per_img;
+  int tw_log2, y0, x0;
+  if (trem < interior) {
+    tw_log2 = tw_log2_in;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    y0 = ty * (TQ >> tw_log2);
+    x0 = tx << tw_log2;
+  } else {
+    tw_log2 = 0;
+    y0 = (trem - interior) * TQ;
+    x0 = a.w;
+  }
+  const int TW = 1 << tw_log2, TH = TQ >> tw_log2, PW = TW + 1, PP = (TH + 1) * PW;
+
+  const int chan0 = (pn * a.groups + g) * a.cin_g;
+  const float* sg = IN_SCALE ? a.in_scale + chan0 : nullptr;
+  const __amdgpu_buffer_rsrc_t xr = uniform_rsrc(a.x + (size_t)chan0 * hw, a.cin_g * hw * 4);
+
+  // ---- patch gather: thread -> (patch pixel, 16 of the chunk's 32 channels); the patch origin is (y0-1, x0-1)
+  const int pp = tid & (2 * TQ - 1), half = tid / (2 * TQ);
+  const bool pin = pp < PP;
+  unsigned pvoff;
+  {
+    const int pr = pp / PW, pc = pp - pr * PW;
+    const int iy = y0 + pr - 1, ix = x0 + pc - 1;
+    const bool pok = pin & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
+    pvoff = pok ? (unsigned)(half * 16 * hw + iy * a.w + ix) * 4u : kOobOffset;
+  }
+  const int lpp = 2 * TQ + (tid & 1), lci = (tid >> 1) & (BKS - 1);      // the last two patch pixels
+  const bool lin = tid < 2 * BKS && lpp < PP;
+  unsigned lvoff;
+  {
+    const int pr = lpp / PW, pc = lpp - pr * PW;
+    const int iy = y0 + pr - 1, ix = x0 + pc - 1;
+    const bool lok = lin & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
+    lvoff = lok ? (unsigned)(lci * hw + iy * a.w + ix) * 4u : kOobOffset;
+  }
+  // ---- weight rows
+  const int wrow = (tid >> 1) & (TCO - 1), wpart = tid & 1;
+  const bool w_thr = tid < 2 * TCO;
+  const bool w_ok = (co0 + wrow) < a.cout_g;
+  const int kfull = 9 * a.cin_g;
+  const unsigned short* wrow_ptr = a.wsplit + ((size_t)g * a.cout_g + (w_ok ? co0 + wrow : 0)) * kfull + wpart * EPT;
+
+  const int chunk0 = split * a.slabs_per_split;
+  int chunk1 = chunk0 + a.slabs_per_split;
+  if (chunk1 > a.nslabs) chunk1 = a.nslabs;
+
+  float xa[16], xl = 0.f;
+  U4 wv[LIMBS][EPT / 8];
+
+  auto load_patch = [&](int chunk) {
+    const int cbase = __builtin_amdgcn_readfirstlane(chunk * BKS * hw * 4);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
+    xl = buffer_load_f32(xr, lvoff, cbase);
+  };
+  auto store_patch = [&](int chunk) {
+    if (pin) {
+      if (IN_SCALE) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xa[j] *= sg[chunk * BKS + half * 16 + j];
+      }
+#pragma unroll
+      for (int l = 0; l < LIMBS; ++l) {
+        U4* dst = reinterpret_cast<U4*>(&sP[l][pp * ROWB + half * 32]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          unsigned pk[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = 8 * q + 2 * e;
+            pk[e] = pack_bf16x2(xa[j], xa[j + 1]);
+            if (l + 1 < LIMBS) {
+              xa[j] -= bf16_lo(pk[e]);
+              xa[j + 1] -= bf16_hi(pk[e]);
+            }
+          }
+          dst[q] = U4{pk[0], pk[1], pk[2], pk[3]};
+        }
+      }
+    }
+    if (lin) {
+      float v = xl;
+      if (IN_SCALE) v *= sg[chunk * BKS + lci];
+#pragma unroll
+      for (int l = 0; l < LIMBS; ++l) {
+        const __bf16 hb = (__bf16)v;
+        *reinterpret_cast<__bf16*>(&sP[l][lpp * ROWB + lci * 2]) = hb;
+        v -= (float)hb;
+      }
+    }
+  };
+  auto load_w = [&](int chunk, int t) {
+    if (!w_thr) return;
+    const unsigned short* wsrc = wrow_ptr + (size_t)t * a.cin_g + chunk * BKS;
+#pragma unroll
+    for (int l = 0; l < LIMBS; ++l) {
+      const U4* w4 = reinterpret_cast<const U4*>(wsrc + (size_t)l * a.wsplit_stride);
+#pragma unroll
+      for (int q = 0; q < EPT / 8; ++q) wv[l][q] = w4[q];
+    }
+  };
+  auto store_w = [&]() {
+    if (!w_thr) return;
+    const U4 z{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int l = 0; l < LIMBS; ++l) {
+      U4* wd = reinterpret_cast<U4*>(&sW[l][wrow * ROWB + wpart * EPT * 2]);
+#pragma unroll
+      for (int q = 0; q < EPT / 8; ++q) wd[q] = w_ok ? wv[l][q] : z;
+    }
+  };
+
+  f32x16 acc[4][NJ];                        // [parity class py*2+px][pixel sub-tile]
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
+
+  const int kh = lane >> 5, l31 = lane & 31;
+  int pbase[NJ];                            // byte offset of the lane's pixels relative to the patch origin
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int p = (wpix * NJ + j) * 32 + l31;
+    const int r = p >> tw_log2, c = p & (TW - 1);
+    pbase[j] = (r * PW + c) * ROWB;
+  }
+
+  if (chunk0 < chunk1) {
+    load_patch(chunk0);
+    load_w(chunk0, 0);
+    for (int chunk = chunk0; chunk < chunk1; ++chunk) {
+      __syncthreads();
+      store_patch(chunk);
+      if (chunk + 1 < chunk1) load_patch(chunk + 1);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        store_w();
+        __syncthreads();
+        if (t + 1 < 9) load_w(chunk, t + 1);
+        else if (chunk + 1 < chunk1) load_w(chunk + 1, 0);
+        const int ky = t / 3, kx = t - ky * 3;
+        const int cls = (ky & 1) * 2 + (kx & 1);
+        // x[q - j]: patch row/col (q - y0) + 1 - j
+        const int tapoff = ((1 - (ky >> 1)) * PW + (1 - (kx >> 1))) * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < BKS / 16; ++ks) {
+          bf16x8 fa[LIMBS], fb[LIMBS][NJ];
+#pragma unroll
+          for (int l = 0; l < LIMBS; ++l) {
+            fa[l] = *reinterpret_cast<const bf16x8*>(&sW[l][(wco * 32 + l31) * ROWB + ks * 32 + kh * 16]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              fb[l][j] = *reinterpret_cast<const bf16x8*>(&sP[l][pbase[j] + tapoff + ks * 32 + kh * 16]);
+          }
+#pragma unroll
+          for (int sum = LIMBS - 1; sum >= 0; --sum)
+#pragma unroll
+            for (int la = 0; la <= sum; ++la) {
+              const int lb = sum - la;
+#pragma unroll
+              for (int j = 0; j < NJ; ++j)
+                acc[cls][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la], fb[lb][j], acc[cls][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  const bool atomic = a.splitk > 1;
+  const int ohw = a.oh * a.ow;
+  const int ochan0 = (pn * a.groups + g) * a.cout_g;
+  const float* osc = a.out_scale ? a.out_scale + ochan0 : nullptr;
+  const float* bia = (a.bias && split == 0) ? a.bias + g * a.cout_g : nullptr;
+  if (atomic) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int p = (wpix * NJ + j) * 32 + l31;
+        const int oy = 2 * (y0 + (p >> tw_log2)) + (c >> 1) - pad, ox = 2 * (x0 + (p & (TW - 1))) + (c & 1) - pad;
+        if ((unsigned)oy >= (unsigned)a.oh || (unsigned)ox >= (unsigned)a.ow) continue;
+        float* yp = a.y + (size_t)ochan0 * ohw + (size_t)oy * a.ow + ox;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (co >= a.cout_g) continue;
+          float v = acc[c][j][r];
+          if (osc) v *= osc[co];
+          if (bia) v += bia[co];
+          unsafeAtomicAdd(yp + (size_t)co * ohw, v);
+        }
+      }
+    }
+    return;
+  }
+  // interleave the classes through LDS: per pass 8 channels x (2*64) outputs of one output-row parity
+  __syncthreads();
+  float* stage = reinterpret_cast<float*>(smem) + wid * (8 * 128);
+#pragma unroll
+  for (int py = 0; py < 2; ++py) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = q4 * 4 + rr;
+        const int lrow = rr + 4 * (lane >> 5);
+        const int co = co0 + wco * 32 + lrow + 8 * q4;
+        float sc = 1.f, bi = 0.f;
+        if (co < a.cout_g) {
+          if (osc) sc = osc[co];
+          if (bia) bi = bia[co];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int px = 0; px < 2; ++px)
+            stage[lrow * 128 + (j * 32 + l31) * 2 + px] = acc[py * 2 + px][j][r] * sc + bi;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int idx = it * 64 + lane;
+        const int lrow = idx >> 7, s = idx & 127;
+        const int p = wpix * 64 + (s >> 1);
+        const int oy = 2 * (y0 + (p >> tw_log2)) + py - pad, ox = 2 * (x0 + (p & (TW - 1))) + (s & 1) - pad;
+        const int co = co0 + wco * 32 + lrow + 8 * q4;
+        if (co < a.cout_g && (unsigned)oy < (unsigned)a.oh && (unsigned)ox < (unsigned)a.ow)
+          a.y[(size_t)(ochan0 + co) * ohw + (size_t)oy * a.ow + ox] = stage[lrow * 128 + s];
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -1184,6 +1475,7 @@ int launch_conv_split(const ConvArgs& a, int limbs, hipStream_t st) {
 bool patch_geometry(const ConvArgs& a, int tpix, int& tw_log2) {
   const int w = a.w, h = a.h;
   if (w < 16 || (w & (w - 1)) != 0) return false;
+  if ((long long)a.cin_g * h * w * 4 >= (1LL << 31)) return false;        // buffer-resource addressing
   int tw = w < 64 ? w : 64;
   tw_log2 = 0;
   while ((1 << tw_log2) < tw) ++tw_log2;
@@ -1228,8 +1520,62 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
   return gg::launch_status("conv3x3_patch");
 }
 
+// all-classes transposed 3x3 / stride 2 kernel: power-of-two input width >= 16
+int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
+  int tw_log2 = 0;
+  const int tw = a.w < 64 ? a.w : 64;
+  while ((1 << tw_log2) < tw) ++tw_log2;
+  a.tiles_co = (a.cout_g + 127) / 128;
+  auto tiles_for = [&](int tq, int& tiles_y, int& edge) {
+    const int th = tq >> tw_log2;
+    tiles_y = (a.h + th) / th;                  // ceil((h + 1) / th)
+    edge = (a.h + tq) / tq;                     // ceil((h + 1) / tq)
+    return (long long)a.batch * (tiles_y * (a.w >> tw_log2) + edge);
+  };
+  int tiles_y, edge;
+  int tq = 128;
+  long long tp = tiles_for(tq, tiles_y, edge);
+  if (limbs != 2 || tp * a.tiles_co * a.groups < 2 * gg::kNumCu) {
+    tq = 64;
+    tp = tiles_for(tq, tiles_y, edge);
+  }
+  if (tp * a.tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
+  a.tiles_pix = (int)tp;
+  a.nslabs = a.cin_g / BKS;
+  const long long blocks = tp * a.tiles_co * a.groups;
+  int splitk = 1;
+  if (blocks < 2 * gg::kNumCu) {
+    splitk = (int)((2 * gg::kNumCu + blocks - 1) / blocks);
+    if (splitk > a.nslabs) splitk = a.nslabs;
+    if (splitk < 1) splitk = 1;
+  }
+  a.slabs_per_split = (a.nslabs + splitk - 1) / splitk;
+  a.splitk = (a.nslabs + a.slabs_per_split - 1) / a.slabs_per_split;
+  if (a.splitk > 1) {
+    const size_t out_elems = (size_t)a.batch * a.groups * a.cout_g * a.oh * a.ow;
+    hipError_t e = hipMemsetAsync(a.y, 0, sizeof(float) * out_elems, st);
+    if (e != hipSuccess) return gg::fail((int)e, "conv2d: memset failed");
+  }
+  dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
+  const bool sc = a.in_scale != nullptr;
+  if (limbs == 2 && tq == 128) {
+    if (sc) convT3x3s2_patch_kernel<2, true, 128><<<grid, 512, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
+    else convT3x3s2_patch_kernel<2, false, 128><<<grid, 512, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
+  } else if (limbs == 2) {
+    if (sc) convT3x3s2_patch_kernel<2, true, 64><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
+    else convT3x3s2_patch_kernel<2, false, 64><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
+  } else {
+    if (sc) convT3x3s2_patch_kernel<3, true, 64><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
+    else convT3x3s2_patch_kernel<3, false, 64><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
+  }
+  return gg::launch_status("convT3x3s2_patch");
+}
+
 template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {
+  if (limbs && KS == 3 && mode == 1 && pad <= 1 && a.w >= 16 && (a.w & (a.w - 1)) == 0 &&
+      (long long)a.cin_g * a.h * a.w * 4 < (1LL << 31))
+    return launch_convT_patch(a, limbs, pad, st);
   if (limbs && KS == 3 && mode == 0 && stride == 1 && pad == 1) {
     int tw_log2;
     // 256-pixel tiles when they still fill the chip (>= 2 blocks per CU), else 128-pixel tiles

@@ -26,6 +26,12 @@ CASES = [
     (1, 512, 512, 4, 3, 1, 1, 0, True),       # split-K + atomics
     (2, 64, 130, 20, 1, 1, 0, 0, False),      # 1x1, ragged cout
     (2, 128, 64, 15, 1, 2, 0, 1, False),      # 1x1 transposed: odd positions stay zero
+    # all-parity-classes transposed kernel (power-of-two input width >= 16)
+    (2, 64, 130, (16, 16), 3, 2, 0, 1, True),     # 16-wide tiles, ragged cout
+    (2, 64, 128, (21, 32), 3, 2, 0, 1, True),     # 32-wide tiles, ragged tile rows
+    (1, 96, 64, (33, 64), 3, 2, 1, 1, False),     # pad 1 (data gradient of a stride-2 conv) + output_padding
+    (4, 32, 128, (128, 128), 3, 2, 0, 1, True),   # enough tiles for the 128-q (8-wave) variant
+    (1, 256, 256, (16, 16), 3, 2, 0, 1, True),    # split-K + atomics
 ]
 
 
@@ -35,17 +41,21 @@ def test_split_conv_matches_fp32_kernel(spec, mode_name, tol, cuda, precision):
     from gangealing_amd.op import conv_mfma as cm
     n, cin, cout, h, k, stride, pad, mode, scaled = spec
     g = torch.Generator(device='cpu').manual_seed(1234)
-    x = torch.randn(n, cin, h, h + 2, generator=g).to(cuda)
+    hh, ww = h if isinstance(h, tuple) else (h, h + 2)
+    x = torch.randn(n, cin, hh, ww, generator=g).to(cuda)
     w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(cuda)
     s_in = (torch.rand(n, cin, generator=g) + 0.5).to(cuda) if scaled else None
     s_out = (torch.rand(n, cout, generator=g) + 0.5).to(cuda) if scaled else None
     bias = torch.randn(cout, generator=g).to(cuda)
     pw = cm.PackedWeight(w, 1, cout, cin, k, 0, 0, 0.7)
     assert pw.split_ok()
+    out_hw = (2 * hh, 2 * ww) if (mode == 1 and pad == 1) else None       # output_padding = 1
     precision('fp32')
-    ref = cm.conv_forward(x, pw, n, 1, cin, cout, k, stride, pad, mode, in_scale=s_in, out_scale=s_out, bias=bias)
+    ref = cm.conv_forward(x, pw, n, 1, cin, cout, k, stride, pad, mode, in_scale=s_in, out_scale=s_out, bias=bias,
+                          out_hw=out_hw)
     precision(mode_name)
-    out = cm.conv_forward(x, pw, n, 1, cin, cout, k, stride, pad, mode, in_scale=s_in, out_scale=s_out, bias=bias)
+    out = cm.conv_forward(x, pw, n, 1, cin, cout, k, stride, pad, mode, in_scale=s_in, out_scale=s_out, bias=bias,
+                          out_hw=out_hw)
     assert out.shape == ref.shape
     err = float((out - ref).abs().max() / ref.abs().max())
     assert err < tol, err
