@@ -286,6 +286,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* p, i
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
                                            __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
+__device__ __forceinline__ U4 buffer_load_u4(__amdgpu_buffer_rsrc_t r, unsigned voffset, int soffset) {
+  return __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voffset, soffset, 0));
+}
 __device__ __forceinline__ float buffer_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voffset, int soffset) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voffset, soffset, 0));
 }   // a native vector: a struct here is kept in scratch by the compiler
@@ -556,7 +559,12 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   const bool w_thr = tid < 2 * TCO;                       // the first 256 threads move the weight slab
   const bool w_ok = (co0 + wrow) < a.cout_g;
   const int kfull = 9 * a.cin_g;
-  const unsigned short* wrow_ptr = a.wsplit + ((size_t)g * a.cout_g + (w_ok ? co0 + wrow : 0)) * kfull + wpart * EPT;
+  // weights through a buffer resource too: loop-invariant lane offset + scalar (tap, chunk, limb) offset, so the
+  // loads need no address VGPRs (no WAR wait on the previous slab's registers) and rows beyond cout read as zero
+  const __amdgpu_buffer_rsrc_t wr = uniform_rsrc(reinterpret_cast<const float*>(a.wsplit),
+                                                 (int)(a.wsplit_stride * 2 * LIMBS));
+  const unsigned wvoff = w_ok ? (unsigned)((((size_t)g * a.cout_g + co0 + wrow) * kfull + wpart * EPT) * 2) : kOobOffset;
+  const int wlimb = __builtin_amdgcn_readfirstlane((int)(a.wsplit_stride * 2));     // bytes between limb planes
 
   const int chunk0 = split * a.slabs_per_split;
   int chunk1 = chunk0 + a.slabs_per_split;
@@ -609,22 +617,21 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   };
   auto load_w = [&](int chunk, int t) {
     if (!w_thr) return;
-    const unsigned short* wsrc = wrow_ptr + (size_t)t * a.cin_g + chunk * BKS;
+    const int soff = __builtin_amdgcn_readfirstlane((t * a.cin_g + chunk * BKS) * 2);
 #pragma unroll
     for (int l = 0; l < LIMBS; ++l) {
-      const U4* w4 = reinterpret_cast<const U4*>(wsrc + (size_t)l * a.wsplit_stride);
 #pragma unroll
-      for (int q = 0; q < EPT / 8; ++q) wv[l][q] = w4[q];
+      for (int q = 0; q < EPT / 8; ++q)
+        wv[l][q] = buffer_load_u4(wr, wvoff, soff + l * wlimb + q * 16);
     }
   };
   auto store_w = [&]() {
     if (!w_thr) return;
-    const U4 z{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int l = 0; l < LIMBS; ++l) {
       U4* wd = reinterpret_cast<U4*>(&sW[l][wrow * ROWB + wpart * EPT * 2]);
 #pragma unroll
-      for (int q = 0; q < EPT / 8; ++q) wd[q] = w_ok ? wv[l][q] : z;
+      for (int q = 0; q < EPT / 8; ++q) wd[q] = wv[l][q];
     }
   };
 
@@ -831,7 +838,12 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   const bool w_thr = tid < 2 * TCO;
   const bool w_ok = (co0 + wrow) < a.cout_g;
   const int kfull = 9 * a.cin_g;
-  const unsigned short* wrow_ptr = a.wsplit + ((size_t)g * a.cout_g + (w_ok ? co0 + wrow : 0)) * kfull + wpart * EPT;
+  // weights through a buffer resource too: loop-invariant lane offset + scalar (tap, chunk, limb) offset, so the
+  // loads need no address VGPRs (no WAR wait on the previous slab's registers) and rows beyond cout read as zero
+  const __amdgpu_buffer_rsrc_t wr = uniform_rsrc(reinterpret_cast<const float*>(a.wsplit),
+                                                 (int)(a.wsplit_stride * 2 * LIMBS));
+  const unsigned wvoff = w_ok ? (unsigned)((((size_t)g * a.cout_g + co0 + wrow) * kfull + wpart * EPT) * 2) : kOobOffset;
+  const int wlimb = __builtin_amdgcn_readfirstlane((int)(a.wsplit_stride * 2));     // bytes between limb planes
 
   const int chunk0 = split * a.slabs_per_split;
   int chunk1 = chunk0 + a.slabs_per_split;
@@ -884,22 +896,21 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   };
   auto load_w = [&](int chunk, int t) {
     if (!w_thr) return;
-    const unsigned short* wsrc = wrow_ptr + (size_t)t * a.cin_g + chunk * BKS;
+    const int soff = __builtin_amdgcn_readfirstlane((t * a.cin_g + chunk * BKS) * 2);
 #pragma unroll
     for (int l = 0; l < LIMBS; ++l) {
-      const U4* w4 = reinterpret_cast<const U4*>(wsrc + (size_t)l * a.wsplit_stride);
 #pragma unroll
-      for (int q = 0; q < EPT / 8; ++q) wv[l][q] = w4[q];
+      for (int q = 0; q < EPT / 8; ++q)
+        wv[l][q] = buffer_load_u4(wr, wvoff, soff + l * wlimb + q * 16);
     }
   };
   auto store_w = [&]() {
     if (!w_thr) return;
-    const U4 z{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int l = 0; l < LIMBS; ++l) {
       U4* wd = reinterpret_cast<U4*>(&sW[l][wrow * ROWB + wpart * EPT * 2]);
 #pragma unroll
-      for (int q = 0; q < EPT / 8; ++q) wd[q] = w_ok ? wv[l][q] : z;
+      for (int q = 0; q < EPT / 8; ++q) wd[q] = wv[l][q];
     }
   };
 
@@ -1670,6 +1681,7 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
     if (cin_g % BKS != 0) return gg::fail(-2, "conv2d_split: cin per group must be a multiple of %d", BKS);
     if (in_scale && (reinterpret_cast<uintptr_t>(in_scale) & 15)) return gg::fail(-2, "conv2d_split: in_scale must be 16-byte aligned");
     if (reinterpret_cast<uintptr_t>(wsplit) & 15) return gg::fail(-2, "conv2d_split: weights must be 16-byte aligned");
+    if (wsplit_stride * 2 * limbs >= (1LL << 31)) return gg::fail(-2, "conv2d_split: weight buffer too large");
   }
   ConvArgs a;
   a.y = y; a.x = x; a.wmat = wmat; a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
