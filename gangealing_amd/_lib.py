@@ -43,6 +43,7 @@ _PROTOS = {
     'gg_conv2d_f32': 'ppppppiiiiiiiiiiiis',
     'gg_conv_pack_weight_split': 'ppiiiiiiifis',
     'gg_conv2d_split_f32': 'pppqipppiiiiiiiiiiiis',
+    'gg_modconv3x3_act_f32': 'ppppqipppppffiiiiis',
     'gg_conv2d_wgrad_f32': 'pppiiiiiiiiifs',
     'gg_conv2d_wgrad_split_f32': 'pppiiiiiiiiifis',
     'gg_plane_dot_f32': 'pppiqs',

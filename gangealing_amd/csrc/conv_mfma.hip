@@ -52,6 +52,11 @@ struct ConvArgs {
   int tile_pixels;                // pixels per block tile chosen by plan_conv
   const unsigned short* wsplit;   // bf16 limb planes [limb][g][co][k = (tap, ci)]  (split-precision path)
   long long wsplit_stride;        // elements between limb planes
+  // optional StyledConv tail fused into the epilogue: y = lrelu(acc + noise_w[0]*noise[n,pix] + act_bias[co]) * gain
+  const float* act_noise;         // (N, 1, OH, OW) or null = no fused activation
+  const float* act_noise_w;       // device scalar
+  const float* act_bias;          // (groups*cout_g)
+  float act_alpha, act_gain;
 };
 
 // k -> (ci, ky, kx, dy, dx).  MODE 0: correlation taps; MODE 1: taps of one parity class.
@@ -743,6 +748,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
         stage[row * 64 + j * 32 + (lane & 31)] = v;
       }
     __syncthreads();
+    const float anw = a.act_noise ? a.act_noise_w[0] : 0.f;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int idx = it * 64 + lane;
@@ -751,7 +757,16 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       const int p = wpix * 64 + c4 * 4;
       const int oy = y0 + (p >> tw_log2), ox = x0 + (p & (TW - 1));
       if (co < a.cout_g) {
-        const float4 v4 = *reinterpret_cast<const float4*>(stage + row * 64 + c4 * 4);
+        float4 v4 = *reinterpret_cast<const float4*>(stage + row * 64 + c4 * 4);
+        if (a.act_noise) {       // NoiseInjection + FusedLeakyReLU (networks.py:291-298, 344-350)
+          const float4 nz = *reinterpret_cast<const float4*>(a.act_noise + (size_t)pn * hw + (size_t)oy * a.w + ox);
+          const float ab = a.act_bias[g * a.cout_g + co];
+          float t;
+          t = v4.x + anw * nz.x + ab; v4.x = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
+          t = v4.y + anw * nz.y + ab; v4.y = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
+          t = v4.z + anw * nz.z + ab; v4.z = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
+          t = v4.w + anw * nz.w + ab; v4.w = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
+        }
         *reinterpret_cast<float4*>(a.y + (size_t)(ochan0 + co) * hw + (size_t)oy * a.w + ox) = v4;
       }
     }
@@ -1482,6 +1497,12 @@ int launch_conv_split(const ConvArgs& a, int limbs, hipStream_t st) {
   return gg::launch_status("conv_split");
 }
 
+// the StyledConv tail as a separate in-place pass (launches whose epilogue cannot carry it)
+int post_activation(const ConvArgs& a, hipStream_t st) {
+  return gg_noise_bias_act_f32(a.y, a.y, a.act_noise, a.act_noise_w, a.act_bias, a.act_alpha, a.act_gain, a.batch,
+                               a.groups * a.cout_g, (long long)a.oh * a.ow, st);
+}
+
 // 3x3 / stride 1 / pad 1 with a power-of-two width >= 16 whose 128-pixel tiles fit the image
 bool patch_geometry(const ConvArgs& a, int tpix, int& tw_log2) {
   const int w = a.w, h = a.h;
@@ -1518,6 +1539,8 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
   }
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
+  const ConvArgs full = a;
+  if (a.splitk > 1) a.act_noise = nullptr;                  // atomically combined partials: activation afterwards
   if (limbs == 2 && tpix == 256) {
     if (sc) conv3x3_patch_kernel<2, true, 256><<<grid, 512, 0, st>>>(a, tw_log2);
     else conv3x3_patch_kernel<2, false, 256><<<grid, 512, 0, st>>>(a, tw_log2);
@@ -1528,7 +1551,9 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
     if (sc) conv3x3_patch_kernel<3, true, 128><<<grid, 256, 0, st>>>(a, tw_log2);
     else conv3x3_patch_kernel<3, false, 128><<<grid, 256, 0, st>>>(a, tw_log2);
   }
-  return gg::launch_status("conv3x3_patch");
+  const int rc = gg::launch_status("conv3x3_patch");
+  if (rc || !full.act_noise || a.act_noise) return rc;
+  return post_activation(full, st);
 }
 
 // all-classes transposed 3x3 / stride 2 kernel: power-of-two input width >= 16
@@ -1584,7 +1609,7 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
 
 template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {
-  if (limbs && KS == 3 && mode == 1 && pad <= 1 && a.w >= 16 && (a.w & (a.w - 1)) == 0 &&
+  if (!a.act_noise && limbs && KS == 3 && mode == 1 && pad <= 1 && a.w >= 16 && (a.w & (a.w - 1)) == 0 &&
       (long long)a.cin_g * a.h * a.w * 4 < (1LL << 31))
     return launch_convT_patch(a, limbs, pad, st);
   if (limbs && KS == 3 && mode == 0 && stride == 1 && pad == 1) {
@@ -1594,6 +1619,12 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     if (limbs == 2 && tiles256 >= 2 * gg::kNumCu && patch_geometry(a, 256, tw_log2))
       return launch_conv_patch(a, limbs, tw_log2, 256, st);
     if (patch_geometry(a, 128, tw_log2)) return launch_conv_patch(a, limbs, tw_log2, 128, st);
+  }
+  if (a.act_noise) {      // no other kernel carries the activation in its epilogue
+    ConvArgs plain = a;
+    plain.act_noise = nullptr;
+    const int rc = conv_dispatch<KS>(plain, stride, pad, mode, st, limbs);
+    return rc ? rc : post_activation(a, st);
   }
   // tile selector.  (Measured on the 128->128 @256^2 layer: an 8-wave 128x128 variant, a 128co x 256pix
   // variant with 8 accumulators per wave and BK = 32 are all within -20..+1 % of this 4-wave tile.)
@@ -1663,10 +1694,17 @@ extern "C" int gg_conv_pack_weight_f32(float* wmat, const float* w, int groups, 
 }
 
 namespace {
+struct ActArgs {
+  const float* noise = nullptr;
+  const float* noise_w = nullptr;
+  const float* bias = nullptr;
+  float alpha = 0.f, gain = 1.f;
+};
+
 int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned short* wsplit, long long wsplit_stride,
                  int limbs, const float* in_scale, const float* out_scale, const float* bias, int batch, int groups,
                  int cin_g, int cout_g, int h, int w, int ksize, int stride, int pad, int mode, int out_h, int out_w,
-                 void* stream) {
+                 void* stream, const ActArgs& act = ActArgs()) {
   if (batch <= 0 || groups <= 0 || cin_g <= 0 || cout_g <= 0) return 0;
   if (!y || !x || (!wmat && !wsplit) || h <= 0 || w <= 0) return gg::fail(-2, "conv2d: bad arguments");
   if (ksize != 1 && ksize != 3) return gg::fail(-2, "conv2d: kernel size %d not supported (1 or 3)", ksize);
@@ -1686,6 +1724,8 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   ConvArgs a;
   a.y = y; a.x = x; a.wmat = wmat; a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
   a.wsplit = wsplit; a.wsplit_stride = wsplit_stride;
+  a.act_noise = act.noise; a.act_noise_w = act.noise_w; a.act_bias = act.bias;
+  a.act_alpha = act.alpha; a.act_gain = act.gain;
   a.batch = batch; a.groups = groups; a.cin_g = cin_g; a.cout_g = cout_g; a.h = h; a.w = w;
   if (mode == 0) {
     a.oh = (h + 2 * pad - ksize) / stride + 1;
@@ -1718,6 +1758,22 @@ extern "C" int gg_conv2d_split_f32(float* y, const float* x, const unsigned shor
                                    int pad, int mode, int out_h, int out_w, void* stream) {
   return conv2d_entry(y, x, nullptr, wsplit, limb_stride, limbs, in_scale, out_scale, bias, batch, groups, cin_g,
                       cout_g, h, w, ksize, stride, pad, mode, out_h, out_w, stream);
+}
+
+extern "C" int gg_modconv3x3_act_f32(float* y, const float* x, const float* wmat, const unsigned short* wsplit,
+                                     long long limb_stride, int limbs, const float* in_scale,
+                                     const float* out_scale, const float* noise, const float* noise_weight,
+                                     const float* act_bias, float alpha, float gain, int batch, int cin, int cout,
+                                     int h, int w, void* stream) {
+  if (!noise || !noise_weight || !act_bias) return gg::fail(-2, "modconv3x3_act: null activation operand");
+  if ((h * w) % 4 != 0 || (reinterpret_cast<uintptr_t>(noise) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
+    return gg::fail(-2, "modconv3x3_act: H*W must be a multiple of 4 and y / noise 16-byte aligned");
+  if (limbs == 0 && !wmat) return gg::fail(-2, "modconv3x3_act: fp32 weights missing");
+  if (limbs != 0 && !wsplit) return gg::fail(-2, "modconv3x3_act: split weights missing");
+  ActArgs act;
+  act.noise = noise; act.noise_w = noise_weight; act.bias = act_bias; act.alpha = alpha; act.gain = gain;
+  return conv2d_entry(y, x, limbs ? nullptr : wmat, limbs ? wsplit : nullptr, limb_stride, limbs, in_scale, out_scale,
+                      nullptr, batch, 1, cin, cout, h, w, 3, 1, 1, 0, 0, 0, stream, act);
 }
 
 extern "C" int gg_conv_pack_weight_split(unsigned short* wsplit, const float* w, int groups, int cout_g, int cin_g,

@@ -108,7 +108,10 @@ def pack_weight(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0)
 
 
 def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in_scale=None, out_scale=None,
-                 bias=None, out_hw=None):
+                 bias=None, out_hw=None, act=None):
+    """act = (noise (N,1,OH,OW), noise_weight (1,), act_bias (Cout,), alpha, gain): the StyledConv tail
+    lrelu(y + noise_weight*noise + act_bias)*gain fused behind a 3x3/stride-1/pad-1 convolution
+    (gg_modconv3x3_act_f32)."""
     h, w = x.shape[-2], x.shape[-1]
     if mode == 0:
         oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
@@ -135,7 +138,15 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
         if prof is not None:
             start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record()
-        if use_split:
+        if act is not None:
+            if (k, stride, pad, mode, groups) != (3, 1, 1, 0, 1) or bias is not None or (oh * ow) % 4:
+                raise NotImplementedError('conv_forward: the fused activation needs a 3x3 stride-1 pad-1 single-group conv')
+            noise, noise_weight, act_bias, alpha, gain = act
+            wbuf, stride_l = wmat.split(limbs) if use_split else (None, 0)
+            wm = None if use_split else (wmat.fp32() if isinstance(wmat, PackedWeight) else wmat)
+            _lib.call('gg_modconv3x3_act_f32', y, x, wm, wbuf, stride_l, limbs if use_split else 0, in_scale, out_scale,
+                      noise, noise_weight, act_bias, alpha, gain, batch, cin_g, cout_g, h, w)
+        elif use_split:
             wbuf, stride_l = wmat.split(limbs)
             _lib.call('gg_conv2d_split_f32', y, x, wbuf, stride_l, limbs, in_scale, out_scale, bias, batch, groups,
                       cin_g, cout_g, h, w, k, stride, pad, mode, oh if mode == 1 else 0, ow if mode == 1 else 0)
@@ -322,5 +333,48 @@ class _ModulatedConv(Function):
         return dx, dstyle, None, None, None, None, None, None
 
 
-def modulated_conv2d(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample=False, demodulate=True):
+class _ModulatedConvAct(Function):
+    """StyledConv without upsampling, in one kernel: lrelu(demod * conv(W, style * x) + nw * noise + b) * gain
+    (networks.py:243-298, 344-350).  Used when no gradient is wanted for the style, the noise weight or the
+    activation bias (frozen generator beyond the learned W+ slots): the backward is the leaky-ReLU mask
+    (sign reference = the saved OUTPUT, as in fused_act.py:27-38) followed by the data gradient."""
+
+    @staticmethod
+    def forward(ctx, x, style, wmat_fwd, wmat_bwd, wsq, demodulate, noise, noise_weight, act_bias, alpha, gain):
+        x = x.contiguous()
+        style = style.contiguous()
+        n, cin, h, w = x.shape
+        cout = wmat_fwd.cout_g
+        demod = torch.rsqrt((style * style) @ wsq.t() + 1e-8) if demodulate else None
+        y = conv_forward(x, wmat_fwd, n, 1, cin, cout, 3, 1, 1, 0, in_scale=style, out_scale=demod,
+                         act=(noise.contiguous(), noise_weight.contiguous(), act_bias.contiguous(), alpha, gain))
+        ctx.save_for_backward(style, demod if demod is not None else style.new_empty(0), y)
+        ctx.wmat_bwd = wmat_bwd
+        ctx.conf = (demodulate, alpha, gain, cin)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        style, demod, y = ctx.saved_tensors
+        demodulate, alpha, gain, cin = ctx.conf
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 11
+        dy = dy.contiguous()
+        n, cout, h, w = y.shape
+        g = torch.empty_like(dy)
+        _lib.call('gg_fused_lrelu_bwd_f32', g, None, dy, y, alpha, gain, n, cout, h * w)
+        dx = conv_forward(g, ctx.wmat_bwd, n, 1, cout, cin, 3, 1, 1, 0, in_scale=demod if demodulate else None,
+                          out_scale=style)
+        return (dx,) + (None,) * 10
+
+
+def modulated_conv2d(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample=False, demodulate=True, act=None):
+    """act = (noise, noise_weight, act_bias, alpha, gain) fuses the StyledConv tail (3x3, no upsampling, and no
+    gradient wanted for style / noise weight / bias)."""
+    if act is not None:
+        noise, noise_weight, act_bias, alpha, gain = act
+        if k != 3 or upsample or style.requires_grad or noise_weight.requires_grad or act_bias.requires_grad:
+            raise NotImplementedError('modulated_conv2d: fused activation not applicable to this layer')
+        return _ModulatedConvAct.apply(x, style, wmat_fwd, wmat_bwd, wsq, demodulate, noise, noise_weight, act_bias,
+                                       alpha, gain)
     return _ModulatedConv.apply(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate)

@@ -169,14 +169,28 @@ class ModulatedConv2d(nn.Module):
             self._packed = (key, wmat_fwd, wmat_bwd, wsq)
         return self._packed[1:]
 
-    def forward(self, input, style):
+    def forward(self, input, style, act=None):
+        """act = (noise, noise_weight, bias, negative_slope, scale): fuse StyledConv's NoiseInjection +
+        FusedLeakyReLU into the convolution (callers check `can_fuse_act` first)."""
         style = self.modulation(style)                                  # (N, Cin)
         wmat_fwd, wmat_bwd, wsq = self._weights()
         out = conv_mfma.modulated_conv2d(input, style, wmat_fwd, wmat_bwd, wsq, self.kernel_size,
-                                         upsample=self.upsample, demodulate=self.demodulate)
+                                         upsample=self.upsample, demodulate=self.demodulate, act=act)
         if self.upsample:
             out = self.blur(out)
         return out
+
+    def can_fuse_act(self, input, style, *frozen):
+        """The one-kernel StyledConv applies to 3x3 layers without upsampling when neither the style (i.e. the
+        latent and the modulation layer) nor the activation parameters need a gradient."""
+        if self.upsample or self.kernel_size != 3 or input.dtype != torch.float32:
+            return False
+        if (input.shape[-1] * input.shape[-2]) % 4:
+            return False
+        if torch.is_grad_enabled() and (style.requires_grad or self.modulation.weight.requires_grad or
+                                        any(p.requires_grad for p in frozen)):
+            return False
+        return True
 
 
 class NoiseInjection(nn.Module):
@@ -213,6 +227,14 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
 
     def forward(self, input, style, noise=None):
+        if self.conv.can_fuse_act(input, style, self.noise.weight, self.activate.bias):
+            n, _, h, w = input.shape
+            if noise is None:
+                noise = input.new_empty(n, 1, h, w).normal_()
+            elif noise.shape[0] != n:
+                noise = noise.expand(n, -1, -1, -1)
+            return self.conv(input, style, act=(noise.type(input.dtype), self.noise.weight, self.activate.bias,
+                                                self.activate.negative_slope, self.activate.scale))
         out = self.conv(input, style)
         n, _, h, w = out.shape
         if out.dtype == torch.float32 and (h * w) % 4 == 0:

@@ -215,6 +215,16 @@ int gg_conv2d_split_f32(float* y, const float* x, const unsigned short* wsplit, 
                         const float* in_scale, const float* out_scale, const float* bias, int batch, int groups,
                         int cin_g, int cout_g, int h, int w, int ksize, int stride, int pad, int mode, int out_h,
                         int out_w, void* stream);
+/* StyledConv without upsampling in ONE pass (networks.py:243-298, 344-350: ModulatedConv2d -> NoiseInjection ->
+ * FusedLeakyReLU):  y = lrelu(out_scale[n,co] * conv3x3(W, in_scale[n,ci] * x) + noise_weight[0] * noise[n,0] +
+ * act_bias[co], alpha) * gain.  3x3 / stride 1 / pad 1, one group.  limbs = 0: fp32 MFMA kernel with `wmat`
+ * (gg_conv_pack_weight_f32); limbs = 2|3: split-precision kernel with `wsplit` (gg_conv_pack_weight_split).
+ * The activation rides in the convolution's epilogue when the launch needs no split-K; otherwise the library runs
+ * gg_noise_bias_act_f32 in place afterwards - the result is the same either way.  H*W % 4 == 0. */
+int gg_modconv3x3_act_f32(float* y, const float* x, const float* wmat, const unsigned short* wsplit,
+                          long long limb_stride, int limbs, const float* in_scale, const float* out_scale,
+                          const float* noise, const float* noise_weight, const float* act_bias, float alpha,
+                          float gain, int batch, int cin, int cout, int h, int w, void* stream);
 /* Weight gradient: dw (groups, cout_g, cin_g, k, k) torch layout, overwritten.
  *   dw[g,co,ci,ky,kx] = sum_{n,oy,ox} dy[n,g*cout_g+co,oy,ox] * x[n,g*cin_g+ci, oy*stride+ky-pad, ox*stride+kx-pad] */
 int gg_conv2d_wgrad_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g, int cout_g,

@@ -99,3 +99,35 @@ def test_autograd_through_split_conv(cuda, precision):
     F.conv2d(xc, wc, padding=1).backward(g.cpu())
     np.testing.assert_allclose(x.grad.cpu().numpy(), xc.grad.numpy(), atol=2e-4, rtol=2e-4)
     np.testing.assert_allclose(w.grad.cpu().numpy(), wc.grad.numpy(), atol=5e-4, rtol=5e-4)   # wgrad stays fp32 MFMA
+
+
+@pytest.mark.parametrize('mode_name', ['fp32', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('shape', [(2, 64, 96, 16), (1, 512, 512, 4), (4, 32, 128, 64), (16, 64, 128, 64)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_styled_conv_fused_activation_matches_unfused(shape, mode_name, cuda, precision):
+    """One-kernel StyledConv (conv epilogue carries noise + bias + leaky ReLU) == conv, then noise_bias_act."""
+    from gangealing_amd.op.fused_act import noise_bias_leaky_relu
+    from gangealing_amd.stylegan2.networks import StyledConv
+    n, cin, cout, res = shape
+    precision(mode_name)
+    torch.manual_seed(7)
+    layer = StyledConv(cin, cout, 3, 32).to(cuda).requires_grad_(False)
+    layer.noise.weight.fill_(0.37)
+    layer.activate.bias.copy_(torch.randn(cout, device=cuda) * 0.5)
+    x = torch.randn(n, cin, res, res, device=cuda, requires_grad=True)
+    style = torch.randn(n, 32, device=cuda)
+    noise = torch.randn(n, 1, res, res, device=cuda)
+    assert layer.conv.can_fuse_act(x, style, layer.noise.weight, layer.activate.bias)
+    fused = layer(x, style, noise=noise)
+    g = torch.randn_like(fused)
+    (dx_fused,) = torch.autograd.grad(fused, x, g)
+    pre = layer.conv(x, style)
+    ref = noise_bias_leaky_relu(pre, noise, layer.noise.weight, layer.activate.bias, layer.activate.negative_slope,
+                                layer.activate.scale)
+    (dx_ref,) = torch.autograd.grad(ref, x, g)
+    scale = float(ref.detach().abs().max())
+    # same kernels, same accumulation order: only the epilogue's fused multiply-add differs
+    assert float((fused - ref).detach().abs().max()) <= 2e-6 * scale
+    assert float((dx_fused - dx_ref).abs().max()) <= 2e-6 * float(dx_ref.abs().max())
+    # a style that needs a gradient (learned W+ slots) must keep the unfused path
+    assert not layer.conv.can_fuse_act(x, style.clone().requires_grad_(True), layer.noise.weight, layer.activate.bias)
