@@ -23,6 +23,7 @@ _PROTOS = {
     'gg_noise_bias_act_f32': 'pppppffiiqs',
     'gg_upfirdn2d_f32': 'pppiiiiiiiiiiiiis',
     'gg_upfirdn2d_f64': 'pppiiiiiiiiiiiiis',
+    'gg_blur4_fused_f32': 'pppiiiiiiiippppffs',
     'gg_splat_forward_f32': 'pppppiiiiis',
     'gg_splat2d_f32': 'ppppppiiiiiis',
     'gg_mip_downsample2x_f32': 'ppiiis',

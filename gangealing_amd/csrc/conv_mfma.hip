@@ -1556,7 +1556,7 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
   return post_activation(full, st);
 }
 
-// all-classes transposed 3x3 / stride 2 kernel: power-of-two input width >= 16
+// all-classes transposed 3x3 / stride 2 kernel: power-of-two input width >= 4
 int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   int tw_log2 = 0;
   const int tw = a.w < 64 ? a.w : 64;
@@ -1609,7 +1609,7 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
 
 template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {
-  if (!a.act_noise && limbs && KS == 3 && mode == 1 && pad <= 1 && a.w >= 16 && (a.w & (a.w - 1)) == 0 &&
+  if (!a.act_noise && limbs && KS == 3 && mode == 1 && pad <= 1 && a.w >= 4 && (a.w & (a.w - 1)) == 0 &&
       (long long)a.cin_g * a.h * a.w * 4 < (1LL << 31))
     return launch_convT_patch(a, limbs, pad, st);
   if (limbs && KS == 3 && mode == 0 && stride == 1 && pad == 1) {

@@ -23,10 +23,24 @@ constexpr int TILE = 64;          // output tile edge of the blur kernel
 constexpr int TIN = TILE + 3;     // input tile edge (4 taps)
 constexpr int ROWS_PER_WAVE = TILE / 4;
 
+// Optional fusions for the generator's up-sampling StyledConv (networks.py:268-298, 344-350):
+//   EPI: the blur is followed by NoiseInjection + FusedLeakyReLU -> applied to the result before the store;
+//   PRO: the blur's INPUT is a leaky-ReLU gradient g * (ref > 0 ? 1 : alpha) * gain -> applied while the tile is
+//        staged (the backward of an EPI blur is a PRO blur of the incoming gradient with ref = the saved output).
+struct BlurFuse {
+  const float* noise;      // (N, 1, out_h, out_w)
+  const float* noise_w;    // device scalar
+  const float* bias;       // (C)
+  const float* ref;        // same shape as `in`
+  float alpha, gain;
+  int channels;
+};
+
+template <bool EPI, bool PRO>
 __global__ __launch_bounds__(256) void upfirdn2d_blur4_tile(
     float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ kernel,
     int planes, int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0,
-    int tiles_x, int tiles_y, unsigned ntiles) {
+    int tiles_x, int tiles_y, unsigned ntiles, const BlurFuse f) {
   __shared__ float sx[TIN][TIN + 1];
   __shared__ float sk[16];
 
@@ -47,7 +61,10 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_tile(
     const int r = idx / TIN, c = idx - r * TIN;
     const int iy = iy0 + r, ix = ix0 + c;
     float v = 0.f;
-    if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = src[(size_t)iy * in_w + ix];
+    if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) {
+      v = src[(size_t)iy * in_w + ix];
+      if (PRO) v *= (f.ref[(size_t)plane * in_h * in_w + (size_t)iy * in_w + ix] > 0.f) ? f.gain : f.gain * f.alpha;
+    }
     sx[r][c] = v;
   }
   __syncthreads();
@@ -67,6 +84,14 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_tile(
     w2[c] = sx[r0 + 2][lane + c];
   }
   float* dst = out + (size_t)plane * out_h * out_w;
+  const float* nz = nullptr;
+  float nw = 0.f, ab = 0.f;
+  if (EPI) {
+    const int n = plane / f.channels;
+    nz = f.noise + (size_t)n * out_h * out_w;
+    nw = f.noise_w[0];
+    ab = f.bias[plane - n * f.channels];
+  }
 #pragma unroll
   for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
 #pragma unroll
@@ -81,7 +106,13 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_tile(
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc += w3[c] * kf[12 + c];
     const int oy = oy0 + r0 + rr;
-    if (oy < out_h && ox < out_w) dst[(size_t)oy * out_w + ox] = acc;
+    if (oy < out_h && ox < out_w) {
+      if (EPI) {
+        const float t = acc + nw * nz[(size_t)oy * out_w + ox] + ab;
+        acc = (t > 0.f ? t : t * f.alpha) * f.gain;
+      }
+      dst[(size_t)oy * out_w + ox] = acc;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) { w0[c] = w1[c]; w1[c] = w2[c]; w2[c] = w3[c]; }
   }
@@ -145,9 +176,9 @@ int upfirdn2d_impl(T* out, const T* in, const T* kernel, int major, int in_h, in
     const int tiles_x = (out_w + TILE - 1) / TILE, tiles_y = (out_h + TILE - 1) / TILE;
     const long long ntiles = (long long)tiles_x * tiles_y * major;
     if (ntiles < (1LL << 31)) {
-      upfirdn2d_blur4_tile<<<(unsigned)ntiles, 256, 0, st>>>(
+      upfirdn2d_blur4_tile<false, false><<<(unsigned)ntiles, 256, 0, st>>>(
           reinterpret_cast<float*>(out), reinterpret_cast<const float*>(in), reinterpret_cast<const float*>(kernel),
-          major, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, (unsigned)ntiles);
+          major, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, (unsigned)ntiles, BlurFuse{});
       return gg::launch_status("upfirdn2d_blur4_tile");
     }
   }
@@ -163,6 +194,37 @@ extern "C" int gg_upfirdn2d_f32(float* out, const float* in, const float* kernel
                                 int pad_x1, int pad_y0, int pad_y1, void* stream) {
   return upfirdn2d_impl<float>(out, in, kernel, major, in_h, in_w, kernel_h, kernel_w, up_x, up_y, down_x, down_y,
                                pad_x0, pad_x1, pad_y0, pad_y1, stream);
+}
+extern "C" int gg_blur4_fused_f32(float* out, const float* in, const float* kernel, int n, int c, int in_h, int in_w,
+                                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise,
+                                  const float* noise_weight, const float* act_bias, const float* ref, float alpha,
+                                  float gain, void* stream) {
+  const int out_h = in_h + pad_y0 + pad_y1 - 3, out_w = in_w + pad_x0 + pad_x1 - 3;
+  if (n <= 0 || c <= 0 || out_h <= 0 || out_w <= 0) return 0;
+  if (!out || !in || !kernel) return gg::fail(-2, "blur4_fused: null pointer");
+  const bool epi = noise != nullptr, pro = ref != nullptr;
+  if (epi && (!noise_weight || !act_bias)) return gg::fail(-2, "blur4_fused: noise weight / bias missing");
+  if (epi && pro) return gg::fail(-2, "blur4_fused: epilogue and prologue are exclusive");
+  const int tiles_x = (out_w + TILE - 1) / TILE, tiles_y = (out_h + TILE - 1) / TILE;
+  const long long ntiles = (long long)tiles_x * tiles_y * n * c;
+  if (ntiles >= (1LL << 31)) return gg::fail(-2, "blur4_fused: too many tiles");
+  BlurFuse f;
+  f.noise = noise; f.noise_w = noise_weight; f.bias = act_bias; f.ref = ref; f.alpha = alpha; f.gain = gain;
+  f.channels = c;
+  hipStream_t st = gg::as_stream(stream);
+  if (epi)
+    upfirdn2d_blur4_tile<true, false><<<(unsigned)ntiles, 256, 0, st>>>(out, in, kernel, n * c, in_h, in_w, out_h,
+                                                                         out_w, pad_x0, pad_y0, tiles_x, tiles_y,
+                                                                         (unsigned)ntiles, f);
+  else if (pro)
+    upfirdn2d_blur4_tile<false, true><<<(unsigned)ntiles, 256, 0, st>>>(out, in, kernel, n * c, in_h, in_w, out_h,
+                                                                         out_w, pad_x0, pad_y0, tiles_x, tiles_y,
+                                                                         (unsigned)ntiles, f);
+  else
+    upfirdn2d_blur4_tile<false, false><<<(unsigned)ntiles, 256, 0, st>>>(out, in, kernel, n * c, in_h, in_w, out_h,
+                                                                          out_w, pad_x0, pad_y0, tiles_x, tiles_y,
+                                                                          (unsigned)ntiles, f);
+  return gg::launch_status("blur4_fused");
 }
 extern "C" int gg_upfirdn2d_f64(double* out, const double* in, const double* kernel, int major, int in_h, int in_w,
                                 int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0,

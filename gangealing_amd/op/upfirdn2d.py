@@ -63,3 +63,48 @@ def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     if input.device.type != 'cuda':
         raise _lib.HipLibraryError('upfirdn2d: HIP tensors only (the CPU restatement is oracle/np_ops.upfirdn2d)')
     return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+
+
+class _BlurNoiseAct(Function):
+    """lrelu(blur4x4(x) + noise_weight * noise + bias) * scale in one kernel, and its backward (the adjoint blur
+    of the leaky-ReLU-masked gradient) in one kernel - the tail of the generator's up-sampling StyledConv
+    (networks.py:268-298, 344-350) when noise weight and bias are frozen."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, pad, noise, noise_weight, bias, negative_slope, scale):
+        x = x.contiguous()
+        kernel = kernel.to(x.dtype).contiguous()
+        n, c, in_h, in_w = x.shape
+        p0, p1 = pad
+        out = torch.empty((n, c, in_h + p0 + p1 - 3, in_w + p0 + p1 - 3), dtype=x.dtype, device=x.device)
+        _lib.call('gg_blur4_fused_f32', out, x, kernel, n, c, in_h, in_w, p0, p1, p0, p1, noise.contiguous(),
+                  noise_weight.contiguous(), bias.contiguous(), None, negative_slope, scale)
+        ctx.save_for_backward(kernel, out)
+        # adjoint padding (reference upfirdn2d.py:113-118 with up = down = 1)
+        ctx.g_pad = (4 - p0 - 1, in_w - out.shape[3] + p0)
+        ctx.conf = (negative_slope, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        kernel, out = ctx.saved_tensors
+        negative_slope, scale = ctx.conf
+        grad_output = grad_output.contiguous()
+        n, c, h, w = grad_output.shape
+        g0, g1 = ctx.g_pad
+        dx = torch.empty((n, c, h + g0 + g1 - 3, w + g0 + g1 - 3), dtype=grad_output.dtype, device=grad_output.device)
+        _lib.call('gg_blur4_fused_f32', dx, grad_output, torch.flip(kernel, [0, 1]).contiguous(), n, c, h, w,
+                  g0, g1, g0, g1, None, None, None, out, negative_slope, scale)
+        return dx, None, None, None, None, None, None, None
+
+
+def blur_noise_act_ok(x, kernel, pad):
+    """Shapes the fused 4x4-blur kernel takes (the 64x64-tile kernel of csrc/upfirdn2d.hip)."""
+    return (x.dtype == torch.float32 and tuple(kernel.shape) == (4, 4) and
+            x.shape[-2] + pad[0] + pad[1] - 3 >= 24 and x.shape[-1] + pad[0] + pad[1] - 3 >= 24)
+
+
+def blur_noise_act(x, kernel, pad, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):
+    if noise_weight.requires_grad or bias.requires_grad:
+        raise NotImplementedError('blur_noise_act: noise weight / bias gradients are not produced (frozen generator)')
+    return _BlurNoiseAct.apply(x, kernel, (int(pad[0]), int(pad[1])), noise, noise_weight, bias, negative_slope, scale)

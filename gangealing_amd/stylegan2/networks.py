@@ -23,6 +23,7 @@ from torch.nn import functional as F
 
 from ..op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from ..op.fused_act import noise_bias_leaky_relu
+from ..op.upfirdn2d import blur_noise_act, blur_noise_act_ok
 from ..op import conv_mfma
 
 
@@ -174,6 +175,12 @@ class ModulatedConv2d(nn.Module):
         FusedLeakyReLU into the convolution (callers check `can_fuse_act` first)."""
         style = self.modulation(style)                                  # (N, Cin)
         wmat_fwd, wmat_bwd, wsq = self._weights()
+        if self.upsample and act is not None:
+            # up-sampling layer: the activation follows the blur, so it rides in the blur kernel instead
+            out = conv_mfma.modulated_conv2d(input, style, wmat_fwd, wmat_bwd, wsq, self.kernel_size,
+                                             upsample=True, demodulate=self.demodulate)
+            noise, noise_weight, bias, negative_slope, scale = act
+            return blur_noise_act(out, self.blur.kernel, self.blur.pad, noise, noise_weight, bias, negative_slope, scale)
         out = conv_mfma.modulated_conv2d(input, style, wmat_fwd, wmat_bwd, wsq, self.kernel_size,
                                          upsample=self.upsample, demodulate=self.demodulate, act=act)
         if self.upsample:
@@ -183,9 +190,13 @@ class ModulatedConv2d(nn.Module):
     def can_fuse_act(self, input, style, *frozen):
         """The one-kernel StyledConv applies to 3x3 layers without upsampling when neither the style (i.e. the
         latent and the modulation layer) nor the activation parameters need a gradient."""
-        if self.upsample or self.kernel_size != 3 or input.dtype != torch.float32:
+        if self.kernel_size != 3 or input.dtype != torch.float32:
             return False
-        if (input.shape[-1] * input.shape[-2]) % 4:
+        if self.upsample:
+            h, w = 2 * input.shape[-2] + 1, 2 * input.shape[-1] + 1           # transposed-conv output
+            if not blur_noise_act_ok(input.new_empty((1, 1, h, w)), self.blur.kernel, self.blur.pad):
+                return False
+        elif (input.shape[-1] * input.shape[-2]) % 4:
             return False
         if torch.is_grad_enabled() and (style.requires_grad or self.modulation.weight.requires_grad or
                                         any(p.requires_grad for p in frozen)):
@@ -229,6 +240,8 @@ class StyledConv(nn.Module):
     def forward(self, input, style, noise=None):
         if self.conv.can_fuse_act(input, style, self.noise.weight, self.activate.bias):
             n, _, h, w = input.shape
+            if self.conv.upsample:
+                h, w = 2 * h, 2 * w
             if noise is None:
                 noise = input.new_empty(n, 1, h, w).normal_()
             elif noise.shape[0] != n:

@@ -74,6 +74,16 @@ int gg_upfirdn2d_f64(double* out, const double* in, const double* kernel,
                      int major, int in_h, int in_w, int kernel_h, int kernel_w,
                      int up_x, int up_y, int down_x, int down_y,
                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+/* 4x4 FIR blur (up = down = 1; upfirdn2d.py:147-158 with a 4x4 kernel) with the neighbouring element-wise
+ * stage of the generator's up-sampling StyledConv fused in (networks.py:268-298, 344-350):
+ *   noise != NULL: out = lrelu(blur(in) + noise_weight[0] * noise[n,0] + act_bias[c], alpha) * gain   (forward)
+ *   ref   != NULL: out = blur(in * (ref > 0 ? 1 : alpha) * gain)      (backward: `kernel` already flipped, the
+ *                  adjoint padding of upfirdn2d.py:113-118, ref = the saved forward output)
+ *   neither: the plain blur.  in (n,c,in_h,in_w), out (n,c,in_h+pad_y0+pad_y1-3, in_w+pad_x0+pad_x1-3). */
+int gg_blur4_fused_f32(float* out, const float* in, const float* kernel, int n, int c, int in_h, int in_w,
+                       int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise,
+                       const float* noise_weight, const float* act_bias, const float* ref, float alpha, float gain,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a11  splat2d.

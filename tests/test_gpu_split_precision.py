@@ -32,6 +32,8 @@ CASES = [
     (1, 96, 64, (33, 64), 3, 2, 1, 1, False),     # pad 1 (data gradient of a stride-2 conv) + output_padding
     (4, 32, 128, (128, 128), 3, 2, 0, 1, True),   # enough tiles for the 128-q (8-wave) variant
     (1, 256, 256, (16, 16), 3, 2, 0, 1, True),    # split-K + atomics
+    (2, 64, 96, (4, 4), 3, 2, 0, 1, True),        # 4-wide image: one tile covers the whole q-grid
+    (3, 64, 64, (7, 8), 3, 2, 1, 1, False),       # 8-wide, pad 1
 ]
 
 
@@ -102,21 +104,23 @@ def test_autograd_through_split_conv(cuda, precision):
 
 
 @pytest.mark.parametrize('mode_name', ['fp32', 'bf16x3', 'bf16x6'])
-@pytest.mark.parametrize('shape', [(2, 64, 96, 16), (1, 512, 512, 4), (4, 32, 128, 64), (16, 64, 128, 64)],
+@pytest.mark.parametrize('shape', [(2, 64, 96, 16, 0), (1, 512, 512, 4, 0), (4, 32, 128, 64, 0), (16, 64, 128, 64, 0),
+                                   (2, 64, 96, 16, 1), (3, 32, 64, 40, 1)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_styled_conv_fused_activation_matches_unfused(shape, mode_name, cuda, precision):
-    """One-kernel StyledConv (conv epilogue carries noise + bias + leaky ReLU) == conv, then noise_bias_act."""
+    """One-kernel StyledConv tail: the conv epilogue (or, on up-sampling layers, the blur kernel) carries noise +
+    bias + leaky ReLU, and the backward applies the leaky-ReLU mask while staging the adjoint blur's input."""
     from gangealing_amd.op.fused_act import noise_bias_leaky_relu
     from gangealing_amd.stylegan2.networks import StyledConv
-    n, cin, cout, res = shape
+    n, cin, cout, res, up = shape
     precision(mode_name)
     torch.manual_seed(7)
-    layer = StyledConv(cin, cout, 3, 32).to(cuda).requires_grad_(False)
+    layer = StyledConv(cin, cout, 3, 32, upsample=bool(up)).to(cuda).requires_grad_(False)
     layer.noise.weight.fill_(0.37)
     layer.activate.bias.copy_(torch.randn(cout, device=cuda) * 0.5)
     x = torch.randn(n, cin, res, res, device=cuda, requires_grad=True)
     style = torch.randn(n, 32, device=cuda)
-    noise = torch.randn(n, 1, res, res, device=cuda)
+    noise = torch.randn(n, 1, res * (2 if up else 1), res * (2 if up else 1), device=cuda)
     assert layer.conv.can_fuse_act(x, style, layer.noise.weight, layer.activate.bias)
     fused = layer(x, style, noise=noise)
     g = torch.randn_like(fused)
