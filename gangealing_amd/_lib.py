@@ -47,6 +47,7 @@ _PROTOS = {
     'gg_modconv3x3_act_f32': 'ppppqipppppffiiiiis',
     'gg_conv2d_wgrad_f32': 'pppiiiiiiiiifs',
     'gg_conv2d_wgrad_split_f32': 'pppiiiiiiiiifis',
+    'gg_style_demod_f32': 'pppqpppiiiifffs',
     'gg_plane_dot_f32': 'pppiqs',
     'gg_adam_ema_f32': 'pppppqffffiffs',
 }
@@ -87,9 +88,20 @@ def load():
     return lib
 
 
+class Strided:
+    """Marks a tensor whose strides are passed to the entry point explicitly (skips the contiguity check)."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+
 def _dev_ptr(t):
     if t is None:
         return None
+    if isinstance(t, Strided):
+        if t.tensor.device.type != 'cuda':
+            raise HipLibraryError('gangealing_amd operators run on HIP devices only')
+        return ctypes.c_void_p(t.tensor.data_ptr())
     if not isinstance(t, torch.Tensor):
         raise TypeError(f'expected a tensor or None, got {type(t)}')
     if t.device.type != 'cuda':

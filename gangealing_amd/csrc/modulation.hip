@@ -1,0 +1,84 @@
+// Style modulation of one ModulatedConv2d layer in one C call (reference models/stylegan2/networks.py:214-216
+// EqualLinear, :244-249 style/demodulation):
+//   style[n,ci] = sum_k latent[n,k] * W[ci,k] * w_scale + b[ci] * b_scale          (EqualLinear)
+//   demod[n,co] = rsqrt(sum_ci style[n,ci]^2 * wsq[co,ci] + eps),  wsq[co,ci] = sum_taps (scale*Wconv)^2
+// The shared-weight form of the modulated convolution (csrc/conv_mfma.hip) needs exactly these two small
+// per-sample vectors; as separate torch ops they were seven ~5 us launches per layer and per generator pass.
+// Two launches of one row-dot kernel (style, then demod): a wave owns one weight row, keeps it in registers and
+// dots it with every sample of the batch (staged in LDS), so each weight matrix is read once per launch.
+#include "../../include/gangealing_hip.h"
+#include "gg_common.h"
+
+namespace {
+
+constexpr int LDS_FLOATS = 16384;      // batch chunk x reduction length staged per block
+constexpr int MAX_DIM = 2048;          // reduction length (32 row elements per lane)
+
+// out[n, r] = f(scale * sum_k g(in[n*in_stride + k]) * m[r, k] + bias[r] * bias_scale)
+//   SQUARE: g(v) = v*v else v;  RSQRT: f(v) = rsqrt(v + eps) else v
+template <bool SQUARE, bool RSQRT>
+__global__ __launch_bounds__(256) void rowdot_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                     long long in_stride, const float* __restrict__ m,
+                                                     const float* __restrict__ bias, int n_total, int nb, int kdim,
+                                                     int rows, float scale, float bias_scale, float eps) {
+  __shared__ float sin[LDS_FLOATS];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n0 = blockIdx.y * nb;
+  const int ncount = min(nb, n_total - n0);
+  for (int i = threadIdx.x; i < ncount * kdim; i += 256) {
+    const int n = i / kdim, k = i - n * kdim;
+    const float v = in[(size_t)(n0 + n) * in_stride + k];
+    sin[i] = SQUARE ? v * v : v;
+  }
+  __syncthreads();
+  const int r = blockIdx.x * 4 + wid;
+  if (r >= rows) return;
+  const float* row = m + (size_t)r * kdim;
+  // this lane's slice of the row: k = lane + 64 * j
+  float wreg[MAX_DIM / 64];
+#pragma unroll
+  for (int j = 0; j < MAX_DIM / 64; ++j) {
+    const int k = lane + 64 * j;
+    wreg[j] = k < kdim ? row[k] : 0.f;
+  }
+  const float bb = bias ? bias[r] * bias_scale : 0.f;
+  for (int n = 0; n < ncount; ++n) {
+    const float* x = sin + n * kdim;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_DIM / 64; ++j) {
+      const int k = lane + 64 * j;
+      if (k < kdim) acc += x[k] * wreg[j];
+    }
+    acc = gg::wave_sum(acc);
+    if (lane == 0) {
+      const float v = acc * scale + bb;
+      out[(size_t)(n0 + n) * rows + r] = RSQRT ? rsqrtf(v + eps) : v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int gg_style_demod_f32(float* style, float* demod, const float* latent, long long lat_stride,
+                                  const float* w, const float* b, const float* wsq, int n, int style_dim, int cin,
+                                  int cout, float w_scale, float b_scale, float eps, void* stream) {
+  if (n <= 0 || cin <= 0) return 0;
+  if (!style || !latent || !w) return gg::fail(-2, "style_demod: null pointer");
+  if (demod && (!wsq || cout <= 0)) return gg::fail(-2, "style_demod: demodulation needs wsq and cout");
+  if (style_dim <= 0 || style_dim > MAX_DIM || cin > MAX_DIM)
+    return gg::fail(-2, "style_demod: style_dim and cin must be in [1, %d]", MAX_DIM);
+  hipStream_t st = gg::as_stream(stream);
+  {
+    const int nb = LDS_FLOATS / style_dim < n ? LDS_FLOATS / style_dim : n;
+    dim3 grid((unsigned)((cin + 3) / 4), (unsigned)((n + nb - 1) / nb));
+    rowdot_kernel<false, false><<<grid, 256, 0, st>>>(style, latent, lat_stride, w, b, n, nb, style_dim, cin, w_scale,
+                                                     b_scale, 0.f);
+    const int rc = gg::launch_status("style_demod (style)");
+    if (rc || !demod) return rc;
+  }
+  const int nb = LDS_FLOATS / cin < n ? LDS_FLOATS / cin : n;
+  dim3 grid((unsigned)((cout + 3) / 4), (unsigned)((n + nb - 1) / nb));
+  rowdot_kernel<true, true><<<grid, 256, 0, st>>>(demod, style, cin, wsq, nullptr, n, nb, cin, cout, 1.f, 0.f, eps);
+  return gg::launch_status("style_demod (demod)");
+}

@@ -282,14 +282,14 @@ class _ModulatedConv(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate):
+    def forward(ctx, x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate, demod_pre=None):
         x = x.contiguous()
         style = style.contiguous()
         n, cin, h, w = x.shape
         cout = wmat_fwd.cout_g
         demod = None
         if demodulate:
-            demod = torch.rsqrt((style * style) @ wsq.t() + 1e-8)
+            demod = demod_pre if demod_pre is not None else torch.rsqrt((style * style) @ wsq.t() + 1e-8)
         if upsample:
             y = conv_forward(x, wmat_fwd, n, 1, cin, cout, k, 2, 0, 1, in_scale=style, out_scale=demod)
         else:
@@ -330,7 +330,7 @@ class _ModulatedConv(Function):
                 dx = dxt * style.view(n, cin, 1, 1) if ctx.needs_input_grad[0] else None
             else:
                 dx = dxt
-        return dx, dstyle, None, None, None, None, None, None
+        return dx, dstyle, None, None, None, None, None, None, None
 
 
 class _ModulatedConvAct(Function):
@@ -340,12 +340,15 @@ class _ModulatedConvAct(Function):
     (sign reference = the saved OUTPUT, as in fused_act.py:27-38) followed by the data gradient."""
 
     @staticmethod
-    def forward(ctx, x, style, wmat_fwd, wmat_bwd, wsq, demodulate, noise, noise_weight, act_bias, alpha, gain):
+    def forward(ctx, x, style, wmat_fwd, wmat_bwd, wsq, demodulate, noise, noise_weight, act_bias, alpha, gain,
+                demod_pre=None):
         x = x.contiguous()
         style = style.contiguous()
         n, cin, h, w = x.shape
         cout = wmat_fwd.cout_g
-        demod = torch.rsqrt((style * style) @ wsq.t() + 1e-8) if demodulate else None
+        demod = None
+        if demodulate:
+            demod = demod_pre if demod_pre is not None else torch.rsqrt((style * style) @ wsq.t() + 1e-8)
         y = conv_forward(x, wmat_fwd, n, 1, cin, cout, 3, 1, 1, 0, in_scale=style, out_scale=demod,
                          act=(noise.contiguous(), noise_weight.contiguous(), act_bias.contiguous(), alpha, gain))
         ctx.save_for_backward(style, demod if demod is not None else style.new_empty(0), y)
@@ -358,23 +361,42 @@ class _ModulatedConvAct(Function):
         style, demod, y = ctx.saved_tensors
         demodulate, alpha, gain, cin = ctx.conf
         if not ctx.needs_input_grad[0]:
-            return (None,) * 11
+            return (None,) * 12
         dy = dy.contiguous()
         n, cout, h, w = y.shape
         g = torch.empty_like(dy)
         _lib.call('gg_fused_lrelu_bwd_f32', g, None, dy, y, alpha, gain, n, cout, h * w)
         dx = conv_forward(g, ctx.wmat_bwd, n, 1, cout, cin, 3, 1, 1, 0, in_scale=demod if demodulate else None,
                           out_scale=style)
-        return (dx,) + (None,) * 10
+        return (dx,) + (None,) * 11
 
 
-def modulated_conv2d(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample=False, demodulate=True, act=None):
+def style_demod(latent, weight, bias, w_scale, b_scale, wsq=None, eps=1e-8):
+    """(style, demod) of one modulated layer from its W+ slot in a single launch (gg_style_demod_f32):
+    style = EqualLinear(latent) (networks.py:214-216), demod = rsqrt(style^2 @ wsq^T + eps) (:244-249; None when
+    wsq is None).  No autograd: for layers whose latent / modulation weights need no gradient."""
+    if latent.dim() != 2 or latent.stride(1) != 1:
+        latent = latent.contiguous()
+    n, style_dim = latent.shape
+    cin = weight.shape[0]
+    style = torch.empty((n, cin), dtype=torch.float32, device=latent.device)
+    demod = None
+    cout = 0
+    if wsq is not None:
+        cout = wsq.shape[0]
+        demod = torch.empty((n, cout), dtype=torch.float32, device=latent.device)
+    _lib.call('gg_style_demod_f32', style, demod, _lib.Strided(latent), latent.stride(0), weight.contiguous(),
+              None if bias is None else bias.contiguous(), wsq, n, style_dim, cin, cout, w_scale, b_scale, eps)
+    return style, demod
+
+
+def modulated_conv2d(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample=False, demodulate=True, act=None, demod=None):
     """act = (noise, noise_weight, act_bias, alpha, gain) fuses the StyledConv tail (3x3, no upsampling, and no
-    gradient wanted for style / noise weight / bias)."""
+    gradient wanted for style / noise weight / bias).  demod: precomputed demodulation (style_demod)."""
     if act is not None:
         noise, noise_weight, act_bias, alpha, gain = act
         if k != 3 or upsample or style.requires_grad or noise_weight.requires_grad or act_bias.requires_grad:
             raise NotImplementedError('modulated_conv2d: fused activation not applicable to this layer')
         return _ModulatedConvAct.apply(x, style, wmat_fwd, wmat_bwd, wsq, demodulate, noise, noise_weight, act_bias,
-                                       alpha, gain)
-    return _ModulatedConv.apply(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate)
+                                       alpha, gain, demod)
+    return _ModulatedConv.apply(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate, demod)

@@ -173,16 +173,25 @@ class ModulatedConv2d(nn.Module):
     def forward(self, input, style, act=None):
         """act = (noise, noise_weight, bias, negative_slope, scale): fuse StyledConv's NoiseInjection +
         FusedLeakyReLU into the convolution (callers check `can_fuse_act` first)."""
-        style = self.modulation(style)                                  # (N, Cin)
         wmat_fwd, wmat_bwd, wsq = self._weights()
+        mod = self.modulation
+        demod = None
+        if (input.dtype == torch.float32 and style.dtype == torch.float32 and mod.activation is None and
+                not (torch.is_grad_enabled() and (style.requires_grad or mod.weight.requires_grad or
+                                                  (mod.bias is not None and mod.bias.requires_grad)))):
+            # no gradient wanted for the style: EqualLinear + demodulation in one launch (csrc/modulation.hip)
+            style, demod = conv_mfma.style_demod(style, mod.weight, mod.bias, mod.scale, mod.lr_mul,
+                                                 wsq if self.demodulate else None, self.eps)
+        else:
+            style = mod(style)                                          # (N, Cin)
         if self.upsample and act is not None:
             # up-sampling layer: the activation follows the blur, so it rides in the blur kernel instead
             out = conv_mfma.modulated_conv2d(input, style, wmat_fwd, wmat_bwd, wsq, self.kernel_size,
-                                             upsample=True, demodulate=self.demodulate)
+                                             upsample=True, demodulate=self.demodulate, demod=demod)
             noise, noise_weight, bias, negative_slope, scale = act
             return blur_noise_act(out, self.blur.kernel, self.blur.pad, noise, noise_weight, bias, negative_slope, scale)
         out = conv_mfma.modulated_conv2d(input, style, wmat_fwd, wmat_bwd, wsq, self.kernel_size,
-                                         upsample=self.upsample, demodulate=self.demodulate, act=act)
+                                         upsample=self.upsample, demodulate=self.demodulate, act=act, demod=demod)
         if self.upsample:
             out = self.blur(out)
         return out

@@ -244,6 +244,13 @@ int gg_conv2d_wgrad_f32(float* dw, const float* x, const float* dy, int batch, i
 int gg_conv2d_wgrad_split_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g,
                               int cout_g, int h, int w, int ksize, int stride, int pad, float scale, int limbs,
                               void* stream);
+/* Style modulation of one ModulatedConv2d layer in one launch (networks.py:214-216 EqualLinear + :244-249):
+ *   style[n,ci] = sum_k latent[n*lat_stride + k] * w[ci,k] * w_scale + b[ci] * b_scale      (b may be NULL)
+ *   demod[n,co] = rsqrt(sum_ci style[n,ci]^2 * wsq[co,ci] + eps)                             (demod may be NULL)
+ * wsq (cout, cin) = sum over taps of (conv weight * scale)^2.  style_dim, cin <= 2048. */
+int gg_style_demod_f32(float* style, float* demod, const float* latent, long long lat_stride, const float* w,
+                       const float* b, const float* wsq, int n, int style_dim, int cin, int cout, float w_scale,
+                       float b_scale, float eps, void* stream);
 /* Per-(n,c) dot products over the spatial plane: out[n*c] = sum_hw a*b (style / demod gradients). */
 int gg_plane_dot_f32(float* out, const float* a, const float* b, int planes, long long hw, void* stream);
 

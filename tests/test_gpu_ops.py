@@ -302,3 +302,24 @@ def test_modulated_conv_golden(case, cuda):
     out.backward(T(case['g'], cuda))
     close(x.grad, case['gx'], TOL)
     close(w.grad, case['gw'], 2e-4, 2e-4)
+
+
+@pytest.mark.parametrize('n,style_dim,cin,cout', [(16, 512, 512, 512), (3, 512, 128, 3), (5, 96, 70, 33)])
+def test_style_demod_matches_torch_ops(n, style_dim, cin, cout, cuda):
+    """EqualLinear modulation + demodulation in one launch == the reference's op sequence (networks.py:214-249)."""
+    from gangealing_amd.op.conv_mfma import style_demod
+    g = torch.Generator(device='cpu').manual_seed(5)
+    wplus = torch.randn(n, 4, style_dim, generator=g).to(cuda)
+    latent = wplus[:, 2]                                          # a strided W+ slot
+    w = torch.randn(cin, style_dim, generator=g).to(cuda)
+    b = torch.randn(cin, generator=g).to(cuda)
+    wsq = torch.rand(cout, cin, generator=g).to(cuda)
+    scale, lr_mul = style_dim ** -0.5, 1.0
+    style, demod = style_demod(latent, w, b, scale, lr_mul, wsq, 1e-8)
+    ref_style = torch.nn.functional.linear(latent.double(), w.double() * scale, b.double() * lr_mul)
+    ref_demod = torch.rsqrt((ref_style * ref_style) @ wsq.double().t() + 1e-8)
+    np.testing.assert_allclose(style.cpu().numpy(), ref_style.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(demod.cpu().numpy(), ref_demod.cpu().numpy(), rtol=2e-5, atol=1e-7)
+    style_only, none = style_demod(latent, w, None, scale, lr_mul)
+    assert none is None
+    np.testing.assert_allclose(style_only.cpu().numpy(), (ref_style - b.double() * lr_mul).cpu().numpy(), rtol=2e-5, atol=2e-5)
