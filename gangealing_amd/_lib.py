@@ -47,6 +47,7 @@ _PROTOS = {
     'gg_modconv3x3_act_f32': 'ppppqipppppffiiiiis',
     'gg_conv2d_wgrad_f32': 'pppiiiiiiiiifs',
     'gg_conv2d_wgrad_split_f32': 'pppiiiiiiiiifis',
+    'gg_conv2d_wgrad_acc_f32': 'pppiiiiiiiiifis',
     'gg_style_demod_f32': 'pppqpppiiiifffs',
     'gg_plane_dot_f32': 'pppiqs',
     'gg_adam_ema_f32': 'pppppqffffiffs',

@@ -1789,7 +1789,7 @@ extern "C" int gg_conv_pack_weight_split(unsigned short* wsplit, const float* w,
 
 namespace {
 int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g, int cout_g, int h,
-                int w, int ksize, int stride, int pad, float scale, int limbs, void* stream) {
+                int w, int ksize, int stride, int pad, float scale, int limbs, void* stream, bool accumulate = false) {
   if (groups <= 0 || cin_g <= 0 || cout_g <= 0) return 0;
   if (!dw || !x || !dy) return gg::fail(-2, "conv2d_wgrad: null pointer");
   if (ksize != 1 && ksize != 3) return gg::fail(-2, "conv2d_wgrad: kernel size must be 1 or 3");
@@ -1802,8 +1802,10 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
   a.ow = (w + 2 * pad - ksize) / stride + 1;
   a.stride = stride; a.pad = pad; a.scale = scale;
   a.jtot = cin_g * ksize * ksize;
-  hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)groups * cout_g * a.jtot, st);
-  if (e != hipSuccess) return gg::fail((int)e, "conv2d_wgrad: memset failed");
+  if (!accumulate) {        // the kernels combine their K-splits with atomic adds: start from zero unless asked to add
+    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)groups * cout_g * a.jtot, st);
+    if (e != hipSuccess) return gg::fail((int)e, "conv2d_wgrad: memset failed");
+  }
   if (batch <= 0 || a.oh <= 0 || a.ow <= 0) return 0;
   if (limbs) {
     if (limbs != 2 && limbs != 3) return gg::fail(-2, "conv2d_wgrad_split: limbs must be 2 or 3");
@@ -1852,9 +1854,41 @@ extern "C" int gg_conv2d_wgrad_split_f32(float* dw, const float* x, const float*
   return wgrad_entry(dw, x, dy, batch, groups, cin_g, cout_g, h, w, ksize, stride, pad, scale, limbs, stream);
 }
 
+extern "C" int gg_conv2d_wgrad_acc_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g,
+                                       int cout_g, int h, int w, int ksize, int stride, int pad, float scale,
+                                       int limbs, void* stream) {
+  return wgrad_entry(dw, x, dy, batch, groups, cin_g, cout_g, h, w, ksize, stride, pad, scale, limbs, stream, true);
+}
+
 extern "C" int gg_plane_dot_f32(float* out, const float* a, const float* b, int planes, long long hw, void* stream) {
   if (planes <= 0) return 0;
   if (!out || !a || !b || hw < 0) return gg::fail(-2, "plane_dot: bad arguments");
   plane_dot_kernel<<<planes, 256, 0, gg::as_stream(stream)>>>(out, a, b, hw);
   return gg::launch_status("plane_dot");
+}
+
+// Diagnostic: resident workgroups per CU of the main convolution kernels on the current device, as
+// "name=blocks;..." (what hipOccupancyMaxActiveBlocksPerMultiprocessor reports).
+extern "C" int gg_debug_conv_occupancy(char* out, int out_len) {
+  if (!out || out_len <= 0) return gg::fail(-2, "debug_conv_occupancy: no buffer");
+  struct Entry { const char* name; const void* fn; int threads; };
+  const Entry entries[] = {
+      {"conv3x3_patch<2,true,256>", reinterpret_cast<const void*>(&conv3x3_patch_kernel<2, true, 256>), 512},
+      {"conv3x3_patch<2,false,128>", reinterpret_cast<const void*>(&conv3x3_patch_kernel<2, false, 128>), 256},
+      {"conv3x3_patch<3,true,128>", reinterpret_cast<const void*>(&conv3x3_patch_kernel<3, true, 128>), 256},
+      {"convT3x3s2_patch<2,true,128>", reinterpret_cast<const void*>(&convT3x3s2_patch_kernel<2, true, 128>), 512},
+      {"convT3x3s2_patch<2,true,64>", reinterpret_cast<const void*>(&convT3x3s2_patch_kernel<2, true, 64>), 256},
+      {"conv_split<3,0,2,true,256>", reinterpret_cast<const void*>(&conv_split_kernel<3, 0, 2, true, 256>), 512},
+      {"conv_split<3,0,2,false,128>", reinterpret_cast<const void*>(&conv_split_kernel<3, 0, 2, false, 128>), 256},
+      {"conv_wgrad_split<3,2>", reinterpret_cast<const void*>(&conv_wgrad_split_kernel<3, 2>), 256},
+      {"conv_igemm<3,0,2,2,2,2,true>", reinterpret_cast<const void*>(&conv_igemm_kernel<3, 0, 2, 2, 2, 2, true>), 256},
+  };
+  int pos = 0;
+  for (const Entry& e : entries) {
+    int blocks = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, e.fn, e.threads, 0) != hipSuccess) blocks = -1;
+    pos += snprintf(out + pos, pos < out_len ? out_len - pos : 0, "%s=%d;", e.name, blocks);
+    if (pos >= out_len) break;
+  }
+  return 0;
 }

@@ -16,7 +16,7 @@ constexpr int MAX_DIM = 2048;          // reduction length (32 row elements per 
 
 // out[n, r] = f(scale * sum_k g(in[n*in_stride + k]) * m[r, k] + bias[r] * bias_scale)
 //   SQUARE: g(v) = v*v else v;  RSQRT: f(v) = rsqrt(v + eps) else v
-template <bool SQUARE, bool RSQRT>
+template <bool SQUARE, bool RSQRT, int KPL>      // KPL: row elements per lane (reduction length <= 64 * KPL)
 __global__ __launch_bounds__(256) void rowdot_kernel(float* __restrict__ out, const float* __restrict__ in,
                                                      long long in_stride, const float* __restrict__ m,
                                                      const float* __restrict__ bias, int n_total, int nb, int kdim,
@@ -25,30 +25,32 @@ __global__ __launch_bounds__(256) void rowdot_kernel(float* __restrict__ out, co
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n0 = blockIdx.y * nb;
   const int ncount = min(nb, n_total - n0);
-  for (int i = threadIdx.x; i < ncount * kdim; i += 256) {
-    const int n = i / kdim, k = i - n * kdim;
-    const float v = in[(size_t)(n0 + n) * in_stride + k];
-    sin[i] = SQUARE ? v * v : v;
-  }
-  __syncthreads();
+  // the weight row first (longest latency), then the batch chunk
   const int r = blockIdx.x * 4 + wid;
-  if (r >= rows) return;
-  const float* row = m + (size_t)r * kdim;
-  // this lane's slice of the row: k = lane + 64 * j
-  float wreg[MAX_DIM / 64];
+  const float* row = m + (size_t)(r < rows ? r : 0) * kdim;
+  float wreg[KPL];
 #pragma unroll
-  for (int j = 0; j < MAX_DIM / 64; ++j) {
+  for (int j = 0; j < KPL; ++j) {
     const int k = lane + 64 * j;
     wreg[j] = k < kdim ? row[k] : 0.f;
   }
+  for (int n = 0; n < ncount; ++n) {
+    const float* src = in + (size_t)(n0 + n) * in_stride;
+    for (int k = threadIdx.x; k < kdim; k += 256) {
+      const float v = src[k];
+      sin[n * kdim + k] = SQUARE ? v * v : v;
+    }
+  }
+  __syncthreads();
+  if (r >= rows) return;
   const float bb = bias ? bias[r] * bias_scale : 0.f;
   for (int n = 0; n < ncount; ++n) {
     const float* x = sin + n * kdim;
     float acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < MAX_DIM / 64; ++j) {
+    for (int j = 0; j < KPL; ++j) {
       const int k = lane + 64 * j;
-      if (k < kdim) acc += x[k] * wreg[j];
+      acc += (k < kdim ? x[k] : 0.f) * wreg[j];
     }
     acc = gg::wave_sum(acc);
     if (lane == 0) {
@@ -56,6 +58,20 @@ __global__ __launch_bounds__(256) void rowdot_kernel(float* __restrict__ out, co
       out[(size_t)(n0 + n) * rows + r] = RSQRT ? rsqrtf(v + eps) : v;
     }
   }
+}
+
+template <bool SQUARE, bool RSQRT>
+void launch_rowdot(dim3 grid, hipStream_t st, float* out, const float* in, long long in_stride, const float* m,
+                   const float* bias, int n, int nb, int kdim, int rows, float scale, float bias_scale, float eps) {
+  if (kdim <= 512)
+    rowdot_kernel<SQUARE, RSQRT, 8><<<grid, 256, 0, st>>>(out, in, in_stride, m, bias, n, nb, kdim, rows, scale,
+                                                          bias_scale, eps);
+  else if (kdim <= 1024)
+    rowdot_kernel<SQUARE, RSQRT, 16><<<grid, 256, 0, st>>>(out, in, in_stride, m, bias, n, nb, kdim, rows, scale,
+                                                           bias_scale, eps);
+  else
+    rowdot_kernel<SQUARE, RSQRT, 32><<<grid, 256, 0, st>>>(out, in, in_stride, m, bias, n, nb, kdim, rows, scale,
+                                                           bias_scale, eps);
 }
 
 }  // namespace
@@ -72,13 +88,12 @@ extern "C" int gg_style_demod_f32(float* style, float* demod, const float* laten
   {
     const int nb = LDS_FLOATS / style_dim < n ? LDS_FLOATS / style_dim : n;
     dim3 grid((unsigned)((cin + 3) / 4), (unsigned)((n + nb - 1) / nb));
-    rowdot_kernel<false, false><<<grid, 256, 0, st>>>(style, latent, lat_stride, w, b, n, nb, style_dim, cin, w_scale,
-                                                     b_scale, 0.f);
+    launch_rowdot<false, false>(grid, st, style, latent, lat_stride, w, b, n, nb, style_dim, cin, w_scale, b_scale, 0.f);
     const int rc = gg::launch_status("style_demod (style)");
     if (rc || !demod) return rc;
   }
   const int nb = LDS_FLOATS / cin < n ? LDS_FLOATS / cin : n;
   dim3 grid((unsigned)((cout + 3) / 4), (unsigned)((n + nb - 1) / nb));
-  rowdot_kernel<true, true><<<grid, 256, 0, st>>>(demod, style, cin, wsq, nullptr, n, nb, cin, cout, 1.f, 0.f, eps);
+  launch_rowdot<true, true>(grid, st, demod, style, cin, wsq, nullptr, n, nb, cin, cout, 1.f, 0.f, eps);
   return gg::launch_status("style_demod (demod)");
 }

@@ -4,6 +4,8 @@ conv2d / conv_transpose2d here are what op/conv2d_gradfix.py exposes under the r
 names; `modulated_conv2d` is the shared-weight form of ModulatedConv2d.forward
 (models/stylegan2/networks.py:233-282) used by our generator.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -160,13 +162,29 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
     return y
 
 
-def conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, pad, scale=1.0):
-    """-> (groups*cout_g, cin_g, k, k) gradient of a mode-0 convolution's weight."""
-    dw = torch.empty((groups * cout_g, cin_g, k, k), dtype=torch.float32, device=x.device)
+# Gradient slots: weight storage address -> the tensor its gradient is ACCUMULATED into (a view of the trainer's
+# flat, zero-initialised gradient arena; train_step.FlatArena registers them).  For a registered weight the
+# backward adds the weight gradient straight into the slot (gg_conv2d_wgrad_acc_f32) and hands autograd no
+# gradient: no per-layer memset, no temporary and no AccumulateGrad add - two tiny launches less per layer.
+GRAD_SLOTS = {}
+# developer A/B switches (comma separated names in GG_DISABLE): slots, style_demod, fuse_act
+DISABLED = frozenset(filter(None, os.environ.get('GG_DISABLE', '').split(',')))
+
+
+def conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, pad, scale=1.0, into=None):
+    """-> (groups*cout_g, cin_g, k, k) gradient of a mode-0 convolution's weight; `into`: add it to this tensor
+    instead (returns None)."""
     h, w = x.shape[-2], x.shape[-1]
     oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     limbs = _LIMBS[PRECISION]
-    if limbs and (oh * ow) % 32 == 0 and ow % 4 == 0 and cout_g >= 32 and cin_g * k * k >= 32 and dy.data_ptr() % 16 == 0:
+    split = bool(limbs and (oh * ow) % 32 == 0 and ow % 4 == 0 and cout_g >= 32 and cin_g * k * k >= 32
+                 and dy.data_ptr() % 16 == 0)
+    if into is not None:
+        _lib.call('gg_conv2d_wgrad_acc_f32', into, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale,
+                  limbs if split else 0)
+        return None
+    dw = torch.empty((groups * cout_g, cin_g, k, k), dtype=torch.float32, device=x.device)
+    if split:
         _lib.call('gg_conv2d_wgrad_split_f32', dw, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale,
                   limbs)
     else:
@@ -236,11 +254,14 @@ class _Conv2d(Function):
                     dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 0)
                     dx = dx[..., :h, :w].contiguous() if dx.shape[-2:] != (h, w) else dx
         if ctx.needs_input_grad[1]:
+            slot = GRAD_SLOTS.get(weight.data_ptr()) if (GRAD_SLOTS and 'slots' not in DISABLED) else None
+            if slot is not None and (slot.shape != weight.shape or not slot.is_contiguous()):
+                slot = None
             if not transposed:
-                dw = conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, padding, wscale)
+                dw = conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, padding, wscale, into=slot)
             else:
                 # dW[ci,co,ky,kx] = sum x[ci,i] * dy[co, i*s + k - p]: a mode-0 weight gradient with roles swapped
-                dw = conv_wgrad(dy, x, batch, groups, cout_g, cin_g, k, stride, padding, wscale)
+                dw = conv_wgrad(dy, x, batch, groups, cout_g, cin_g, k, stride, padding, wscale, into=slot)
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 2, 3))
         return dx, dw, db, None, None, None, None, None, None

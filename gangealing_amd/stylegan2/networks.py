@@ -176,7 +176,8 @@ class ModulatedConv2d(nn.Module):
         wmat_fwd, wmat_bwd, wsq = self._weights()
         mod = self.modulation
         demod = None
-        if (input.dtype == torch.float32 and style.dtype == torch.float32 and mod.activation is None and
+        if ('style_demod' not in conv_mfma.DISABLED and input.dtype == torch.float32 and style.dtype == torch.float32 and
+                mod.activation is None and
                 not (torch.is_grad_enabled() and (style.requires_grad or mod.weight.requires_grad or
                                                   (mod.bias is not None and mod.bias.requires_grad)))):
             # no gradient wanted for the style: EqualLinear + demodulation in one launch (csrc/modulation.hip)
@@ -199,7 +200,7 @@ class ModulatedConv2d(nn.Module):
     def can_fuse_act(self, input, style, *frozen):
         """The one-kernel StyledConv applies to 3x3 layers without upsampling when neither the style (i.e. the
         latent and the modulation layer) nor the activation parameters need a gradient."""
-        if self.kernel_size != 3 or input.dtype != torch.float32:
+        if self.kernel_size != 3 or input.dtype != torch.float32 or 'fuse_act' in conv_mfma.DISABLED:
             return False
         if self.upsample:
             h, w = 2 * input.shape[-2] + 1, 2 * input.shape[-1] + 1           # transposed-conv output

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .op import conv_mfma
 from . import distributed as gdist
 from .latent_learner import DirectionInterpolator
 from .losses import gangealing_loss, gangealing_cluster_loss, flow_losses, get_perceptual_loss
@@ -43,9 +44,25 @@ class FlatArena:
                 self.param[off:off + n].copy_(p.reshape(-1))
                 p.data = self.param[off:off + n].view(p.shape)
                 p.grad = self.grad[off:off + n].view(p.shape)
+                if p.dim() == 4:         # conv weights: the backward adds straight into the arena (conv_mfma.GRAD_SLOTS)
+                    conv_mfma.GRAD_SLOTS[p.data_ptr()] = p.grad
                 off += n
         self.params = params
         self.step_count = 0
+
+    def release(self):
+        """Forget the gradient slots of this arena (the registry would otherwise keep the arena alive)."""
+        for p in getattr(self, 'params', ()):
+            slot = conv_mfma.GRAD_SLOTS.get(p.data_ptr())
+            if slot is not None and slot.data_ptr() >= self.grad.data_ptr() and \
+                    slot.data_ptr() < self.grad.data_ptr() + 4 * self.numel:
+                del conv_mfma.GRAD_SLOTS[p.data_ptr()]
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:       # interpreter shutdown
+            pass
 
     def zero_grad(self):
         self.grad.zero_()
@@ -54,6 +71,8 @@ class FlatArena:
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + n].view(p.shape)
+                if p.dim() == 4:
+                    conv_mfma.GRAD_SLOTS[p.data_ptr()] = p.grad
             off += n
 
 

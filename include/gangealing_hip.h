@@ -244,6 +244,12 @@ int gg_conv2d_wgrad_f32(float* dw, const float* x, const float* dy, int batch, i
 int gg_conv2d_wgrad_split_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g,
                               int cout_g, int h, int w, int ksize, int stride, int pad, float scale, int limbs,
                               void* stream);
+/* dw += weight gradient (limbs = 0: fp32 MFMA kernel; 2|3: split precision, same preconditions as above).  The
+ * optimizer-facing form: the trainer keeps all gradients in one flat zero-initialised arena and every layer adds
+ * its weight gradient straight into its slice (no per-layer memset, no separate accumulation pass). */
+int gg_conv2d_wgrad_acc_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g,
+                            int cout_g, int h, int w, int ksize, int stride, int pad, float scale, int limbs,
+                            void* stream);
 /* Style modulation of one ModulatedConv2d layer in one launch (networks.py:214-216 EqualLinear + :244-249):
  *   style[n,ci] = sum_k latent[n*lat_stride + k] * w[ci,k] * w_scale + b[ci] * b_scale      (b may be NULL)
  *   demod[n,co] = rsqrt(sum_ci style[n,ci]^2 * wsq[co,ci] + eps)                             (demod may be NULL)
