@@ -48,6 +48,7 @@ _PROTOS = {
     'gg_conv2d_wgrad_f32': 'pppiiiiiiiiifs',
     'gg_conv2d_wgrad_split_f32': 'pppiiiiiiiiifis',
     'gg_conv2d_wgrad_acc_f32': 'pppiiiiiiiiifis',
+    'gg_conv2d_wgrad_ws_f32': 'pppiiiiiiiiifiipqs',
     'gg_style_demod_f32': 'pppqpppiiiifffs',
     'gg_plane_dot_f32': 'pppiqs',
     'gg_adam_ema_f32': 'pppppqffffiffs',

@@ -793,9 +793,12 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
 template <int LIMBS, bool IN_SCALE, int TQ>
 __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvArgs a, int tw_log2_in, int tiles_y,
                                                                      int edge_tiles, int pad) {
-  constexpr int TCO = 128, NJ = 2, PWAVES = TQ / 64;
+  constexpr int TCO = 128, NJ = 2, NT = TQ * 4, PWAVES = TQ / 64;
   constexpr int PATCH_MAX = 2 * TQ + 2;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LIMBS * (PATCH_MAX + TCO) * ROWB];
+  // weight slabs staged per barrier interval: the 8-wave variant (alone on its CU) takes a whole row of taps
+  // (ky fixed, kx = 0..2) so that each interval carries 36 instead of 12 MFMAs per wave
+  constexpr int TPI = (TQ == 128) ? 3 : 1;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LIMBS * (PATCH_MAX + TPI * TCO) * ROWB];
   unsigned char (*sP)[PATCH_MAX * ROWB] = reinterpret_cast<unsigned char (*)[PATCH_MAX * ROWB]>(smem);
   unsigned char (*sW)[TCO * ROWB] = reinterpret_cast<unsigned char (*)[TCO * ROWB]>(smem + LIMBS * PATCH_MAX * ROWB);
 
@@ -848,16 +851,16 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
     const bool lok = lin & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
     lvoff = lok ? (unsigned)(lci * hw + iy * a.w + ix) * 4u : kOobOffset;
   }
-  // ---- weight rows
-  const int wrow = (tid >> 1) & (TCO - 1), wpart = tid & 1;
-  const bool w_thr = tid < 2 * TCO;
+  // ---- weight rows: every thread moves an equal share of each 128-row x 64-byte slab
+  constexpr int WPARTS = NT / TCO, WEPT = BKS / WPARTS;
+  const int wrow = tid / WPARTS, wpart = tid % WPARTS;
   const bool w_ok = (co0 + wrow) < a.cout_g;
   const int kfull = 9 * a.cin_g;
   // weights through a buffer resource too: loop-invariant lane offset + scalar (tap, chunk, limb) offset, so the
   // loads need no address VGPRs (no WAR wait on the previous slab's registers) and rows beyond cout read as zero
   const __amdgpu_buffer_rsrc_t wr = uniform_rsrc(reinterpret_cast<const float*>(a.wsplit),
                                                  (int)(a.wsplit_stride * 2 * LIMBS));
-  const unsigned wvoff = w_ok ? (unsigned)((((size_t)g * a.cout_g + co0 + wrow) * kfull + wpart * EPT) * 2) : kOobOffset;
+  const unsigned wvoff = w_ok ? (unsigned)((((size_t)g * a.cout_g + co0 + wrow) * kfull + wpart * WEPT) * 2) : kOobOffset;
   const int wlimb = __builtin_amdgcn_readfirstlane((int)(a.wsplit_stride * 2));     // bytes between limb planes
 
   const int chunk0 = split * a.slabs_per_split;
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   if (chunk1 > a.nslabs) chunk1 = a.nslabs;
 
   float xa[16], xl = 0.f;
-  U4 wv[LIMBS][EPT / 8];
+  U4 wv[TPI][LIMBS][WEPT / 8];
 
   auto load_patch = [&](int chunk) {
     const int cbase = __builtin_amdgcn_readfirstlane(chunk * BKS * hw * 4);
@@ -909,24 +912,26 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
       }
     }
   };
-  auto load_w = [&](int chunk, int t) {
-    if (!w_thr) return;
-    const int soff = __builtin_amdgcn_readfirstlane((t * a.cin_g + chunk * BKS) * 2);
+  // interval i of a chunk covers taps [i * TPI, i * TPI + TPI)
+  auto load_w = [&](int chunk, int interval) {
 #pragma unroll
-    for (int l = 0; l < LIMBS; ++l) {
+    for (int u = 0; u < TPI; ++u) {
+      const int soff = __builtin_amdgcn_readfirstlane(((interval * TPI + u) * a.cin_g + chunk * BKS) * 2);
 #pragma unroll
-      for (int q = 0; q < EPT / 8; ++q)
-        wv[l][q] = buffer_load_u4(wr, wvoff, soff + l * wlimb + q * 16);
+      for (int l = 0; l < LIMBS; ++l)
+#pragma unroll
+        for (int q = 0; q < WEPT / 8; ++q) wv[u][l][q] = buffer_load_u4(wr, wvoff, soff + l * wlimb + q * 16);
     }
   };
   auto store_w = [&]() {
-    if (!w_thr) return;
 #pragma unroll
-    for (int l = 0; l < LIMBS; ++l) {
-      U4* wd = reinterpret_cast<U4*>(&sW[l][wrow * ROWB + wpart * EPT * 2]);
+    for (int u = 0; u < TPI; ++u)
 #pragma unroll
-      for (int q = 0; q < EPT / 8; ++q) wd[q] = wv[l][q];
-    }
+      for (int l = 0; l < LIMBS; ++l) {
+        U4* wd = reinterpret_cast<U4*>(&sW[u * LIMBS + l][wrow * ROWB + wpart * WEPT * 2]);
+#pragma unroll
+        for (int q = 0; q < WEPT / 8; ++q) wd[q] = wv[u][l][q];
+      }
   };
 
   f32x16 acc[4][NJ];                        // [parity class py*2+px][pixel sub-tile]
@@ -954,34 +959,38 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
       store_patch(chunk);
       if (chunk + 1 < chunk1) load_patch(chunk + 1);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
+      for (int iv = 0; iv < 9 / TPI; ++iv) {
         store_w();
         __syncthreads();
-        if (t + 1 < 9) load_w(chunk, t + 1);
+        if (iv + 1 < 9 / TPI) load_w(chunk, iv + 1);
         else if (chunk + 1 < chunk1) load_w(chunk + 1, 0);
-        const int ky = t / 3, kx = t - ky * 3;
-        const int cls = (ky & 1) * 2 + (kx & 1);
-        // x[q - j]: patch row/col (q - y0) + 1 - j
-        const int tapoff = ((1 - (ky >> 1)) * PW + (1 - (kx >> 1))) * ROWB;
 #pragma unroll
-        for (int ks = 0; ks < BKS / 16; ++ks) {
-          bf16x8 fa[LIMBS], fb[LIMBS][NJ];
+        for (int u = 0; u < TPI; ++u) {
+          const int t = iv * TPI + u;
+          const int ky = t / 3, kx = t - ky * 3;
+          const int cls = (ky & 1) * 2 + (kx & 1);
+          // x[q - j]: patch row/col (q - y0) + 1 - j
+          const int tapoff = ((1 - (ky >> 1)) * PW + (1 - (kx >> 1))) * ROWB;
 #pragma unroll
-          for (int l = 0; l < LIMBS; ++l) {
-            fa[l] = *reinterpret_cast<const bf16x8*>(&sW[l][(wco * 32 + l31) * ROWB + ks * 32 + kh * 16]);
+          for (int ks = 0; ks < BKS / 16; ++ks) {
+            bf16x8 fa[LIMBS], fb[LIMBS][NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-              fb[l][j] = *reinterpret_cast<const bf16x8*>(&sP[l][pbase[j] + tapoff + ks * 32 + kh * 16]);
-          }
-#pragma unroll
-          for (int sum = LIMBS - 1; sum >= 0; --sum)
-#pragma unroll
-            for (int la = 0; la <= sum; ++la) {
-              const int lb = sum - la;
+            for (int l = 0; l < LIMBS; ++l) {
+              fa[l] = *reinterpret_cast<const bf16x8*>(&sW[u * LIMBS + l][(wco * 32 + l31) * ROWB + ks * 32 + kh * 16]);
 #pragma unroll
               for (int j = 0; j < NJ; ++j)
-                acc[cls][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la], fb[lb][j], acc[cls][j], 0, 0, 0);
+                fb[l][j] = *reinterpret_cast<const bf16x8*>(&sP[l][pbase[j] + tapoff + ks * 32 + kh * 16]);
             }
+#pragma unroll
+            for (int sum = LIMBS - 1; sum >= 0; --sum)
+#pragma unroll
+              for (int la = 0; la <= sum; ++la) {
+                const int lb = sum - la;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                  acc[cls][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la], fb[lb][j], acc[cls][j], 0, 0, 0);
+              }
+          }
         }
         __syncthreads();
       }
@@ -1389,6 +1398,243 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradArgs a
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 weight gradient, row-streaming formulation (split precision).
+// The generic kernel above re-gathers and re-converts every x element once per tap (j = (ci, tap) columns): ~40
+// VALU instructions per MFMA.  Here a block owns a (TCO co) x (TCI ci) x 9-tap tile and walks DOWN a vertical
+// strip of the image (32 pixels wide), one output row per slab:
+//   * the dy row segment (TCO x 32 px) is staged as [co][px] (k = px contiguous -> MFMA A operand);
+//   * x lives in LDS as a rolling 3-row window [ci][row slot][48 px] (8-px aligned halo on both sides); each new
+//     slab converts ONE new x row, and every x element then feeds all 9 taps;
+//   * the B fragment of tap (ky, kx) is 8 consecutive pixels of row slot (y+ky-1) starting at px+kx-1: kx = 1
+//     is an aligned 16-byte read, kx = 0 / 2 are built from it and one neighbouring dword with v_alignbit.
+// Each wave owns 32 co x 32 ci and keeps the nine 32x32 accumulators (one per tap): 54 MFMAs per slab.
+// K-splits (image, strip, row block) are combined with fp32 atomics into dw (torch layout [co][ci][3][3]).
+// ------------------------------------------------------------------------------------------------
+constexpr int WR_XROW = 96;                  // bytes per x row slot: 48 bf16 = 8 halo + 32 + 8 halo
+constexpr int WR_XS = 3 * WR_XROW + 16;      // bytes per ci (odd multiple of 16 -> conflict-free lane stride)
+
+template <int LIMBS, int TCO, int TCI>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradArgs a, int segs, int rblocks,
+                                                                    int rows_per_block, float* __restrict__ ws) {
+  static_assert(TCO * TCI == 4096, "four waves of 32 co x 32 ci");
+  constexpr int WCI = TCI / 32;                       // ci waves; co waves = 4 / WCI
+  constexpr int DPARTS = 256 / TCO, DPX = 32 / DPARTS;        // dy: threads per row, pixels per thread
+  constexpr int XPT = TCI / 32;                       // x (ci, 4-px group) items per thread
+  __shared__ __attribute__((aligned(16))) unsigned char sD[LIMBS][TCO * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char sX[LIMBS][TCI * WR_XS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wci = wid % WCI, wco = wid / WCI;
+  const int tiles_ci = a.tiles_j;
+  const unsigned ntiles = (unsigned)a.tiles_co * tiles_ci;
+  const unsigned logical = gg::xcd_remap(blockIdx.x, ntiles);
+  const int tile_co = logical % a.tiles_co, tile_ci = logical / a.tiles_co;
+  const int co0 = tile_co * TCO, ci0 = tile_ci * TCI;
+  const int g = blockIdx.z;
+  // split -> (image, strip, row block)
+  int sp = blockIdx.y;
+  const int rb = sp % rblocks; sp /= rblocks;
+  const int seg = sp % segs;
+  const int n = sp / segs;
+  const int c0 = seg * 32;
+  const int y0 = rb * rows_per_block;
+  int y1 = y0 + rows_per_block;
+  if (y1 > a.h) y1 = a.h;
+  const int hw = a.h * a.w;
+
+  const float* dyn = a.dy + ((size_t)(n * a.groups + g) * a.cout_g) * hw;
+  const float* xn = a.x + ((size_t)(n * a.groups + g) * a.cin_g) * hw;
+
+  // ---- dy mover: row drow, pixels dpart*DPX .. +DPX
+  const int drow = tid / DPARTS, dpart = tid % DPARTS;
+  const bool d_ok = (co0 + drow) < a.cout_g;
+  const float* dsrc = dyn + (size_t)(d_ok ? co0 + drow : 0) * hw + c0 + dpart * DPX;
+  // ---- x mover: items (ci, 4-pixel group)
+  int xci[XPT], xsub[XPT];
+  bool x_ok[XPT];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int item = tid + 256 * i;
+    xci[i] = item >> 3;
+    xsub[i] = item & 7;
+    x_ok[i] = (ci0 + xci[i]) < a.cin_g;
+  }
+
+  float4 rd[DPX / 4];
+  float4 rx[XPT];
+  float rh[XPT];                                   // halo pixel (left for sub 0, right for sub 7)
+  auto load_dy = [&](int y) {
+    const bool ok = d_ok & (y < y1);
+#pragma unroll
+    for (int q = 0; q < DPX / 4; ++q)
+      rd[q] = ok ? *reinterpret_cast<const float4*>(dsrc + (size_t)y * a.w + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto load_x = [&](int row) {
+    const bool rok = (unsigned)row < (unsigned)a.h;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const bool ok = rok & x_ok[i];
+      const float* src = xn + (size_t)(ok ? ci0 + xci[i] : 0) * hw + (size_t)(ok ? row : 0) * a.w + c0;
+      rx[i] = ok ? *reinterpret_cast<const float4*>(src + xsub[i] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int hc = xsub[i] == 0 ? c0 - 1 : c0 + 32;
+      const bool hok = ok & ((xsub[i] == 0) | (xsub[i] == 7)) & ((unsigned)hc < (unsigned)a.w);
+      rh[i] = hok ? src[hc - c0] : 0.f;
+    }
+  };
+  auto store_dy = [&]() {
+    float v[DPX];
+#pragma unroll
+    for (int q = 0; q < DPX / 4; ++q) { v[4 * q] = rd[q].x; v[4 * q + 1] = rd[q].y; v[4 * q + 2] = rd[q].z; v[4 * q + 3] = rd[q].w; }
+#pragma unroll
+    for (int l = 0; l < LIMBS; ++l) {
+      unsigned pk[DPX / 2];
+#pragma unroll
+      for (int j = 0; j < DPX / 2; ++j) {
+        pk[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+        if (l + 1 < LIMBS) { v[2 * j] -= bf16_lo(pk[j]); v[2 * j + 1] -= bf16_hi(pk[j]); }
+      }
+      U4* dst = reinterpret_cast<U4*>(&sD[l][drow * ROWB + dpart * DPX * 2]);
+#pragma unroll
+      for (int q = 0; q < DPX / 8; ++q) dst[q] = U4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
+    }
+  };
+  auto store_x = [&](int row) {
+    const int slot = (row + 3) % 3;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
+      float hv = rh[i];
+      unsigned char* base = nullptr;
+#pragma unroll
+      for (int l = 0; l < LIMBS; ++l) {
+        base = &sX[l][xci[i] * WR_XS + slot * WR_XROW];
+        const unsigned p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(base + (8 + xsub[i] * 4) * 2) = make_uint2(p0, p1);
+        const __bf16 hb = (__bf16)hv;
+        if (xsub[i] == 0) *reinterpret_cast<__bf16*>(base + 7 * 2) = hb;
+        if (xsub[i] == 7) *reinterpret_cast<__bf16*>(base + 40 * 2) = hb;
+        if (l + 1 < LIMBS) {
+          v[0] -= bf16_lo(p0); v[1] -= bf16_hi(p0); v[2] -= bf16_lo(p1); v[3] -= bf16_hi(p1);
+          hv -= (float)hb;
+        }
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int kh = lane >> 5, l31 = lane & 31;
+  const int a_off = (wco * 32 + l31) * ROWB + kh * 16;               // + ks*32
+  const int b_off = (wci * 32 + l31) * WR_XS + (8 + kh * 8) * 2;     // + slot*WR_XROW + ks*32
+
+  if (y0 < y1) {
+    // prologue: rows y0-1 and y0 of x
+    load_x(y0 - 1);
+    store_x(y0 - 1);
+    load_x(y0);
+    store_x(y0);
+    load_dy(y0);
+    load_x(y0 + 1);
+    for (int y = y0; y < y1; ++y) {
+      store_dy();
+      store_x(y + 1);
+      __syncthreads();
+      load_dy(y + 1);
+      load_x(y + 2);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 fa[LIMBS];
+#pragma unroll
+        for (int l = 0; l < LIMBS; ++l) fa[l] = *reinterpret_cast<const bf16x8*>(&sD[l][a_off + ks * 32]);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int slot = (y + ky + 2) % 3;                          // row y + ky - 1
+          bf16x8 fb[LIMBS][3];
+#pragma unroll
+          for (int l = 0; l < LIMBS; ++l) {
+            const unsigned char* p = &sX[l][b_off + slot * WR_XROW + ks * 32];
+            const U4 mid = *reinterpret_cast<const U4*>(p);
+            const unsigned prev = *reinterpret_cast<const unsigned*>(p - 4);
+            const unsigned next = *reinterpret_cast<const unsigned*>(p + 16);
+            const U4 left{__builtin_amdgcn_alignbit(mid[0], prev, 16), __builtin_amdgcn_alignbit(mid[1], mid[0], 16),
+                          __builtin_amdgcn_alignbit(mid[2], mid[1], 16), __builtin_amdgcn_alignbit(mid[3], mid[2], 16)};
+            const U4 right{__builtin_amdgcn_alignbit(mid[1], mid[0], 16), __builtin_amdgcn_alignbit(mid[2], mid[1], 16),
+                           __builtin_amdgcn_alignbit(mid[3], mid[2], 16), __builtin_amdgcn_alignbit(next, mid[3], 16)};
+            fb[l][0] = __builtin_bit_cast(bf16x8, left);              // kx = 0: pixels px-1 ..
+            fb[l][1] = __builtin_bit_cast(bf16x8, mid);               // kx = 1
+            fb[l][2] = __builtin_bit_cast(bf16x8, right);             // kx = 2: pixels px+1 ..
+          }
+#pragma unroll
+          for (int sum = LIMBS - 1; sum >= 0; --sum)
+#pragma unroll
+            for (int la = 0; la <= sum; ++la) {
+              const int lb = sum - la;
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx)
+                acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la], fb[lb][kx], acc[ky * 3 + kx], 0, 0, 0);
+            }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  if (ws) {
+    // partial tile -> workspace [tile][split][tap][co][ci] (ci fastest: 128-byte runs per store); summed by
+    // wgrad_reduce_kernel.  (Atomics straight into dw serialise: blocks x 36,864 adds onto few addresses.)
+    const size_t tile = ((size_t)g * a.tiles_co + tile_co) * tiles_ci + tile_ci;
+    float* base = ws + (tile * gridDim.y + blockIdx.y) * (size_t)(9 * TCO * TCI);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int col = wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        base[((size_t)t * TCO + col) * TCI + wci * 32 + l31] = acc[t][r];
+      }
+    return;
+  }
+  float* dwg = a.dw + (size_t)g * a.cout_g * a.cin_g * 9;
+  const int ci = ci0 + wci * 32 + l31;
+  if (ci < a.cin_g) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (co >= a.cout_g) continue;
+      float* dst = dwg + ((size_t)co * a.cin_g + ci) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) unsafeAtomicAdd(dst + t, acc[t][r] * a.scale);
+    }
+  }
+}
+
+// dw[g][co][ci][tap] (+)= scale * sum_split ws[tile][split][tap][co_l][ci_l]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ ws,
+                                                           int groups, int cout_g, int cin_g, int tiles_co,
+                                                           int tiles_ci, int tco, int tci, int splits, float scale,
+                                                           int accumulate) {
+  const size_t tile_elems = (size_t)9 * tco * tci;
+  const size_t total = (size_t)groups * tiles_co * tiles_ci * tile_elems;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+    const size_t tile = o / tile_elems;
+    const int e = (int)(o - tile * tile_elems);
+    const int ci_l = e % tci, co_l = (e / tci) % tco, t = e / (tci * tco);
+    const int tile_ci = (int)(tile % tiles_ci), tile_co = (int)((tile / tiles_ci) % tiles_co);
+    const int g = (int)(tile / ((size_t)tiles_ci * tiles_co));
+    const int co = tile_co * tco + co_l, ci = tile_ci * tci + ci_l;
+    if (co >= cout_g || ci >= cin_g) continue;
+    const float* src = ws + tile * splits * tile_elems + e;
+    float sum = 0.f;
+    for (int sidx = 0; sidx < splits; ++sidx) sum += src[(size_t)sidx * tile_elems];
+    float* dst = dw + (((size_t)g * cout_g + co) * cin_g + ci) * 9 + t;
+    *dst = (accumulate ? *dst : 0.f) + sum * scale;
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_weight_kernel(float* __restrict__ wmat, const float* __restrict__ w,
                                                           long long total, int cout_g, int cin_g, int kh, int kw,
                                                           int transpose_io, int flip, float scale) {
@@ -1789,7 +2035,8 @@ extern "C" int gg_conv_pack_weight_split(unsigned short* wsplit, const float* w,
 
 namespace {
 int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g, int cout_g, int h,
-                int w, int ksize, int stride, int pad, float scale, int limbs, void* stream, bool accumulate = false) {
+                int w, int ksize, int stride, int pad, float scale, int limbs, void* stream, bool accumulate = false,
+                float* workspace = nullptr, long long workspace_bytes = 0) {
   if (groups <= 0 || cin_g <= 0 || cout_g <= 0) return 0;
   if (!dw || !x || !dy) return gg::fail(-2, "conv2d_wgrad: null pointer");
   if (ksize != 1 && ksize != 3) return gg::fail(-2, "conv2d_wgrad: kernel size must be 1 or 3");
@@ -1802,16 +2049,54 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
   a.ow = (w + 2 * pad - ksize) / stride + 1;
   a.stride = stride; a.pad = pad; a.scale = scale;
   a.jtot = cin_g * ksize * ksize;
-  if (!accumulate) {        // the kernels combine their K-splits with atomic adds: start from zero unless asked to add
+  auto zero_dw = [&]() -> int {  // the kernels combine their K-splits with atomic adds: start from zero unless adding
+    if (accumulate) return 0;
     hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)groups * cout_g * a.jtot, st);
-    if (e != hipSuccess) return gg::fail((int)e, "conv2d_wgrad: memset failed");
-  }
-  if (batch <= 0 || a.oh <= 0 || a.ow <= 0) return 0;
+    return e == hipSuccess ? 0 : gg::fail((int)e, "conv2d_wgrad: memset failed");
+  };
+  if (batch <= 0 || a.oh <= 0 || a.ow <= 0) return zero_dw();
   if (limbs) {
     if (limbs != 2 && limbs != 3) return gg::fail(-2, "conv2d_wgrad_split: limbs must be 2 or 3");
     if ((a.oh * a.ow) % BKS != 0 || a.ow % 4 != 0 || (reinterpret_cast<uintptr_t>(dy) & 15))
       return gg::fail(-2, "conv2d_wgrad_split: needs OH*OW %% 32 == 0, OW %% 4 == 0 and 16-byte aligned dy");
   }
+  if (limbs && ksize == 3 && stride == 1 && pad == 1 && a.w % 32 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    // row-streaming kernel: (128 co x 32 ci) tiles, or (64 x 64) for narrow outputs
+    const bool narrow = cout_g <= 64;
+    const int tco = narrow ? 64 : 128, tci = narrow ? 64 : 32;
+    a.tiles_co = (cout_g + tco - 1) / tco;
+    a.tiles_j = (cin_g + tci - 1) / tci;
+    const int segs = a.w / 32;
+    const long long tiles = (long long)a.tiles_co * a.tiles_j * groups;
+    const long long units = (long long)batch * segs;
+    // two resident blocks per CU; more blocks only add partial tiles to write and reduce
+    long long rblocks = (2LL * gg::kNumCu + tiles * units - 1) / (tiles * units);
+    const long long max_rb = (a.h + 7) / 8;                             // >= 8 rows per block
+    if (rblocks > max_rb) rblocks = max_rb;
+    if (rblocks < 1) rblocks = 1;
+    const int rows_per_block = (int)((a.h + rblocks - 1) / rblocks);
+    rblocks = (a.h + rows_per_block - 1) / rows_per_block;
+    const long long splits = units * rblocks;
+    const long long need = tiles * splits * 9LL * 4096 * (long long)sizeof(float);
+    if (workspace && workspace_bytes >= need && splits <= 65535 && (long long)a.tiles_co * a.tiles_j < (1LL << 31)) {
+      dim3 grid((unsigned)(a.tiles_co * a.tiles_j), (unsigned)splits, (unsigned)groups);
+      if (limbs == 2) {
+        if (narrow) conv3x3_wgrad_rows_kernel<2, 64, 64><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace);
+        else conv3x3_wgrad_rows_kernel<2, 128, 32><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace);
+      } else {
+        if (narrow) conv3x3_wgrad_rows_kernel<3, 64, 64><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace);
+        else conv3x3_wgrad_rows_kernel<3, 128, 32><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace);
+      }
+      int rc = gg::launch_status("conv3x3_wgrad_rows");
+      if (rc) return rc;
+      const long long total = tiles * 9LL * 4096;
+      wgrad_reduce_kernel<<<gg::stream_grid(total, 256), 256, 0, st>>>(dw, workspace, groups, cout_g, cin_g, a.tiles_co,
+                                                                      a.tiles_j, tco, tci, (int)splits, scale,
+                                                                      accumulate ? 1 : 0);
+      return gg::launch_status("wgrad_reduce");
+    }
+  }
+  if (int rc = zero_dw()) return rc;
   a.ktot = (long long)batch * a.oh * a.ow;
   a.tiles_co = (cout_g + WT - 1) / WT;
   a.tiles_j = (a.jtot + WT - 1) / WT;
@@ -1858,6 +2143,14 @@ extern "C" int gg_conv2d_wgrad_acc_f32(float* dw, const float* x, const float* d
                                        int cout_g, int h, int w, int ksize, int stride, int pad, float scale,
                                        int limbs, void* stream) {
   return wgrad_entry(dw, x, dy, batch, groups, cin_g, cout_g, h, w, ksize, stride, pad, scale, limbs, stream, true);
+}
+
+extern "C" int gg_conv2d_wgrad_ws_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g,
+                                      int cout_g, int h, int w, int ksize, int stride, int pad, float scale,
+                                      int limbs, int accumulate, float* workspace, long long workspace_bytes,
+                                      void* stream) {
+  return wgrad_entry(dw, x, dy, batch, groups, cin_g, cout_g, h, w, ksize, stride, pad, scale, limbs, stream,
+                     accumulate != 0, workspace, workspace_bytes);
 }
 
 extern "C" int gg_plane_dot_f32(float* out, const float* a, const float* b, int planes, long long hw, void* stream) {

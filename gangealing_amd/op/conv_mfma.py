@@ -167,8 +167,18 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
 # backward adds the weight gradient straight into the slot (gg_conv2d_wgrad_acc_f32) and hands autograd no
 # gradient: no per-layer memset, no temporary and no AccumulateGrad add - two tiny launches less per layer.
 GRAD_SLOTS = {}
-# developer A/B switches (comma separated names in GG_DISABLE): slots, style_demod, fuse_act
+# developer A/B switches (comma separated names in GG_DISABLE): slots, style_demod, fuse_act, wgrad_rows
 DISABLED = frozenset(filter(None, os.environ.get('GG_DISABLE', '').split(',')))
+
+
+_WORKSPACES = {}
+
+
+def _workspace(device, nbytes):
+    ws = _WORKSPACES.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _WORKSPACES[device] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    return ws
 
 
 def conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, pad, scale=1.0, into=None):
@@ -179,6 +189,14 @@ def conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, pad, scale=1.0, i
     limbs = _LIMBS[PRECISION]
     split = bool(limbs and (oh * ow) % 32 == 0 and ow % 4 == 0 and cout_g >= 32 and cin_g * k * k >= 32
                  and dy.data_ptr() % 16 == 0)
+    if split and k == 3 and stride == 1 and pad == 1 and w % 32 == 0 and 'wgrad_rows' not in DISABLED:
+        # row-streaming kernel; its K-split partials go through a workspace (one per device, grown on demand)
+        ws = _workspace(x.device, 1200 * 147456)
+        dw = into if into is not None else torch.empty((groups * cout_g, cin_g, k, k), dtype=torch.float32,
+                                                       device=x.device)
+        _lib.call('gg_conv2d_wgrad_ws_f32', dw, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale,
+                  limbs, 1 if into is not None else 0, ws, ws.numel() * 4)
+        return None if into is not None else dw
     if into is not None:
         _lib.call('gg_conv2d_wgrad_acc_f32', into, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale,
                   limbs if split else 0)

@@ -250,6 +250,14 @@ int gg_conv2d_wgrad_split_f32(float* dw, const float* x, const float* dy, int ba
 int gg_conv2d_wgrad_acc_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g,
                             int cout_g, int h, int w, int ksize, int stride, int pad, float scale, int limbs,
                             void* stream);
+/* Weight gradient with a caller-provided workspace.  With limbs != 0, a 3x3 / stride-1 / pad-1 convolution and
+ * W % 32 == 0 the row-streaming kernel runs: each block walks down a 32-pixel-wide strip keeping a rolling 3-row
+ * window of x in LDS, writes its partial (co, ci, tap) tile to `workspace`, and a second kernel sums the partials
+ * (dw = or += depending on `accumulate`).  Workspace need: blocks * 147,456 bytes (at most ~1,100 blocks); when it
+ * is NULL / too small, or for any other shape, this is gg_conv2d_wgrad(_split / _acc)_f32. */
+int gg_conv2d_wgrad_ws_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g, int cout_g,
+                           int h, int w, int ksize, int stride, int pad, float scale, int limbs, int accumulate,
+                           float* workspace, long long workspace_bytes, void* stream);
 /* Style modulation of one ModulatedConv2d layer in one launch (networks.py:214-216 EqualLinear + :244-249):
  *   style[n,ci] = sum_k latent[n*lat_stride + k] * w[ci,k] * w_scale + b[ci] * b_scale      (b may be NULL)
  *   demod[n,co] = rsqrt(sum_ci style[n,ci]^2 * wsq[co,ci] + eps)                             (demod may be NULL)

@@ -135,3 +135,28 @@ def test_styled_conv_fused_activation_matches_unfused(shape, mode_name, cuda, pr
     assert float((dx_fused - dx_ref).abs().max()) <= 2e-6 * float(dx_ref.abs().max())
     # a style that needs a gradient (learned W+ slots) must keep the unfused path
     assert not layer.conv.can_fuse_act(x, style.clone().requires_grad_(True), layer.noise.weight, layer.activate.bias)
+
+
+@pytest.mark.parametrize('mode_name,tol', [('bf16x3', 3e-5), ('bf16x6', 1e-5)])
+@pytest.mark.parametrize('spec', [(2, 64, 64, 32, 32, 1), (1, 48, 72, 40, 64, 1), (3, 160, 136, 9, 32, 1),
+                                  (2, 64, 192, 16, 96, 2), (16, 64, 64, 128, 128, 1)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_row_streaming_wgrad_matches_fp32_kernel(spec, mode_name, tol, cuda, precision):
+    """3x3 / stride 1 / pad 1 weight gradient (conv3x3_wgrad_rows_kernel: rolling x window, alignbit-shifted taps)
+    against the exact-fp32 MFMA kernel; width % 32 == 0 selects it, other shapes keep the generic kernel."""
+    from gangealing_amd.op import conv_mfma as cm
+    n, cin, cout, h, w, groups = spec
+    g = torch.Generator(device='cpu').manual_seed(99)
+    x = torch.randn(n, cin * groups, h, w, generator=g).to(cuda)
+    dy = torch.randn(n, cout * groups, h, w, generator=g).to(cuda)
+    precision('fp32')
+    ref = cm.conv_wgrad(x, dy, n, groups, cin, cout, 3, 1, 1, 0.5)
+    precision(mode_name)
+    out = cm.conv_wgrad(x, dy, n, groups, cin, cout, 3, 1, 1, 0.5)
+    assert out.shape == ref.shape == (groups * cout, cin, 3, 3)
+    err = float((out - ref).abs().max() / ref.abs().max())
+    assert err < tol, err
+    # accumulate-into form: adds to what is there
+    slot = torch.ones_like(ref)
+    cm.conv_wgrad(x, dy, n, groups, cin, cout, 3, 1, 1, 0.5, into=slot)
+    assert float((slot - 1 - ref).abs().max() / ref.abs().max()) < tol
