@@ -508,9 +508,11 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
 // pixels per tile: 128 (4 waves) or 256 (8 waves: half the weight traffic per output, the dominant L2 stream)
 constexpr int patch_pixels(int tpix) { return (tpix / 64 + 2) * 66; }    // (TH+2)*(TW+2) for TW = 64
 
-template <int LIMBS, bool IN_SCALE, int TPIX>
+// MI = 32-row co sub-tiles per wave: 2 -> 128-channel tiles; 1 -> 64-channel tiles (layers with cout <= 64 would
+// otherwise spend half of their MFMAs on zero rows)
+template <int LIMBS, bool IN_SCALE, int TPIX, int MI = 2>
 __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvArgs a, int tw_log2) {
-  constexpr int TCO = 128, MI = 2, NJ = 2, NT = TPIX * 2, PWAVES = TPIX / 64;
+  constexpr int TCO = MI * 64, NJ = 2, NT = TPIX * 2, PWAVES = TPIX / 64;
   constexpr int PATCH_MAX = patch_pixels(TPIX);
   // one LDS arena: [limb][patch rows] then [limb][weight rows]; reused as the epilogue staging buffer
   __shared__ __attribute__((aligned(16))) unsigned char smem[LIMBS * (PATCH_MAX + TCO) * ROWB];
@@ -1764,7 +1766,8 @@ bool patch_geometry(const ConvArgs& a, int tpix, int& tw_log2) {
 int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t st) {
   // plan in units of 32-channel chunks
   a.mh = a.oh; a.mw = a.ow;
-  a.tiles_co = (a.cout_g + 127) / 128;
+  const bool narrow = limbs == 2 && a.cout_g <= 64;           // 64-channel tiles
+  a.tiles_co = narrow ? 1 : (a.cout_g + 127) / 128;
   const long long tp = (long long)a.batch * a.oh * a.ow / tpix;
   if (tp * a.tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
   a.tiles_pix = (int)tp;
@@ -1787,7 +1790,13 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
   const bool sc = a.in_scale != nullptr;
   const ConvArgs full = a;
   if (a.splitk > 1) a.act_noise = nullptr;                  // atomically combined partials: activation afterwards
-  if (limbs == 2 && tpix == 256) {
+  if (narrow && tpix == 256) {
+    if (sc) conv3x3_patch_kernel<2, true, 256, 1><<<grid, 512, 0, st>>>(a, tw_log2);
+    else conv3x3_patch_kernel<2, false, 256, 1><<<grid, 512, 0, st>>>(a, tw_log2);
+  } else if (narrow) {
+    if (sc) conv3x3_patch_kernel<2, true, 128, 1><<<grid, 256, 0, st>>>(a, tw_log2);
+    else conv3x3_patch_kernel<2, false, 128, 1><<<grid, 256, 0, st>>>(a, tw_log2);
+  } else if (limbs == 2 && tpix == 256) {
     if (sc) conv3x3_patch_kernel<2, true, 256><<<grid, 512, 0, st>>>(a, tw_log2);
     else conv3x3_patch_kernel<2, false, 256><<<grid, 512, 0, st>>>(a, tw_log2);
   } else if (limbs == 2) {
