@@ -46,7 +46,10 @@ def test_upfirdn2d_hot_shapes_vs_oracle(cuda):
     k = (np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0).astype(np.float32)
     for (shape, gain, pad) in [((2, 4, 129, 129), 4, (1, 1)), ((1, 3, 257, 257), 4, (1, 1)),
                                ((2, 2, 128, 128), 1, (2, 2)), ((2, 2, 128, 128), 1, (1, 1)),
-                               ((1, 2, 200, 75), 1, (2, 2)), ((1, 1, 65, 65), 4, (1, 1))]:
+                               ((1, 2, 200, 75), 1, (2, 2)), ((1, 1, 65, 65), 4, (1, 1)),
+                               # full-width row-band kernel: odd last column, partial last band, 64-wide groups
+                               ((1, 2, 256, 256), 1, (2, 2)), ((2, 3, 64, 64), 1, (2, 2)), ((1, 2, 50, 131), 1, (1, 1)),
+                               ((1, 2, 37, 66), 4, (1, 1))]:
         x = rs.randn(*shape).astype(np.float32)
         out = upfirdn2d(T(x, cuda), T(k * gain, cuda), pad=pad)
         close(out, np_ops.upfirdn2d(x, k * gain, pad=(pad[0], pad[1], pad[0], pad[1])), 1e-5)

@@ -105,7 +105,7 @@ def test_autograd_through_split_conv(cuda, precision):
 
 @pytest.mark.parametrize('mode_name', ['fp32', 'bf16x3', 'bf16x6'])
 @pytest.mark.parametrize('shape', [(2, 64, 96, 16, 0), (1, 512, 512, 4, 0), (4, 32, 128, 64, 0), (16, 64, 128, 64, 0),
-                                   (2, 64, 96, 16, 1), (3, 32, 64, 40, 1)],
+                                   (2, 64, 96, 16, 1), (3, 32, 64, 40, 1), (2, 32, 64, 32, 1), (1, 32, 64, 128, 1)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_styled_conv_fused_activation_matches_unfused(shape, mode_name, cuda, precision):
     """One-kernel StyledConv tail: the conv epilogue (or, on up-sampling layers, the blur kernel) carries noise +
