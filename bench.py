@@ -33,12 +33,29 @@ WORKLOADS = {
 MFMA_PEAK_TFLOPS = {'fp32': 157.3, 'bf16x3': 2500.0, 'bf16x6': 2500.0}
 KERNEL_NAME = {
     'fp32': 'conv_igemm_kernel<3,0,2,2,2,2,*> (3x3 correlation, 128co x 128pix tile, v_mfma_f32_32x32x2_f32)',
-    'bf16x3': 'conv3x3_patch_kernel<2, true, 256> (3x3 stride-1 modulated conv, 128co x 256pix tile, input patch '
-              'staged once per 32-channel chunk, v_mfma_f32_32x32x16_bf16, 2 bf16 limbs per fp32 operand = 3 MFMA '
-              'products per algorithmic product)',
-    'bf16x6': 'conv3x3_patch_kernel<3, *, 128> / conv_split_kernel<3,0,3,*> (v_mfma_f32_32x32x16_bf16, 3 bf16 limbs '
-              'per fp32 operand = 6 MFMA products per algorithmic product)',
+    'bf16x3': 'conv3x3_patch_kernel<2, true, 256, 2> (3x3 stride-1 modulated conv + fused noise/bias/lrelu epilogue, '
+              '128co x 256pix tile, input patch staged once per 32-channel chunk, v_mfma_f32_32x32x16_bf16, 2 bf16 '
+              'limbs per fp32 operand = 3 MFMA products per algorithmic product)',
+    'bf16x6': 'conv3x3_patch_kernel<3, true, 128, 2> (same layers, 128co x 128pix tile, 3 bf16 limbs per fp32 operand '
+              '= 6 MFMA products per algorithmic product)',
 }
+MFMA_PRODUCTS = {'fp32': 1, 'bf16x3': 3, 'bf16x6': 6}
+
+
+def pmc_traffic(precision, workload, batch):
+    """HBM bytes per launch of the dominant kernel, measured offline with rocprofv3 --pmc on this same command
+    (scripts/final_measure.sh) and committed under profiles/; None for configurations that were not profiled."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if (rec.get('precision'), rec.get('workload'), rec.get('batch')) != (precision, workload, batch):
+        return None
+    return rec.get('hbm_bytes_per_launch')
+
+
 DTYPE = {'fp32': 'f32', 'bf16x3': 'bf16x3 (fp32 operands split into 2 bf16 limbs, fp32 accumulate)',
          'bf16x6': 'bf16x6 (fp32 operands split into 3 bf16 limbs, fp32 accumulate)'}
 
@@ -166,10 +183,17 @@ def main():
                        'loss': float(parts['p'])},
             'roofline': {
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS[args.precision],
-                'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS[args.precision], 4), 'traffic': None,
+                'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS[args.precision], 4),
+                'traffic': pmc_traffic(args.precision, args.workload, wl['batch']),
                 'kernel': KERNEL_NAME[args.precision],
+                'mfma_products_per_flop': MFMA_PRODUCTS[args.precision],
+                'mfma_issue_frac': round(achieved * MFMA_PRODUCTS[args.precision] / MFMA_PEAK_TFLOPS[args.precision], 4),
                 'note': 'achieved = algorithmic conv FLOPs (2*N*Cin*Cout*9*OH*OW per launch) / HIP-event time; '
-                        'peak = dense MFMA peak of the instruction used',
+                        'peak = dense MFMA peak of the instruction used; mfma_issue_frac = share of that peak the '
+                        'matrix pipe actually executes (split precision issues 3 or 6 MFMA products per algorithmic '
+                        'product); traffic = HBM bytes per launch from the committed rocprofv3 PMC passes '
+                        '(profiles/r01_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), null when '
+                        'the run is not the profiled configuration',
                 'launches': psum['launches'],
                 'avg_launch_ms': round(psum['total_ms'] / max(psum['launches'], 1), 4),
                 'avg_launch_gflop': round(psum['total_flops'] / max(psum['launches'], 1) / 1e9, 3),

@@ -135,6 +135,10 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
                 if (limbs == 2 and stride == 1 and pad == 1 and in_scale is not None and pow2 and tiles256 >= 512
                         and oh % (256 // min(ow, 64)) == 0):
                     prof = PROFILER
+                # bf16x6: the same layers run conv3x3_patch_kernel<3, true, 128>
+                if (limbs == 3 and stride == 1 and pad == 1 and in_scale is not None and pow2 and tiles256 >= 512
+                        and oh % (128 // min(ow, 64)) == 0):
+                    prof = PROFILER
             elif limbs == 0 and cout_g > 64 and batch * oh * ow >= 4096:
                 prof = PROFILER          # fp32 mode: conv_igemm_kernel<3,0,2,2,2,2,*> launches without split-K
         if prof is not None:
