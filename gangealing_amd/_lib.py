@@ -50,6 +50,8 @@ _PROTOS = {
     'gg_conv2d_wgrad_acc_f32': 'pppiiiiiiiiifis',
     'gg_conv2d_wgrad_ws_f32': 'pppiiiiiiiiifiipqs',
     'gg_style_demod_f32': 'pppqpppiiiifffs',
+    'gg_lpips_tail_fwd_f32': 'pppiiqfs',
+    'gg_lpips_tail_bwd_f32': 'ppppiiqfs',
     'gg_plane_dot_f32': 'pppiqs',
     'gg_adam_ema_f32': 'pppppqffffiffs',
 }

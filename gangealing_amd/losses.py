@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from .op import conv_mfma
 from .spatial_transformers.flow_ops import flow_losses
 
@@ -75,6 +76,37 @@ def gangealing_cluster_loss(generator, stn, ll, loss_fn, resize_fake2stn, psi, b
     return assignments.values.mean(), delta_flow.contiguous()
 
 
+class _LpipsTail(torch.autograd.Function):
+    """mean_pixels sum_c lin[c] * (normalize(f0) - normalize(f1))^2 for one feature tap, fused
+    (csrc/lpips.hip; lpips.py:26-28,190-199).  feats: (2N, C, H, W), first half image 0."""
+
+    @staticmethod
+    def forward(ctx, feats, lin, eps):
+        feats = feats.contiguous()
+        n2, c, h, w = feats.shape
+        n = n2 // 2
+        out = torch.empty(n, dtype=torch.float32, device=feats.device)
+        _lib.call('gg_lpips_tail_fwd_f32', out, feats, lin, n, c, h * w, eps)
+        ctx.save_for_backward(feats, lin if lin is not None else feats.new_empty(0))
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feats, lin = ctx.saved_tensors
+        n2, c, h, w = feats.shape
+        dfeats = torch.empty_like(feats)
+        _lib.call('gg_lpips_tail_bwd_f32', dfeats, feats, lin if lin.numel() else None, grad_out.contiguous().float(),
+                  n2 // 2, c, h * w, ctx.eps)
+        return dfeats, None, None
+
+
+def lpips_tail(feats, lin=None, eps=1e-10):
+    if lin is not None:
+        lin = lin.reshape(-1).contiguous().float()
+    return _LpipsTail.apply(feats, lin, eps)
+
+
 VGG16_CFG = [(64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512)]
 
 
@@ -119,6 +151,9 @@ class VGGPerceptualLoss(nn.Module):
         feats = self.features(torch.cat([in0, in1], 0))       # one batched pass for both images
         val = 0
         for f in feats:
+            if f.dtype == torch.float32 and 'lpips_tail' not in conv_mfma.DISABLED:
+                val = val + lpips_tail(f).view(n, 1, 1, 1)     # normalize -> diff^2 -> channel sum -> mean, one kernel
+                continue
             f = f / (torch.sqrt(torch.sum(f ** 2, dim=1, keepdim=True)) + 1e-10)
             d = (f[:n] - f[n:]) ** 2
             val = val + d.sum(dim=1, keepdim=True).mean(dim=(2, 3), keepdim=True)

@@ -265,6 +265,14 @@ int gg_conv2d_wgrad_ws_f32(float* dw, const float* x, const float* dy, int batch
 int gg_style_demod_f32(float* style, float* demod, const float* latent, long long lat_stride, const float* w,
                        const float* b, const float* wsq, int n, int style_dim, int cin, int cout, float w_scale,
                        float b_scale, float eps, void* stream);
+/* Perceptual-loss tail of one feature tap (reference models/losses/lpips.py:26-28, 190-199):
+ * feats (2n, c, hw): samples [0,n) belong to image 0, [n,2n) to image 1.  With u = f / (sqrt(sum_c f^2) + eps):
+ *   out[s] = mean_pixels sum_c lin[c] * (u0 - u1)^2     (lin NULL = all ones: the lpips=False / vgg_ssl branch)
+ * _bwd writes d out / d feats (2n, c, hw) for grad_out (n). */
+int gg_lpips_tail_fwd_f32(float* out, const float* feats, const float* lin, int n, int c, long long hw, float eps,
+                          void* stream);
+int gg_lpips_tail_bwd_f32(float* dfeats, const float* feats, const float* lin, const float* grad_out, int n, int c,
+                          long long hw, float eps, void* stream);
 /* Per-(n,c) dot products over the spatial plane: out[n*c] = sum_hw a*b (style / demod gradients). */
 int gg_plane_dot_f32(float* out, const float* a, const float* b, int planes, long long hw, void* stream);
 

@@ -326,3 +326,26 @@ def test_style_demod_matches_torch_ops(n, style_dim, cin, cout, cuda):
     style_only, none = style_demod(latent, w, None, scale, lr_mul)
     assert none is None
     np.testing.assert_allclose(style_only.cpu().numpy(), (ref_style - b.double() * lr_mul).cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('n,c,h,w,use_lin', [(3, 64, 20, 28, False), (2, 512, 8, 8, True), (1, 7, 5, 3, False)])
+def test_lpips_tail_matches_torch_ops(n, c, h, w, use_lin, cuda):
+    """Fused perceptual-loss tail (normalize -> diff^2 -> lin / channel sum -> spatial mean) and its gradient against
+    the reference's op sequence (lpips.py:26-28, 190-199) evaluated in float64."""
+    from gangealing_amd.losses import lpips_tail
+    g = torch.Generator(device='cpu').manual_seed(3)
+    feats = torch.relu(torch.randn(2 * n, c, h, w, generator=g) + 0.3)
+    lin = torch.rand(1, c, 1, 1, generator=g) if use_lin else None
+    gout = torch.randn(n, generator=g)
+    x = feats.to(cuda).requires_grad_(True)
+    out = lpips_tail(x, None if lin is None else lin.to(cuda))
+    out.backward(gout.to(cuda))
+    xr = feats.double().requires_grad_(True)
+    u = xr / (torch.sqrt(torch.sum(xr ** 2, dim=1, keepdim=True)) + 1e-10)
+    d = (u[:n] - u[n:]) ** 2
+    if lin is not None:
+        d = d * lin.double()
+    ref = d.sum(dim=1).mean(dim=(1, 2))
+    ref.backward(gout.double())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-4, atol=2e-7 * float(xr.grad.abs().max()) * 50)
