@@ -53,7 +53,8 @@ struct ConvArgs {
   const unsigned short* wsplit;   // bf16 limb planes [limb][g][co][k = (tap, ci)]  (split-precision path)
   long long wsplit_stride;        // elements between limb planes
   // optional StyledConv tail fused into the epilogue: y = lrelu(acc + noise_w[0]*noise[n,pix] + act_bias[co]) * gain
-  const float* act_noise;         // (N, 1, OH, OW) or null = no fused activation
+  int act;                        // 1: fused bias / noise / leaky-ReLU epilogue
+  const float* act_noise;         // (N, 1, OH, OW) or null = no noise term
   const float* act_noise_w;       // device scalar
   const float* act_bias;          // (groups*cout_g)
   float act_alpha, act_gain;
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
         stage[row * 64 + j * 32 + (lane & 31)] = v;
       }
     __syncthreads();
-    const float anw = a.act_noise ? a.act_noise_w[0] : 0.f;
+    const float anw = (a.act && a.act_noise) ? a.act_noise_w[0] : 0.f;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int idx = it * 64 + lane;
@@ -760,9 +761,10 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       const int oy = y0 + (p >> tw_log2), ox = x0 + (p & (TW - 1));
       if (co < a.cout_g) {
         float4 v4 = *reinterpret_cast<const float4*>(stage + row * 64 + c4 * 4);
-        if (a.act_noise) {       // NoiseInjection + FusedLeakyReLU (networks.py:291-298, 344-350)
-          const float4 nz = *reinterpret_cast<const float4*>(a.act_noise + (size_t)pn * hw + (size_t)oy * a.w + ox);
-          const float ab = a.act_bias[g * a.cout_g + co];
+        if (a.act) {             // (NoiseInjection +) bias + leaky ReLU (networks.py:291-298, 344-350; fused_act.py:74-97)
+          const float4 nz = a.act_noise ? *reinterpret_cast<const float4*>(a.act_noise + (size_t)pn * hw + (size_t)oy * a.w + ox)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float ab = a.act_bias ? a.act_bias[g * a.cout_g + co] : 0.f;
           float t;
           t = v4.x + anw * nz.x + ab; v4.x = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
           t = v4.y + anw * nz.y + ab; v4.y = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
@@ -1747,6 +1749,10 @@ int launch_conv_split(const ConvArgs& a, int limbs, hipStream_t st) {
 
 // the StyledConv tail as a separate in-place pass (launches whose epilogue cannot carry it)
 int post_activation(const ConvArgs& a, hipStream_t st) {
+  if (!a.act_noise)
+    return gg_fused_bias_act_f32(a.y, a.y, a.act_bias, nullptr, 3, 0, a.act_alpha, a.act_gain,
+                                 (long long)a.batch * a.groups * a.cout_g * a.oh * a.ow, (long long)a.oh * a.ow,
+                                 a.act_bias ? a.groups * a.cout_g : 0, st);
   return gg_noise_bias_act_f32(a.y, a.y, a.act_noise, a.act_noise_w, a.act_bias, a.act_alpha, a.act_gain, a.batch,
                                a.groups * a.cout_g, (long long)a.oh * a.ow, st);
 }
@@ -1789,7 +1795,7 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
   const ConvArgs full = a;
-  if (a.splitk > 1) a.act_noise = nullptr;                  // atomically combined partials: activation afterwards
+  if (a.splitk > 1) a.act = 0;                              // atomically combined partials: activation afterwards
   if (narrow && tpix == 256) {
     if (sc) conv3x3_patch_kernel<2, true, 256, 1><<<grid, 512, 0, st>>>(a, tw_log2);
     else conv3x3_patch_kernel<2, false, 256, 1><<<grid, 512, 0, st>>>(a, tw_log2);
@@ -1807,7 +1813,7 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
     else conv3x3_patch_kernel<3, false, 128><<<grid, 256, 0, st>>>(a, tw_log2);
   }
   const int rc = gg::launch_status("conv3x3_patch");
-  if (rc || !full.act_noise || a.act_noise) return rc;
+  if (rc || !full.act || a.act) return rc;
   return post_activation(full, st);
 }
 
@@ -1864,7 +1870,7 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
 
 template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {
-  if (!a.act_noise && limbs && KS == 3 && mode == 1 && pad <= 1 && a.w >= 4 && (a.w & (a.w - 1)) == 0 &&
+  if (!a.act && limbs && KS == 3 && mode == 1 && pad <= 1 && a.w >= 4 && (a.w & (a.w - 1)) == 0 &&
       (long long)a.cin_g * a.h * a.w * 4 < (1LL << 31))
     return launch_convT_patch(a, limbs, pad, st);
   if (limbs && KS == 3 && mode == 0 && stride == 1 && pad == 1) {
@@ -1875,9 +1881,9 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
       return launch_conv_patch(a, limbs, tw_log2, 256, st);
     if (patch_geometry(a, 128, tw_log2)) return launch_conv_patch(a, limbs, tw_log2, 128, st);
   }
-  if (a.act_noise) {      // no other kernel carries the activation in its epilogue
+  if (a.act) {            // no other kernel carries the activation in its epilogue
     ConvArgs plain = a;
-    plain.act_noise = nullptr;
+    plain.act = 0;
     const int rc = conv_dispatch<KS>(plain, stride, pad, mode, st, limbs);
     return rc ? rc : post_activation(a, st);
   }
@@ -1950,6 +1956,7 @@ extern "C" int gg_conv_pack_weight_f32(float* wmat, const float* w, int groups, 
 
 namespace {
 struct ActArgs {
+  int on = 0;
   const float* noise = nullptr;
   const float* noise_w = nullptr;
   const float* bias = nullptr;
@@ -1979,7 +1986,7 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   ConvArgs a;
   a.y = y; a.x = x; a.wmat = wmat; a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
   a.wsplit = wsplit; a.wsplit_stride = wsplit_stride;
-  a.act_noise = act.noise; a.act_noise_w = act.noise_w; a.act_bias = act.bias;
+  a.act = act.on; a.act_noise = act.noise; a.act_noise_w = act.noise_w; a.act_bias = act.bias;
   a.act_alpha = act.alpha; a.act_gain = act.gain;
   a.batch = batch; a.groups = groups; a.cin_g = cin_g; a.cout_g = cout_g; a.h = h; a.w = w;
   if (mode == 0) {
@@ -2020,13 +2027,13 @@ extern "C" int gg_modconv3x3_act_f32(float* y, const float* x, const float* wmat
                                      const float* out_scale, const float* noise, const float* noise_weight,
                                      const float* act_bias, float alpha, float gain, int batch, int cin, int cout,
                                      int h, int w, void* stream) {
-  if (!noise || !noise_weight || !act_bias) return gg::fail(-2, "modconv3x3_act: null activation operand");
+  if (noise && !noise_weight) return gg::fail(-2, "modconv3x3_act: noise without its weight");
   if ((h * w) % 4 != 0 || (reinterpret_cast<uintptr_t>(noise) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
     return gg::fail(-2, "modconv3x3_act: H*W must be a multiple of 4 and y / noise 16-byte aligned");
   if (limbs == 0 && !wmat) return gg::fail(-2, "modconv3x3_act: fp32 weights missing");
   if (limbs != 0 && !wsplit) return gg::fail(-2, "modconv3x3_act: split weights missing");
   ActArgs act;
-  act.noise = noise; act.noise_w = noise_weight; act.bias = act_bias; act.alpha = alpha; act.gain = gain;
+  act.on = 1; act.noise = noise; act.noise_w = noise_weight; act.bias = act_bias; act.alpha = alpha; act.gain = gain;
   return conv2d_entry(y, x, limbs ? nullptr : wmat, limbs ? wsplit : nullptr, limb_stride, limbs, in_scale, out_scale,
                       nullptr, batch, 1, cin, cout, h, w, 3, 1, 1, 0, 0, 0, stream, act);
 }

@@ -141,7 +141,10 @@ class VGGPerceptualLoss(nn.Module):
                 x = F.max_pool2d(x, 2, 2)
             for _ in stage:
                 conv = self.convs[i]
-                x = F.relu(conv_mfma.conv2d(x, conv.weight, conv.bias, stride=1, padding=1))
+                if x.shape[1] % 32 == 0:     # conv + bias + ReLU in one kernel (alpha 0, gain 1)
+                    x = conv_mfma.conv3x3_bias_act(x, conv.weight, conv.bias, 0.0, 1.0)
+                else:                        # 3-channel stem: fp32 kernel + separate ReLU
+                    x = F.relu(conv_mfma.conv2d(x, conv.weight, conv.bias, stride=1, padding=1))
                 i += 1
             feats.append(x)
         return feats

@@ -147,7 +147,7 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
         if act is not None:
             if (k, stride, pad, mode, groups) != (3, 1, 1, 0, 1) or bias is not None or (oh * ow) % 4:
                 raise NotImplementedError('conv_forward: the fused activation needs a 3x3 stride-1 pad-1 single-group conv')
-            noise, noise_weight, act_bias, alpha, gain = act
+            noise, noise_weight, act_bias, alpha, gain = act       # noise / noise_weight / act_bias may be None
             wbuf, stride_l = wmat.split(limbs) if use_split else (None, 0)
             wm = None if use_split else (wmat.fp32() if isinstance(wmat, PackedWeight) else wmat)
             _lib.call('gg_modconv3x3_act_f32', y, x, wm, wbuf, stride_l, limbs if use_split else 0, in_scale, out_scale,
@@ -287,6 +287,61 @@ class _Conv2d(Function):
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 2, 3))
         return dx, dw, db, None, None, None, None, None, None
+
+
+class _Conv3x3BiasAct(Function):
+    """leaky_relu(conv3x3(x, weight * wscale, pad 1) + bias, alpha) * gain with the bias + activation in the
+    convolution's epilogue: the STN trunk's EqualConv2d + FusedLeakyReLU pair (networks.py:602-640,
+    fused_act.py:74-97) and, with alpha = 0 / gain = 1, the VGG16 backbone's conv + ReLU.  The backward masks the
+    incoming gradient with the saved OUTPUT (as fused_act.py:27-38), then runs the data / weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, alpha, gain, wscale):
+        x = x.contiguous()
+        weight = weight.contiguous()
+        n, cin = x.shape[0], x.shape[1]
+        cout = weight.shape[0]
+        wmat = packed(weight, 1, cout, cin, 3, 0, 0, wscale)
+        y = conv_forward(x, wmat, n, 1, cin, cout, 3, 1, 1, 0,
+                         act=(None, None, None if bias is None else bias.contiguous(), alpha, gain))
+        ctx.save_for_backward(x, weight, y)
+        ctx.conf = (alpha, gain, wscale, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        alpha, gain, wscale, has_bias = ctx.conf
+        dy = dy.contiguous()
+        n, cout, h, w = y.shape
+        cin = x.shape[1]
+        g = torch.empty_like(dy)
+        db = torch.empty(cout, dtype=torch.float32, device=dy.device) if (has_bias and ctx.needs_input_grad[2]) else None
+        _lib.call('gg_fused_lrelu_bwd_f32', g, db, dy, y, alpha, gain, n, cout, h * w)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wm = packed(weight, 1, cin, cout, 3, 1, 1, wscale)
+            dx = conv_forward(g, wm, n, 1, cout, cin, 3, 1, 1, 0)
+        if ctx.needs_input_grad[1]:
+            slot = GRAD_SLOTS.get(weight.data_ptr()) if (GRAD_SLOTS and 'slots' not in DISABLED) else None
+            if slot is not None and (slot.shape != weight.shape or not slot.is_contiguous()):
+                slot = None
+            dw = conv_wgrad(x, g, n, 1, cin, cout, 3, 1, 1, wscale, into=slot)
+        return dx, dw, db, None, None, None
+
+
+def conv3x3_bias_act(input, weight, bias=None, negative_slope=0.2, scale=2 ** 0.5, weight_scale=1.0):
+    """3x3 / stride 1 / pad 1 convolution + bias + leaky ReLU (* scale) in one kernel where the shape allows
+    (gg_modconv3x3_act_f32; the library falls back to conv + activation pass internally otherwise)."""
+    if input.dtype != torch.float32 or weight.shape[-1] != 3 or weight.shape[-2] != 3:
+        raise NotImplementedError('conv3x3_bias_act: float32 3x3 kernels only')
+    if (input.shape[-1] * input.shape[-2]) % 4 or 'fuse_act' in DISABLED:
+        out = conv2d(input, weight, None, 1, 1, weight_scale=weight_scale)
+        from .fused_act import fused_leaky_relu
+        if bias is None:
+            bias = out.new_zeros(weight.shape[0])
+        return fused_leaky_relu(out, bias, negative_slope, scale)
+    return _Conv3x3BiasAct.apply(input, weight, bias, float(negative_slope), float(scale), float(weight_scale))
 
 
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, weight_scale=1.0):

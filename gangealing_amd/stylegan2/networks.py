@@ -306,6 +306,16 @@ class ConvLayer(nn.Sequential):
             layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
         super().__init__(*layers)
 
+    def forward(self, input):
+        # 3x3 / stride 1 conv followed by FusedLeakyReLU: bias + activation ride in the convolution's epilogue
+        if (len(self) == 2 and isinstance(self[0], EqualConv2d) and isinstance(self[1], FusedLeakyReLU) and
+                self[0].weight.shape[-1] == 3 and self[0].stride == 1 and self[0].padding == 1 and
+                self[0].bias is None and input.dtype == torch.float32 and input.is_cuda):
+            conv, act = self[0], self[1]
+            return conv_mfma.conv3x3_bias_act(input, conv.weight, act.bias, act.negative_slope, act.scale,
+                                              weight_scale=conv.scale)
+        return super().forward(input)
+
 
 class ResBlock(nn.Module):
     def __init__(self, in_channel, out_channel, blur_kernel=(1, 3, 3, 1), downsample=True):

@@ -230,7 +230,10 @@ int gg_conv2d_split_f32(float* y, const float* x, const unsigned short* wsplit, 
  * act_bias[co], alpha) * gain.  3x3 / stride 1 / pad 1, one group.  limbs = 0: fp32 MFMA kernel with `wmat`
  * (gg_conv_pack_weight_f32); limbs = 2|3: split-precision kernel with `wsplit` (gg_conv_pack_weight_split).
  * The activation rides in the convolution's epilogue when the launch needs no split-K; otherwise the library runs
- * gg_noise_bias_act_f32 in place afterwards - the result is the same either way.  H*W % 4 == 0. */
+ * gg_noise_bias_act_f32 in place afterwards - the result is the same either way.  H*W % 4 == 0.
+ * noise = NULL drops the noise term and in_scale / out_scale / act_bias may be NULL too, which makes this the plain
+ * "3x3 convolution + bias + leaky ReLU" of the STN trunk (EqualConv2d + FusedLeakyReLU, networks.py:602-640) and,
+ * with alpha = 0 and gain = 1, the conv + bias + ReLU of the VGG16 backbone (lpips_backbones.py:98-140). */
 int gg_modconv3x3_act_f32(float* y, const float* x, const float* wmat, const unsigned short* wsplit,
                           long long limb_stride, int limbs, const float* in_scale, const float* out_scale,
                           const float* noise, const float* noise_weight, const float* act_bias, float alpha,

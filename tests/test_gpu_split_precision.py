@@ -160,3 +160,29 @@ def test_row_streaming_wgrad_matches_fp32_kernel(spec, mode_name, tol, cuda, pre
     slot = torch.ones_like(ref)
     cm.conv_wgrad(x, dy, n, groups, cin, cout, 3, 1, 1, 0.5, into=slot)
     assert float((slot - 1 - ref).abs().max() / ref.abs().max()) < tol
+
+
+@pytest.mark.parametrize('mode_name', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('shape', [(2, 64, 64, 32, 32), (1, 128, 96, 16, 16), (3, 32, 64, 8, 12), (1, 512, 512, 4, 4)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_conv3x3_bias_act_matches_unfused(shape, mode_name, cuda, precision):
+    """conv + bias + leaky ReLU in the convolution's epilogue (STN ConvLayer / VGG conv+ReLU) == conv, then
+    fused_leaky_relu; forward, data gradient, weight gradient and bias gradient."""
+    from gangealing_amd.op import conv_mfma as cm
+    from gangealing_amd.op.fused_act import fused_leaky_relu
+    n, cin, cout, h, w = shape
+    precision(mode_name)
+    g = torch.Generator(device='cpu').manual_seed(11)
+    x = torch.randn(n, cin, h, w, generator=g).to(cuda).requires_grad_(True)
+    wt = torch.randn(cout, cin, 3, 3, generator=g).to(cuda).requires_grad_(True)
+    b = torch.randn(cout, generator=g).to(cuda).requires_grad_(True)
+    scale = (cin * 9) ** -0.5
+    for alpha, gain in ((0.2, 2 ** 0.5), (0.0, 1.0)):
+        fused = cm.conv3x3_bias_act(x, wt, b, alpha, gain, weight_scale=scale)
+        go = torch.randn_like(fused)
+        gf = torch.autograd.grad(fused, (x, wt, b), go)
+        ref = fused_leaky_relu(cm.conv2d(x, wt, None, 1, 1, weight_scale=scale), b, alpha, gain)
+        gr = torch.autograd.grad(ref, (x, wt, b), go)
+        assert float((fused - ref).detach().abs().max()) <= 2e-6 * float(ref.detach().abs().max())
+        for a_, r_ in zip(gf, gr):
+            assert float((a_ - r_).abs().max()) <= 1e-5 * float(r_.abs().max()) + 1e-7
