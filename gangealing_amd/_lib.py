@@ -43,6 +43,7 @@ _PROTOS = {
     'gg_conv_pack_weight_f32': 'ppiiiiiiifs',
     'gg_conv2d_f32': 'ppppppiiiiiiiiiiiis',
     'gg_conv_pack_weight_split': 'ppiiiiiiifis',
+    'gg_conv_pack_weights_many': 'pis',
     'gg_conv2d_split_f32': 'pppqipppiiiiiiiiiiiis',
     'gg_modconv3x3_act_f32': 'ppppqipppppffiiiiis',
     'gg_conv2d_wgrad_f32': 'pppiiiiiiiiifs',

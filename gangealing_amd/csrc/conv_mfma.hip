@@ -1068,15 +1068,13 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
 }
 
 
-__global__ __launch_bounds__(256) void pack_weight_split_kernel(unsigned short* __restrict__ wl,
-                                                                const float* __restrict__ w, long long total,
-                                                                long long limb_stride, int cout_g, int cin_g, int kh,
-                                                                int kw, int transpose_io, int flip, float scale,
-                                                                int limbs) {
-  // wl[limb][g][c][(tap, r)], r (reduction channel) fastest
-  const long long stride = (long long)gridDim.x * blockDim.x;
+// wl[limb][g][c][(tap, r)], r (reduction channel) fastest.  `first` / `stride`: this thread's grid-stride walk.
+__device__ __forceinline__ void pack_weight_split_body(unsigned short* __restrict__ wl, const float* __restrict__ w,
+                                                       long long total, long long limb_stride, int cout_g, int cin_g,
+                                                       int kh, int kw, int transpose_io, int flip, float scale,
+                                                       int limbs, long long first, long long stride) {
   const int kk = kh * kw;
-  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+  for (long long o = first; o < total; o += stride) {
     const int r = (int)(o % cin_g);
     long long q = o / cin_g;
     const int tap = (int)(q % kk);
@@ -1094,6 +1092,43 @@ __global__ __launch_bounds__(256) void pack_weight_split_kernel(unsigned short* 
       v -= (float)h;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void pack_weight_split_kernel(unsigned short* __restrict__ wl,
+                                                                const float* __restrict__ w, long long total,
+                                                                long long limb_stride, int cout_g, int cin_g, int kh,
+                                                                int kw, int transpose_io, int flip, float scale,
+                                                                int limbs) {
+  pack_weight_split_body(wl, w, total, limb_stride, cout_g, cin_g, kh, kw, transpose_io, flip, scale, limbs,
+                         (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+
+// Many weights in one launch (the trainer re-packs every trainable convolution weight after each optimizer step):
+// blockIdx.y = job, blockIdx.x = one of PACK_MANY_BLOCKS grid-stride workers.
+struct PackJob {
+  void* dst;
+  const float* src;
+  long long total;
+  long long limb_stride;
+  int cout_g, cin_g, kh, kw, transpose_io, flip;
+  int limbs;            // 0: fp32 GEMM layout (pack_weight_kernel); 2 | 3: bf16 limb planes
+  float scale;
+};
+constexpr int PACK_MANY_BLOCKS = 48;
+
+__device__ __forceinline__ void pack_weight_body(float* __restrict__ wmat, const float* __restrict__ w, long long total,
+                                                 int cout_g, int cin_g, int kh, int kw, int transpose_io, int flip,
+                                                 float scale, long long first, long long stride);
+
+__global__ __launch_bounds__(256) void pack_weight_many_kernel(const PackJob* __restrict__ jobs) {
+  const PackJob j = jobs[blockIdx.y];
+  const long long first = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+  if (j.limbs)
+    pack_weight_split_body(reinterpret_cast<unsigned short*>(j.dst), j.src, j.total, j.limb_stride, j.cout_g, j.cin_g,
+                           j.kh, j.kw, j.transpose_io, j.flip, j.scale, j.limbs, first, stride);
+  else
+    pack_weight_body(reinterpret_cast<float*>(j.dst), j.src, j.total, j.cout_g, j.cin_g, j.kh, j.kw, j.transpose_io,
+                     j.flip, j.scale, first, stride);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1639,13 +1674,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
   }
 }
 
-__global__ __launch_bounds__(256) void pack_weight_kernel(float* __restrict__ wmat, const float* __restrict__ w,
-                                                          long long total, int cout_g, int cin_g, int kh, int kw,
-                                                          int transpose_io, int flip, float scale) {
-  // wmat[g][(r, ky, kx)][c], r = reduction channel (cin_g of them), c = output channel (cout_g)
-  const long long stride = (long long)gridDim.x * blockDim.x;
+// wmat[g][(r, ky, kx)][c], r = reduction channel (cin_g of them), c = output channel (cout_g)
+__device__ __forceinline__ void pack_weight_body(float* __restrict__ wmat, const float* __restrict__ w, long long total,
+                                                 int cout_g, int cin_g, int kh, int kw, int transpose_io, int flip,
+                                                 float scale, long long first, long long stride) {
   const int kk = kh * kw;
-  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+  for (long long o = first; o < total; o += stride) {
     const int c = (int)(o % cout_g);
     long long q = o / cout_g;
     const int tap = (int)(q % kk);
@@ -1658,6 +1692,13 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(float* __restrict__ wm
                                     : (((size_t)g * cout_g + c) * cin_g + r) * kk + ky * kw + kx;
     wmat[o] = w[src] * scale;
   }
+}
+
+__global__ __launch_bounds__(256) void pack_weight_kernel(float* __restrict__ wmat, const float* __restrict__ w,
+                                                          long long total, int cout_g, int cin_g, int kh, int kw,
+                                                          int transpose_io, int flip, float scale) {
+  pack_weight_body(wmat, w, total, cout_g, cin_g, kh, kw, transpose_io, flip, scale,
+                   (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
 }
 
 // per-plane dot product: one block per plane, 16 B loads when possible
@@ -2036,6 +2077,14 @@ extern "C" int gg_modconv3x3_act_f32(float* y, const float* x, const float* wmat
   act.on = 1; act.noise = noise; act.noise_w = noise_weight; act.bias = act_bias; act.alpha = alpha; act.gain = gain;
   return conv2d_entry(y, x, limbs ? nullptr : wmat, limbs ? wsplit : nullptr, limb_stride, limbs, in_scale, out_scale,
                       nullptr, batch, 1, cin, cout, h, w, 3, 1, 1, 0, 0, 0, stream, act);
+}
+
+extern "C" int gg_conv_pack_weights_many(const void* jobs, int njobs, void* stream) {
+  if (njobs <= 0) return 0;
+  if (!jobs || njobs > 65535) return gg::fail(-2, "conv_pack_weights_many: bad arguments");
+  pack_weight_many_kernel<<<dim3(PACK_MANY_BLOCKS, (unsigned)njobs), 256, 0, gg::as_stream(stream)>>>(
+      reinterpret_cast<const PackJob*>(jobs));
+  return gg::launch_status("conv_pack_weights_many");
 }
 
 extern "C" int gg_conv_pack_weight_split(unsigned short* wsplit, const float* w, int groups, int cout_g, int cin_g,

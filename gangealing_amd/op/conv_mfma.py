@@ -86,11 +86,73 @@ def _pair_eq(v, name):
 _FROZEN_PACKS = {}
 
 
+# Trainable weights: None = pack on every use.  A trainer that updates its parameters in place once per step can
+# switch the registry on (enable_pack_registry) and call repack_trainable() after the optimizer: every pack that was
+# used so far is then rebuilt by ONE launch (gg_conv_pack_weights_many) instead of one launch per layer and use.
+# Entries are validated against the weight's version counter, so any other in-place update falls back to packing.
+class _PackRegistry:
+    def __init__(self):
+        self.entries = {}          # key -> [PackedWeight, weight version the packs correspond to]
+        self.signature = None      # which layouts the job table covers
+        self.jobs = None
+        self.njobs = 0
+
+
+TRAINABLE_PACKS = None
+
+
+def enable_pack_registry(on=True):
+    global TRAINABLE_PACKS
+    TRAINABLE_PACKS = _PackRegistry() if on else None
+
+
+def repack_trainable():
+    """Rebuild every registered pack from the current parameter values (one launch)."""
+    reg = TRAINABLE_PACKS
+    if reg is None or not reg.entries or 'pack_registry' in DISABLED:
+        return
+    signature = tuple((key, ent[0]._fp32 is not None, tuple(sorted(ent[0]._split))) for key, ent in reg.entries.items())
+    if signature != reg.signature:
+        import numpy as np
+        dt = np.dtype([('dst', '<u8'), ('src', '<u8'), ('total', '<i8'), ('limb_stride', '<i8'), ('cout_g', '<i4'),
+                       ('cin_g', '<i4'), ('kh', '<i4'), ('kw', '<i4'), ('transpose_io', '<i4'), ('flip', '<i4'),
+                       ('limbs', '<i4'), ('scale', '<f4')])
+        assert dt.itemsize == 64
+        rows, device = [], None
+        for ent in reg.entries.values():
+            pw = ent[0]
+            device = pw.weight.device
+            total = pw.groups * pw.cout_g * pw.cin_g * pw.k * pw.k
+            tail = (pw.cout_g, pw.cin_g, pw.k, pw.k, pw.transpose_io, pw.flip)
+            if pw._fp32 is not None:
+                rows.append((pw._fp32.data_ptr(), pw.weight.data_ptr(), total, 0) + tail + (0, pw.scale))
+            for limbs, (buf, n) in pw._split.items():
+                rows.append((buf.data_ptr(), pw.weight.data_ptr(), total, n) + tail + (limbs, pw.scale))
+        reg.njobs = len(rows)
+        reg.jobs = None
+        if rows:
+            arr = np.array(rows, dtype=dt)
+            reg.jobs = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).to(device)
+        reg.signature = signature
+    if reg.jobs is not None:
+        _lib.call('gg_conv_pack_weights_many', reg.jobs, reg.njobs)
+    for ent in reg.entries.values():
+        ent[1] = ent[0].weight._version
+
+
 def packed(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0):
     """PackedWeight for `weight`; weights that do not require grad (frozen VGG / generator) keep their
     packs across steps, keyed by storage + version so an in-place update invalidates them."""
     if weight.requires_grad:
-        return PackedWeight(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale)
+        reg = TRAINABLE_PACKS
+        if reg is None or 'pack_registry' in DISABLED:
+            return PackedWeight(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale)
+        key = (weight.data_ptr(), groups, cout_g, cin_g, k, int(transpose_io), int(flip), float(scale))
+        ent = reg.entries.get(key)
+        if ent is None or ent[1] != weight._version:
+            ent = reg.entries[key] = [PackedWeight(weight.detach(), groups, cout_g, cin_g, k, transpose_io, flip, scale),
+                                      weight._version]
+        return ent[0]
     key = (weight.data_ptr(), weight._version, groups, cout_g, cin_g, k, int(transpose_io), int(flip), float(scale))
     pw = _FROZEN_PACKS.get(key)
     if pw is None:

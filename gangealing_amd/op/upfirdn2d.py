@@ -35,6 +35,20 @@ def _launch(x, kernel, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
     return out
 
 
+_FLIPPED = {}
+
+
+def _flipped(kernel):
+    """torch.flip(kernel, [0, 1]), cached per (storage, version): the FIR taps are module buffers."""
+    key = (kernel.data_ptr(), kernel._version, tuple(kernel.shape), kernel.dtype)
+    hit = _FLIPPED.get(key)
+    if hit is None:
+        if len(_FLIPPED) > 256:
+            _FLIPPED.clear()
+        hit = _FLIPPED[key] = (torch.flip(kernel, [0, 1]).contiguous(), kernel)    # keep `kernel` alive: stable address
+    return hit[0]
+
+
 class UpFirDn2d(Function):
     @staticmethod
     def forward(ctx, input, kernel, up, down, pad):
@@ -55,7 +69,7 @@ class UpFirDn2d(Function):
     def backward(ctx, grad_output):
         (kernel,) = ctx.saved_tensors
         up, down = ctx.conf
-        grad_input = UpFirDn2d.apply(grad_output, torch.flip(kernel, [0, 1]), down, up, ctx.g_pad)
+        grad_input = UpFirDn2d.apply(grad_output, _flipped(kernel), down, up, ctx.g_pad)
         return grad_input, None, None, None, None
 
 
@@ -93,7 +107,7 @@ class _BlurNoiseAct(Function):
         n, c, h, w = grad_output.shape
         g0, g1 = ctx.g_pad
         dx = torch.empty((n, c, h + g0 + g1 - 3, w + g0 + g1 - 3), dtype=grad_output.dtype, device=grad_output.device)
-        _lib.call('gg_blur4_fused_f32', dx, grad_output, torch.flip(kernel, [0, 1]).contiguous(), n, c, h, w,
+        _lib.call('gg_blur4_fused_f32', dx, grad_output, _flipped(kernel), n, c, h, w,
                   g0, g1, g0, g1, None, None, None, out, negative_slope, scale)
         return dx, None, None, None, None, None, None, None
 

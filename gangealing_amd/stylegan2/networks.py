@@ -104,11 +104,24 @@ class EqualLinear(nn.Module):
         self.scale = (1 / math.sqrt(in_dim)) * lr_mul
         self.lr_mul = lr_mul
 
+    def _scaled(self):
+        """(weight * scale, bias * lr_mul); cached while the parameters are frozen (the generator's mapping network
+        and modulation layers: two element-wise launches less per layer and pass)."""
+        w, b = self.weight, self.bias
+        if w.requires_grad or (b is not None and b.requires_grad):
+            return w * self.scale, (None if b is None else b * self.lr_mul)
+        key = (w._version, w.data_ptr(), None if b is None else (b._version, b.data_ptr()))
+        if getattr(self, '_scaled_cache', None) is None or self._scaled_cache[0] != key:
+            with torch.no_grad():
+                self._scaled_cache = (key, (w * self.scale).contiguous(), None if b is None else b * self.lr_mul)
+        return self._scaled_cache[1], self._scaled_cache[2]
+
     def forward(self, input):
+        weight, bias = self._scaled()
         if self.activation:
-            out = F.linear(input, self.weight * self.scale)
-            return fused_leaky_relu(out, self.bias * self.lr_mul)
-        return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
+            out = F.linear(input, weight)
+            return fused_leaky_relu(out, bias)
+        return F.linear(input, weight, bias=bias)
 
     def __repr__(self):
         return f'{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})'

@@ -80,6 +80,11 @@ def adam_ema_step(arena, lr, ema_flat=None, ema_decay=0.0, betas=(0.9, 0.999), e
     arena.step_count += 1
     _lib.call('gg_adam_ema_f32', arena.param, arena.exp_avg, arena.exp_avg_sq, ema_flat, arena.grad, arena.numel,
               lr, betas[0], betas[1], eps, arena.step_count, ema_decay, grad_scale)
+    # the kernel wrote through raw pointers: tell autograd's version counters (shared by the parameter views), so
+    # that anything cached against the old values - e.g. conv_mfma's weight packs - is recognised as stale
+    torch.autograd.graph.increment_version(arena.param)
+    if ema_flat is not None:
+        torch.autograd.graph.increment_version(ema_flat)
 
 
 def cosine_psi(step, total):
@@ -133,6 +138,7 @@ class GangealingTrainer:
         self.loss_fn = get_perceptual_loss(loss_fn, device)
         self.resize_fake2stn = BilinearDownsample(gen_size // flow_size, 3).to(device) if gen_size > flow_size \
             else nn.Sequential()
+        conv_mfma.enable_pack_registry()     # trainable conv weights: packs rebuilt once per step (repack_trainable)
         self.stn_arena = FlatArena(self.stn)
         self.ema_arena = FlatArena(self.t_ema)
         self.ll_arena = FlatArena(self.ll)
@@ -172,6 +178,7 @@ class GangealingTrainer:
         adam_ema_step(self.stn_arena, self.stn_lr, self.ema_arena.param, self.ema_decay)
         if not self.freeze_ll:
             adam_ema_step(self.ll_arena, self.ll_lr)
+        conv_mfma.repack_trainable()         # all STN weight packs (forward + data-gradient layouts) in one launch
         return parts
 
 

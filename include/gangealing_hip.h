@@ -221,6 +221,12 @@ int gg_conv2d_f32(float* y, const float* x, const float* wmat, const float* in_s
  * Requires cin_g % 32 == 0; every other argument as gg_conv2d_f32. */
 int gg_conv_pack_weight_split(unsigned short* wsplit, const float* w, int groups, int cout_g, int cin_g, int kh,
                               int kw, int transpose_io, int flip, float scale, int limbs, void* stream);
+/* Many weight packs in one launch.  `jobs`: device array of `njobs` records
+ *   struct { void* dst; const float* src; long long total, limb_stride;
+ *            int cout_g, cin_g, kh, kw, transpose_io, flip, limbs; float scale; }          (64 bytes each)
+ * limbs = 0 writes the fp32 GEMM layout of gg_conv_pack_weight_f32, 2 | 3 the bf16 limb planes of
+ * gg_conv_pack_weight_split (total = groups*cout_g*cin_g*kh*kw, limb_stride = elements between limb planes). */
+int gg_conv_pack_weights_many(const void* jobs, int njobs, void* stream);
 int gg_conv2d_split_f32(float* y, const float* x, const unsigned short* wsplit, long long limb_stride, int limbs,
                         const float* in_scale, const float* out_scale, const float* bias, int batch, int groups,
                         int cin_g, int cout_g, int h, int w, int ksize, int stride, int pad, int mode, int out_h,
