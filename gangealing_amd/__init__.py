@@ -8,6 +8,7 @@ Only what the path needs lives here:
   spatial_transformers/ drop-in for models/spatial_transformers (anti-aliased sampling, heads, STN)
   stylegan2/            the generator built on the fused modulated convolution
   losses, latent_learner, distributed, train_step: the callers on either side of the path
+  cluster_classifier    ResnetClassifier + its training iteration (clustering variants; §8 f3)
   launch.py             runs an unmodified reference script with these modules injected
 """
 __version__ = '0.1.0'

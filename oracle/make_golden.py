@@ -318,6 +318,38 @@ def gen_stn():
     save('stn', cases)
 
 
+def gen_cluster_classifier():
+    from models.cluster_classifier import ResnetClassifier
+    from models import accuracy
+    cases = []
+    for ci, (size, supersize, heads) in enumerate([(32, None, 4), (32, 64, 6)]):
+        net = ResnetClassifier(size, channel_multiplier=0.5, num_heads=heads, supersize=supersize)
+        sd = det_state_dict(net, (('to_logits', 0.05),))
+        torch.nn.Module.load_state_dict(net, sd, strict=False)
+        res = supersize or size
+        x = rnd(f'cls.x{ci}', (5, 3, res, res), 0.5)
+        logits = net(x)
+        labels = torch.tensor([1, 3, 0, 2, 1]) % heads
+        loss = torch.nn.functional.cross_entropy(logits, labels)
+        names = [n for n, _ in net.named_parameters()]
+        grads = torch.autograd.grad(loss, list(net.parameters()))
+        gnorm = {n: float(g.double().norm()) for n, g in zip(names, grads)}
+        scores = rnd(f'cls.scores{ci}', (5, heads))
+        flipped, _, classes, flip_ixs = net.run_flip(x)
+        kept, kept_logits = net.run(x, 1)
+        cart, policy = net.run_flip_cartesian(x[:2])
+        cases.append(dict(x=x, logits=logits, labels=labels, loss=loss, scores=scores,
+                          acc1=accuracy(logits, scores), acc2=accuracy(logits, scores, k=2),
+                          grad_to_logits_weight=grads[names.index('to_logits.weight')],
+                          grad_to_logits_bias=grads[names.index('to_logits.bias')],
+                          assign=net.assign(x), assign_noflip=net.assign(x, ignore_flips=True),
+                          run_flip_images=flipped, run_flip_classes=classes, run_flip_ixs=flip_ixs,
+                          run_kept=kept, run_kept_logits=kept_logits, cart_images=cart, cart_policy=policy,
+                          meta=dict(size=size, supersize=supersize, num_heads=heads, channel_multiplier=0.5,
+                                    scale_rules=[['to_logits', 0.05]], grad_norms=gnorm)))
+    save('cluster_classifier', cases)
+
+
 def gen_train_step():
     """One gangealing_loss evaluation (loss.py:64-75) at a plumbing-sized config with an MSE
     stand-in for the VGG loss (torchvision is not installed).  RNG-dependent inputs (z, per-layer
@@ -397,7 +429,7 @@ if __name__ == '__main__':
     only = sys.argv[1:]
     gens = dict(upfirdn2d=gen_upfirdn2d, fused_act=gen_fused_act, mipmap_warp=gen_mipmap_warp, heads=gen_heads,
                 misc=gen_misc, modconv=gen_modconv, generator=gen_generator, stn=gen_stn,
-                train_step=gen_train_step, splat=gen_splat_selfcheck)
+                train_step=gen_train_step, splat=gen_splat_selfcheck, cluster_classifier=gen_cluster_classifier)
     for name, fn in gens.items():
         if only and name not in only:
             continue

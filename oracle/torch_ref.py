@@ -208,6 +208,21 @@ def stn_trunk(sd, prefix, x, flow_size, is_flow):
     return conv_layer(sd, f'{prefix}final_conv', out)
 
 
+def cluster_classifier(sd, x, size):
+    """ResnetClassifier.forward (reference models/cluster_classifier.py:28-48): optional bilinear downsample to
+    `size`, 1x1 stem, one down-sampling ResBlock per octave down to 4x4, final 3x3 conv, EqualLinear + fused lrelu."""
+    if x.shape[-1] > size:
+        x = bilinear_downsample(x, x.shape[-1] // size)
+    feats = stn_trunk(sd, '', x, size, False)
+    return equal_linear(sd, 'to_logits', feats.reshape(feats.shape[0], -1), activation=True)
+
+
+def reverse_topk_accuracy(predictions, gt_scores, k=1):
+    """models/__init__.py:37-43."""
+    top = predictions.argmax(dim=1, keepdim=True)
+    return (top == gt_scores.topk(k=k, dim=1).indices).any(dim=1).float().mean()
+
+
 def similarity_matrix(params):
     rot = torch.tanh(params[:, 0]) * math.pi
     s = torch.exp(params[:, 1])

@@ -206,3 +206,66 @@ def test_cluster_stn_shapes(cuda):
     torch.testing.assert_close(out, x.repeat_interleave(3, dim=0), atol=1e-5, rtol=1e-5)
     out_u = stn(x, unfold=True, padding_mode='border')
     assert out_u.shape == (2, 3, 3, 64, 64)
+
+
+@pytest.mark.parametrize('case', load_golden('cluster_classifier'), ids=lambda c: f"heads{c['meta']['num_heads']}")
+def test_cluster_classifier_golden(case, cuda):
+    """ResnetClassifier on the HIP kernels against the reference module: logits, loss, gradients, and the
+    index-valued helpers (assign / run / run_flip / run_flip_cartesian) bit-exact."""
+    from gangealing_amd.cluster_classifier import ResnetClassifier, accuracy
+    m = case['meta']
+    net = ResnetClassifier(m['size'], channel_multiplier=m['channel_multiplier'], num_heads=m['num_heads'],
+                           supersize=m['supersize'])
+    net = load_det(net, m['scale_rules']).to(cuda)
+    x = T(case['x'], cuda)
+    logits = net(x)
+    close(logits, case['logits'], 2e-4)
+    loss = torch.nn.functional.cross_entropy(logits, T(case['labels'], cuda))
+    close(loss, case['loss'], 1e-5)
+    loss.backward()
+    grads = dict((n, p.grad) for n, p in net.named_parameters())
+    close(grads['to_logits.weight'], case['grad_to_logits_weight'], 1e-5, 2e-3)
+    close(grads['to_logits.bias'], case['grad_to_logits_bias'], 1e-5, 2e-3)
+    for name, ref_norm in m['grad_norms'].items():
+        got = float(grads[name].double().norm())
+        assert abs(got - ref_norm) <= 5e-3 * max(ref_norm, 1e-9), (name, got, ref_norm)
+    scores = T(case['scores'], cuda)
+    assert float(accuracy(logits, scores)) == float(case['acc1'])
+    assert float(accuracy(logits, scores, k=2)) == float(case['acc2'])
+    with torch.no_grad():
+        assert np.array_equal(net.assign(x).cpu().numpy(), case['assign'])
+        assert np.array_equal(net.assign(x, ignore_flips=True).cpu().numpy(), case['assign_noflip'])
+        flipped, _, classes, flip_ixs = net.run_flip(x)
+        assert np.array_equal(classes.cpu().numpy(), case['run_flip_classes'])
+        assert np.array_equal(flip_ixs.cpu().numpy(), case['run_flip_ixs'])
+        assert np.array_equal(flipped.cpu().numpy(), case['run_flip_images'])
+        kept, kept_logits = net.run(x, 1)
+        assert np.array_equal(kept.cpu().numpy(), case['run_kept'])
+        close(kept_logits, case['run_kept_logits'], 2e-4)
+        cart, policy = net.run_flip_cartesian(x[:2])
+        assert np.array_equal(cart.cpu().numpy(), case['cart_images'])
+        assert np.array_equal(policy.cpu().numpy(), case['cart_policy'])
+
+
+def test_cluster_classifier_training_step(cuda):
+    """One iteration of train_cluster_classifier.py:78-101 on a miniature clustering configuration: labels come from
+    the frozen cluster STN, the classifier's parameters move, nothing else does."""
+    from gangealing_amd.cluster_classifier import ResnetClassifier, cluster_classifier_step
+    from gangealing_amd.train_step import GangealingTrainer
+    tr = GangealingTrainer(cuda, gen_size=64, flow_size=32, batch=4, transform=('similarity',), inject=3, ndirs=2,
+                           num_heads=2, flips=True, perturb_heads=0.05, seed=3)
+    heads = 2
+    cls = ResnetClassifier(32, channel_multiplier=0.5, num_heads=heads * 2).to(cuda)
+    opt = torch.optim.Adam(cls.parameters(), lr=1e-3)
+    before = [p.detach().clone() for p in cls.parameters()]
+    stn_before = tr.stn_arena.param.clone()
+    xent, metrics = cluster_classifier_step(cls, tr.generator, tr.t_ema, tr.ll, tr.loss_fn, tr.resize_fake2stn, 4,
+                                            tr.dim_latent, heads, True, cuda, sample_from_full_res=False,
+                                            padding_mode='border')
+    opt.zero_grad()
+    xent.backward()
+    opt.step()
+    assert torch.isfinite(xent) and 0.0 <= float(metrics['acc@1']) <= float(metrics['acc@2']) <= 1.0
+    assert abs(float(metrics['assignments'].sum()) - 1.0) < 1e-6 and metrics['assignments'].numel() == 4
+    assert any(float((p.detach() - b).abs().max()) > 0 for p, b in zip(cls.parameters(), before))
+    assert torch.equal(tr.stn_arena.param, stn_before)
