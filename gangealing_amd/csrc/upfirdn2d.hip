@@ -76,13 +76,6 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_tile(
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r0 = wid * ROWS_PER_WAVE;
   const int ox = ox0 + lane;
-  float w0[4], w1[4], w2[4], w3[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    w0[c] = sx[r0 + 0][lane + c];
-    w1[c] = sx[r0 + 1][lane + c];
-    w2[c] = sx[r0 + 2][lane + c];
-  }
   float* dst = out + (size_t)plane * out_h * out_w;
   const float* nz = nullptr;
   float nw = 0.f, ab = 0.f;
@@ -91,6 +84,54 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_tile(
     nz = f.noise + (size_t)n * out_h * out_w;
     nw = f.noise_w[0];
     ab = f.bias[plane - n * f.channels];
+  }
+  // Separable taps (every Blur of the networks: make_kernel is an outer product, networks.py:34-41): 4 horizontal +
+  // 4 vertical FMAs per output and a 4-value register window instead of 16 + 16.  The kernel is VALU-issue bound
+  // (~50 instructions per output in the 16-tap form), not bandwidth bound.  k[i][j] = a[i] * b[j] is checked on the
+  // taps themselves; anything else takes the general path below.
+  bool sep = kf[0] != 0.f;
+  float ka[4], kb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) kb[c] = kf[c];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ka[r] = kf[r * 4] / kf[0];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sep = sep & (fabsf(ka[r] * kb[c] - kf[r * 4 + c]) <= 1e-6f * fabsf(kf[r * 4 + c]));
+  if (sep) {
+    float h0, h1, h2;
+    {
+      const float* p = &sx[r0][lane];
+      h0 = p[0] * kb[0] + p[1] * kb[1] + p[2] * kb[2] + p[3] * kb[3];
+      p += TIN + 1;
+      h1 = p[0] * kb[0] + p[1] * kb[1] + p[2] * kb[2] + p[3] * kb[3];
+      p += TIN + 1;
+      h2 = p[0] * kb[0] + p[1] * kb[1] + p[2] * kb[2] + p[3] * kb[3];
+    }
+#pragma unroll
+    for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+      const float* p = &sx[r0 + rr + 3][lane];
+      const float h3 = p[0] * kb[0] + p[1] * kb[1] + p[2] * kb[2] + p[3] * kb[3];
+      float acc = h0 * ka[0] + h1 * ka[1] + h2 * ka[2] + h3 * ka[3];
+      const int oy = oy0 + r0 + rr;
+      if (oy < out_h && ox < out_w) {
+        if (EPI) {
+          const float t = acc + nw * nz[(size_t)oy * out_w + ox] + ab;
+          acc = (t > 0.f ? t : t * f.alpha) * f.gain;
+        }
+        dst[(size_t)oy * out_w + ox] = acc;
+      }
+      h0 = h1; h1 = h2; h2 = h3;
+    }
+    return;
+  }
+  float w0[4], w1[4], w2[4], w3[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    w0[c] = sx[r0 + 0][lane + c];
+    w1[c] = sx[r0 + 1][lane + c];
+    w2[c] = sx[r0 + 2][lane + c];
   }
 #pragma unroll
   for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
