@@ -1,7 +1,7 @@
 """SpatialTransformer / ComposedSTN / get_stn with the constructor arguments, state_dict layout and
 training-path forward semantics of models/spatial_transformers/spatial_transformer.py:11-139,
-388-615.  Point-transfer / flip / propagate helpers used only by the inference applications
-(:141-366, 617-726) are out of this round's scope."""
+388-615.  The point-transfer / flip / propagate helpers of the inference applications (:141-366,
+617-726) come from point_transfer.py (mixins)."""
 import math
 
 import torch
@@ -10,6 +10,7 @@ import torch.nn as nn
 from .antialiased_sampling import BilinearDownsample
 from .warping_heads import SimilarityHead, FlowHead
 from ..stylegan2.networks import EqualLinear, ConvLayer, ResBlock, CHANNELS
+from .point_transfer import ComposedStnPointOps, SingleStnPointOps, unravel_index  # noqa: F401
 
 
 def get_stn(transforms, **stn_kwargs):
@@ -21,7 +22,7 @@ def get_stn(transforms, **stn_kwargs):
     return ComposedSTN(transforms, **stn_kwargs)
 
 
-class SpatialTransformer(nn.Module):
+class SpatialTransformer(SingleStnPointOps, nn.Module):
     """ResNet trunk at flow_size^2 -> warp head.  Similarity: trunk goes down to 4x4 then a linear
     layer; flow: trunk stops at flow_size/flow_downsample and feeds the RAFT-style heads."""
 
@@ -106,7 +107,7 @@ class SpatialTransformer(nn.Module):
                               alpha=alpha, padding_mode=padding_mode, warp_policy=warp_policy, unfold=unfold)
 
 
-class ComposedSTN(nn.Module):
+class ComposedSTN(ComposedStnPointOps, nn.Module):
     """Chains STNs by composing warps (similarity -> flow)."""
 
     def __init__(self, transforms, **stn_kwargs):

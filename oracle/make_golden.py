@@ -350,6 +350,39 @@ def gen_cluster_classifier():
     save('cluster_classifier', cases)
 
 
+def gen_point_transfer():
+    """Key-point helpers of the STN (spatial_transformer.py:141-295, 617-720) on the reference modules."""
+    from models.spatial_transformers.spatial_transformer import get_stn
+    rules = (('warp_head.linear', 0.05), ('flow_out.2', 0.05), ('mask_out', 0.5))
+    cases = []
+    for ci, (transforms, flow_size, supersize) in enumerate([(['similarity'], 32, 32), (['similarity', 'flow'], 64, 64)]):
+        stn = get_stn(transforms, flow_size=flow_size, supersize=supersize, channel_multiplier=0.5, num_heads=1)
+        sd = det_state_dict(stn, rules)
+        torch.nn.Module.load_state_dict(stn, sd, strict=False)
+        stn.eval()
+        imgA = rnd(f'pt.a{ci}', (2, 3, supersize, supersize), 0.5)
+        imgB = rnd(f'pt.b{ci}', (2, 3, supersize, supersize), 0.5)
+        pts = (rnd(f'pt.p{ci}', (2, 7, 2), 1.0).abs() * 0.3 * supersize + 0.2 * supersize).clamp(0, supersize - 1)
+        pts_n = rnd(f'pt.pn{ci}', (2, 7, 2), 0.4).clamp(-0.9, 0.9)
+        with torch.no_grad():
+            kw = dict(padding_mode='border')
+            unc = stn.uncongeal_points(imgB, pts_n, **kw)
+            con = stn.congeal_points(imgA, pts, **kw)
+            tra = stn.transfer_points(imgA, imgB, pts, **kw)
+            case = dict(imgA=imgA, imgB=imgB, points=pts, points_norm=pts_n, uncongealed=unc,
+                        congealed=con.float(), transferred=tra,
+                        meta=dict(transforms=transforms, flow_size=flow_size, supersize=supersize,
+                                  scale_rules=[list(r) for r in rules]))
+            if 'flow' in transforms:
+                out, warp, flow, inputs, flips = stn.forward_with_flip(imgA, return_flow=True, return_warp=True,
+                                                                        return_inputs=True, return_flip_indices=True, **kw)
+                a2, b2, pa2, pb2, pick = stn.match_flows(imgA, imgB, pts, pts.flip(1), **kw)
+                case.update(fwf_out=out, fwf_warp=warp, fwf_flow=flow, fwf_flips=flips, mf_pointsA=pa2, mf_pointsB=pb2,
+                            mf_pick=pick)
+        cases.append(case)
+    save('point_transfer', cases)
+
+
 def gen_train_step():
     """One gangealing_loss evaluation (loss.py:64-75) at a plumbing-sized config with an MSE
     stand-in for the VGG loss (torchvision is not installed).  RNG-dependent inputs (z, per-layer
@@ -429,7 +462,8 @@ if __name__ == '__main__':
     only = sys.argv[1:]
     gens = dict(upfirdn2d=gen_upfirdn2d, fused_act=gen_fused_act, mipmap_warp=gen_mipmap_warp, heads=gen_heads,
                 misc=gen_misc, modconv=gen_modconv, generator=gen_generator, stn=gen_stn,
-                train_step=gen_train_step, splat=gen_splat_selfcheck, cluster_classifier=gen_cluster_classifier)
+                train_step=gen_train_step, splat=gen_splat_selfcheck, cluster_classifier=gen_cluster_classifier,
+                point_transfer=gen_point_transfer)
     for name, fn in gens.items():
         if only and name not in only:
             continue

@@ -269,3 +269,74 @@ def test_cluster_classifier_training_step(cuda):
     assert abs(float(metrics['assignments'].sum()) - 1.0) < 1e-6 and metrics['assignments'].numel() == 4
     assert any(float((p.detach() - b).abs().max()) > 0 for p, b in zip(cls.parameters(), before))
     assert torch.equal(tr.stn_arena.param, stn_before)
+
+
+@pytest.mark.parametrize('case', load_golden('point_transfer'), ids=lambda c: '+'.join(c['meta']['transforms']))
+def test_point_transfer_golden(case, cuda):
+    """Key-point helpers (uncongeal / congeal / transfer points, forward_with_flip, match_flows)
+    against the reference STN's own outputs (pixel coordinates)."""
+    from gangealing_amd.spatial_transformers.spatial_transformer import get_stn
+    m = case['meta']
+    stn = get_stn(m['transforms'], flow_size=m['flow_size'], supersize=m['supersize'], channel_multiplier=0.5,
+                  num_heads=1)
+    stn = load_det(stn, m['scale_rules']).to(cuda).eval()
+    imgA, imgB = T(case['imgA'], cuda), T(case['imgB'], cuda)
+    pts, pts_n = T(case['points'], cuda), T(case['points_norm'], cuda)
+    kw = dict(padding_mode='border')
+    with torch.no_grad():
+        unc = stn.uncongeal_points(imgB, pts_n, **kw)
+        close(unc, case['uncongealed'], 2e-2, 1e-4)                      # pixels
+        con = stn.congeal_points(imgA, pts, **kw).float()
+        ref = torch.from_numpy(case['congealed']).to(cuda)
+        if 'flow' in m['transforms']:
+            # nearest grid node: a near-tie may pick the neighbouring node
+            off = (con - ref).abs()
+            assert float(off.max()) <= 1.0 and float((off == 0).float().mean()) >= 0.85
+        else:
+            close(con, case['congealed'], 1e-3, 1e-4)                     # normalised coordinates
+        tra = stn.transfer_points(imgA, imgB, pts, **kw)
+        assert float((tra - T(case['transferred'], cuda)).abs().max()) <= (1.5 if 'flow' in m['transforms'] else 2e-2)
+        if 'flow' in m['transforms']:
+            out, warp, flow, inputs, flips = stn.forward_with_flip(imgA, return_flow=True, return_warp=True,
+                                                                    return_inputs=True, return_flip_indices=True, **kw)
+            assert np.array_equal(flips.cpu().numpy(), case['fwf_flips'])
+            close(out, case['fwf_out'], 5e-4)
+            close(warp, case['fwf_warp'], 5e-4)
+            close(flow, case['fwf_flow'], 5e-4)
+            _, _, pa2, pb2, pick = stn.match_flows(imgA, imgB, pts, pts.flip(1), **kw)
+            assert np.array_equal(pick.cpu().numpy(), case['mf_pick'])
+            close(pa2, case['mf_pointsA'], 1e-4)
+            close(pb2, case['mf_pointsB'], 1e-4)
+
+
+def test_propagate_object_splat(cuda):
+    """propagate_object = uncongeal_points + in-bounds selection + splat2d (the only caller of the splat kernel in the
+    reference, spatial_transformer.py:297-366).  Checked against the numpy splat restatement on the same moved points
+    (parity of the splat itself is unpinned: the reference op has no CPU path)."""
+    from gangealing_amd.spatial_transformers.spatial_transformer import get_stn
+    from oracle import np_ops
+    stn = get_stn(['similarity', 'flow'], flow_size=64, supersize=64, channel_multiplier=0.5, num_heads=1)
+    stn = load_det(stn, (('warp_head.linear', 0.05), ('flow_out.2', 0.05), ('mask_out', 0.5))).to(cuda).eval()
+    g = torch.Generator(device='cpu').manual_seed(2)
+    n, p = 2, 40
+    target = torch.randn(n, 3, 64, 64, generator=g).to(cuda)
+    pts = (torch.rand(n, p, 2, generator=g) * 2.4 - 1.2).to(cuda)             # some land outside the image
+    vals = torch.rand(n, p, 3, generator=g).to(cuda)
+    mvals = torch.ones(n, p, 1, device=cuda)
+    sigma = torch.tensor([1.0, 1.5], device=cuda)
+    with torch.no_grad():
+        obj, mask = stn.propagate_object(pts, vals, mvals, target, sigma, mem_efficient=True, padding_mode='border')
+        moved = stn.uncongeal_points(target, pts, normalize_input_points=False, unnormalize_output_points=True,
+                                     padding_mode='border')
+    assert obj.shape == (n, 3, 64, 64) and mask.shape == (n, 1, 64, 64)
+    for i in range(n):
+        r = moved[i].round()
+        keep = ((r[:, 0] >= 0) & (r[:, 1] >= 0) & (r[:, 0] < 64) & (r[:, 1] < 64)).cpu().numpy()
+        assert 0 < keep.sum() < p
+        blank = np.zeros((1, 3, 64, 64), np.float32)
+        ref_obj = np_ops.splat2d(blank, moved[i:i + 1].cpu().numpy()[:, keep], vals[i:i + 1].cpu().numpy()[:, keep],
+                                 sigma[i:i + 1].cpu().numpy(), False)
+        ref_mask = np_ops.splat2d(blank[:, :1], moved[i:i + 1].cpu().numpy()[:, keep],
+                                  mvals[i:i + 1].cpu().numpy()[:, keep], sigma[i:i + 1].cpu().numpy(), True)
+        close(obj[i:i + 1], ref_obj, 1e-4, 1e-4)
+        close(mask[i:i + 1], ref_mask, 1e-4, 1e-4)
