@@ -514,7 +514,9 @@ constexpr int patch_pixels(int tpix) { return (tpix / 64 + 2) * 66; }    // (TH+
 template <int LIMBS, bool IN_SCALE, int TPIX, int MI = 2>
 __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvArgs a, int tw_log2) {
   constexpr int TCO = MI * 64, NJ = 2, NT = TPIX * 2, PWAVES = TPIX / 64;
-  constexpr int PATCH_MAX = patch_pixels(TPIX);
+  // 3-limb rows are 240 bytes per pixel: 32-wide tiles ((4+2) x (32+2) patch pixels) keep the block under 80 KB of
+  // LDS, i.e. two blocks per CU instead of one
+  constexpr int PATCH_MAX = LIMBS == 3 ? 6 * 34 : patch_pixels(TPIX);
   // one LDS arena: [limb][patch rows] then [limb][weight rows]; reused as the epilogue staging buffer
   __shared__ __attribute__((aligned(16))) unsigned char smem[LIMBS * (PATCH_MAX + TCO) * ROWB];
   unsigned char (*sP)[PATCH_MAX * ROWB] = reinterpret_cast<unsigned char (*)[PATCH_MAX * ROWB]>(smem);
@@ -1799,11 +1801,12 @@ int post_activation(const ConvArgs& a, hipStream_t st) {
 }
 
 // 3x3 / stride 1 / pad 1 with a power-of-two width >= 16 whose 128-pixel tiles fit the image
-bool patch_geometry(const ConvArgs& a, int tpix, int& tw_log2) {
+bool patch_geometry(const ConvArgs& a, int tpix, int& tw_log2, int limbs = 2) {
   const int w = a.w, h = a.h;
   if (w < 16 || (w & (w - 1)) != 0) return false;
   if ((long long)a.cin_g * h * w * 4 >= (1LL << 31)) return false;        // buffer-resource addressing
-  int tw = w < 64 ? w : 64;
+  const int tw_max = limbs == 3 ? 32 : 64;
+  int tw = w < tw_max ? w : tw_max;
   tw_log2 = 0;
   while ((1 << tw_log2) < tw) ++tw_log2;
   const int th = tpix >> tw_log2;
@@ -1920,7 +1923,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     const long long tiles256 = (long long)a.batch * a.oh * a.ow / 256 * ((a.cout_g + 127) / 128) * a.groups;
     if (limbs == 2 && tiles256 >= 2 * gg::kNumCu && patch_geometry(a, 256, tw_log2))
       return launch_conv_patch(a, limbs, tw_log2, 256, st);
-    if (patch_geometry(a, 128, tw_log2)) return launch_conv_patch(a, limbs, tw_log2, 128, st);
+    if (patch_geometry(a, 128, tw_log2, limbs)) return launch_conv_patch(a, limbs, tw_log2, 128, st);
   }
   if (a.act) {            // no other kernel carries the activation in its epilogue
     ConvArgs plain = a;
