@@ -5,37 +5,56 @@
 // feats (2N, C, H, W): samples [0,N) are image 0, [N,2N) image 1 (one batched backbone pass).
 // As torch ops this is ~10 element-wise / reduction passes over the feature tensors forward and ~20 backward;
 // here the forward reads the features twice (norms, then the weighted squared difference - the second read hits the
-// Infinity Cache) and the backward reads them twice and writes the gradient once.  HBM-bound; lanes run along the
+// Infinity Cache) and the backward reads them twice (moments, then the gradient) and writes the gradient once.  HBM-bound; lanes run along the
 // pixel axis (contiguous in NCHW), channels are a strided loop.
 #include "../../include/gangealing_hip.h"
 #include "gg_common.h"
 
 namespace {
 
+// Block = 64 pixels (lanes, contiguous in NCHW) x 4 channel groups (waves): wave g handles channels g, g+4, ...;
+// per-pixel sums are combined through LDS.  (One thread per pixel walking all channels left the 8x8 / 16x16 taps with
+// 16 blocks of serial 512-channel loops.)
+constexpr int PIX = 64, CG = 4;
+
+template <int NV>
+__device__ __forceinline__ void pixel_sums(float (&v)[NV], float (*red)[NV][PIX], int px, int grp) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) red[grp][i][px] = v[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = red[0][i][px] + red[1][i][px] + red[2][i][px] + red[3][i][px];
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void lpips_tail_fwd_kernel(float* __restrict__ out, const float* __restrict__ f,
                                                              const float* __restrict__ lin, int n, int c,
                                                              long long hw, float eps, float inv_hw) {
-  __shared__ float red[4];
-  const int s = blockIdx.y;                                    // sample
+  __shared__ float red[CG][2][PIX];
+  __shared__ float red4[4];
+  const int s = blockIdx.y, px = threadIdx.x & (PIX - 1), grp = threadIdx.x >> 6;
   const float* f0 = f + (size_t)s * c * hw;
   const float* f1 = f + (size_t)(s + n) * c * hw;
   float acc = 0.f;
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < hw; p += (long long)gridDim.x * 256) {
-    float s00 = 0.f, s11 = 0.f;
-    for (int k = 0; k < c; ++k) {
-      const float a = f0[(size_t)k * hw + p], b = f1[(size_t)k * hw + p];
-      s00 += a * a;
-      s11 += b * b;
-    }
-    const float a0 = 1.f / (sqrtf(s00) + eps), a1 = 1.f / (sqrtf(s11) + eps);
-    float d = 0.f;
-    for (int k = 0; k < c; ++k) {
-      const float t = f0[(size_t)k * hw + p] * a0 - f1[(size_t)k * hw + p] * a1;
-      d += (lin ? lin[k] : 1.f) * t * t;
-    }
-    acc += d;
+  for (long long p0 = (long long)blockIdx.x * PIX; p0 < hw; p0 += (long long)gridDim.x * PIX) {
+    const long long p = p0 + px;
+    const bool ok = p < hw;
+    float v[2] = {0.f, 0.f};
+    if (ok)
+      for (int k = grp; k < c; k += CG) {
+        const float a = f0[(size_t)k * hw + p], b = f1[(size_t)k * hw + p];
+        v[0] += a * a;
+        v[1] += b * b;
+      }
+    pixel_sums<2>(v, red, px, grp);
+    const float a0 = 1.f / (sqrtf(v[0]) + eps), a1 = 1.f / (sqrtf(v[1]) + eps);
+    if (ok)
+      for (int k = grp; k < c; k += CG) {
+        const float t = f0[(size_t)k * hw + p] * a0 - f1[(size_t)k * hw + p] * a1;
+        acc += (lin ? lin[k] : 1.f) * t * t;
+      }
   }
-  const float tot = gg::block_sum_256<float>(acc, red);
+  const float tot = gg::block_sum_256<float>(acc, red4);
   if (threadIdx.x == 0) unsafeAtomicAdd(out + s, tot * inv_hw);
 }
 
@@ -44,42 +63,48 @@ __global__ __launch_bounds__(256) void lpips_tail_bwd_kernel(float* __restrict__
                                                              const float* __restrict__ lin,
                                                              const float* __restrict__ gout, int n, int c,
                                                              long long hw, float eps, float inv_hw) {
-  const int s = blockIdx.y;
+  __shared__ float red[CG][5][PIX];
+  const int s = blockIdx.y, px = threadIdx.x & (PIX - 1), grp = threadIdx.x >> 6;
   const float* f0 = f + (size_t)s * c * hw;
   const float* f1 = f + (size_t)(s + n) * c * hw;
   float* d0 = df + (size_t)s * c * hw;
   float* d1 = df + (size_t)(s + n) * c * hw;
   const float g2 = 2.f * gout[s] * inv_hw;
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < hw; p += (long long)gridDim.x * 256) {
-    float s00 = 0.f, s11 = 0.f;
-    for (int k = 0; k < c; ++k) {
-      const float a = f0[(size_t)k * hw + p], b = f1[(size_t)k * hw + p];
-      s00 += a * a;
-      s11 += b * b;
-    }
-    const float n0 = sqrtf(s00), n1 = sqrtf(s11);
+  for (long long p0 = (long long)blockIdx.x * PIX; p0 < hw; p0 += (long long)gridDim.x * PIX) {
+    const long long p = p0 + px;
+    const bool ok = p < hw;
+    // one pass gives the norms AND the two projections t0 = sum_k q[k] u0[k], t1 = -sum_k q[k] u1[k] through the
+    // lin-weighted moments (t0 = g2 (a0^2 W00 - a0 a1 W01)); their cancellation error is second order in |u0 - u1|
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};                  // s00, s11, w00, w11, w01
+    if (ok)
+      for (int k = grp; k < c; k += CG) {
+        const float a = f0[(size_t)k * hw + p], b = f1[(size_t)k * hw + p];
+        const float l = lin ? lin[k] : 1.f;
+        v[0] += a * a;
+        v[1] += b * b;
+        v[2] += l * a * a;
+        v[3] += l * b * b;
+        v[4] += l * a * b;
+      }
+    pixel_sums<5>(v, red, px, grp);
+    const float n0 = sqrtf(v[0]), n1 = sqrtf(v[1]);
     const float a0 = 1.f / (n0 + eps), a1 = 1.f / (n1 + eps);
-    // t0 = sum_k q[k] u0[k], t1 = sum_k (-q[k]) u1[k]
-    float t0 = 0.f, t1 = 0.f;
-    for (int k = 0; k < c; ++k) {
-      const float u0 = f0[(size_t)k * hw + p] * a0, u1 = f1[(size_t)k * hw + p] * a1;
-      const float q = g2 * (lin ? lin[k] : 1.f) * (u0 - u1);
-      t0 += q * u0;
-      t1 -= q * u1;
-    }
+    const float t0 = g2 * (a0 * a0 * v[2] - a0 * a1 * v[4]);
+    const float t1 = g2 * (a1 * a1 * v[3] - a0 * a1 * v[4]);
     const float r0 = n0 > 0.f ? t0 / n0 : 0.f, r1 = n1 > 0.f ? t1 / n1 : 0.f;
-    for (int k = 0; k < c; ++k) {
-      const float u0 = f0[(size_t)k * hw + p] * a0, u1 = f1[(size_t)k * hw + p] * a1;
-      const float q = g2 * (lin ? lin[k] : 1.f) * (u0 - u1);
-      d0[(size_t)k * hw + p] = a0 * q - u0 * r0;
-      d1[(size_t)k * hw + p] = -a1 * q - u1 * r1;
-    }
+    if (ok)
+      for (int k = grp; k < c; k += CG) {
+        const float u0 = f0[(size_t)k * hw + p] * a0, u1 = f1[(size_t)k * hw + p] * a1;
+        const float q = g2 * (lin ? lin[k] : 1.f) * (u0 - u1);
+        d0[(size_t)k * hw + p] = a0 * q - u0 * r0;
+        d1[(size_t)k * hw + p] = -a1 * q - u1 * r1;
+      }
   }
 }
 
 dim3 tail_grid(int n, long long hw) {
-  long long bx = (hw + 255) / 256;
-  if (bx > 4096) bx = 4096;
+  long long bx = (hw + PIX - 1) / PIX;
+  if (bx > 8192) bx = 8192;
   return dim3((unsigned)bx, (unsigned)n);
 }
 
