@@ -1116,7 +1116,7 @@ struct PackJob {
   int limbs;            // 0: fp32 GEMM layout (pack_weight_kernel); 2 | 3: bf16 limb planes
   float scale;
 };
-constexpr int PACK_MANY_BLOCKS = 48;
+constexpr int PACK_MANY_BLOCKS = 512;        // grid-stride workers per job (small jobs: most exit at once)
 
 __device__ __forceinline__ void pack_weight_body(float* __restrict__ wmat, const float* __restrict__ w, long long total,
                                                  int cout_g, int cin_g, int kh, int kw, int transpose_io, int flip,
