@@ -43,6 +43,7 @@ _PROTOS = {
     'gg_conv_pack_weight_f32': 'ppiiiiiiifs',
     'gg_conv2d_f32': 'ppppppiiiiiiiiiiiis',
     'gg_conv_pack_weight_split': 'ppiiiiiiifis',
+    'gg_conv3x3_masked_dgrad_f32': 'pppffpqippiiiiis',
     'gg_conv_pack_weights_many': 'pis',
     'gg_conv2d_split_f32': 'pppqipppiiiiiiiiiiiis',
     'gg_modconv3x3_act_f32': 'ppppqipppppffiiiiis',
@@ -117,9 +118,10 @@ def _dev_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def call(name, *args):
+def call(name, *args, allow=()):
     """Invoke a C-ABI entry point on torch's current HIP stream; the trailing stream argument is
-    supplied here.  Tensors are passed as raw device pointers."""
+    supplied here.  Tensors are passed as raw device pointers.  Returns the status code; codes other than 0 raise
+    unless listed in `allow` (e.g. 1 = "shape not served, nothing launched" of the optional fused entry points)."""
     lib = load()
     proto = _PROTOS[name]
     if len(args) != len(proto) - 1:
@@ -134,8 +136,9 @@ def call(name, *args):
             conv.append(float(a))
     conv.append(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     rc = getattr(lib, name)(*conv)
-    if rc != 0:
+    if rc != 0 and rc not in allow:
         raise HipLibraryError(f'{name} failed (code {rc}): {lib.gg_last_error().decode()}')
+    return rc
 
 
 def available():

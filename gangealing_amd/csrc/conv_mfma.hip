@@ -53,6 +53,10 @@ struct ConvArgs {
   const unsigned short* wsplit;   // bf16 limb planes [limb][g][co][k = (tap, ci)]  (split-precision path)
   long long wsplit_stride;        // elements between limb planes
   // optional StyledConv tail fused into the epilogue: y = lrelu(acc + noise_w[0]*noise[n,pix] + act_bias[co]) * gain
+  // optional leaky-ReLU gradient mask on the INPUT (data gradient of a conv + activation layer): the gathered
+  // element x is multiplied by (mask_ref > 0 ? 1 : mask_alpha) * mask_gain, mask_ref = the layer's saved output
+  const float* mask_ref;
+  float mask_alpha, mask_gain;
   int act;                        // 1: fused bias / noise / leaky-ReLU epilogue
   const float* act_noise;         // (N, 1, OH, OW) or null = no noise term
   const float* act_noise_w;       // device scalar
@@ -511,7 +515,7 @@ constexpr int patch_pixels(int tpix) { return (tpix / 64 + 2) * 66; }    // (TH+
 
 // MI = 32-row co sub-tiles per wave: 2 -> 128-channel tiles; 1 -> 64-channel tiles (layers with cout <= 64 would
 // otherwise spend half of their MFMAs on zero rows)
-template <int LIMBS, bool IN_SCALE, int TPIX, int MI = 2>
+template <int LIMBS, bool IN_SCALE, int TPIX, int MI = 2, bool MASK = false>
 __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvArgs a, int tw_log2) {
   constexpr int TCO = MI * 64, NJ = 2, NT = TPIX * 2, PWAVES = TPIX / 64;
   // 3-limb rows are 240 bytes per pixel: 32-wide tiles ((4+2) x (32+2) patch pixels) keep the block under 80 KB of
@@ -544,6 +548,8 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   // channel offset` (one address VGPR instead of 32 64-bit pointers), and lanes outside the image use an offset
   // beyond num_records, which the hardware range check turns into 0.0 (the zero padding) without a select
   const __amdgpu_buffer_rsrc_t xr = uniform_rsrc(a.x + (size_t)chan0 * hw, a.cin_g * hw * 4);
+  const __amdgpu_buffer_rsrc_t mr = MASK ? uniform_rsrc(a.mask_ref + (size_t)chan0 * hw, a.cin_g * hw * 4) : xr;
+  const float mpos = a.mask_gain, mneg = a.mask_gain * a.mask_alpha;
 
   // ---- patch gather: thread -> patch pixel `tid` (all 32 channels of the chunk); for TW = 64 the patch has
   //      264 pixels: the 8 left-over pixels x 32 channels are exactly one extra element per thread
@@ -581,6 +587,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   if (chunk1 > a.nslabs) chunk1 = a.nslabs;
 
   float xa[BKS], xl = 0.f;
+  float xm[MASK ? BKS : 1], xml = 0.f;           // saved activation output at the same positions (MASK)
   U4 wv[LIMBS][EPT / 8];
 
   auto load_patch = [&](int chunk) {
@@ -588,8 +595,18 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
 #pragma unroll
     for (int j = 0; j < BKS; ++j) xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
     xl = buffer_load_f32(xr, lvoff, cbase);
+    if (MASK) {
+#pragma unroll
+      for (int j = 0; j < BKS; ++j) xm[MASK ? j : 0] = buffer_load_f32(mr, pvoff, cbase + j * hw * 4);
+      xml = buffer_load_f32(mr, lvoff, cbase);
+    }
   };
   auto store_patch = [&](int chunk) {
+    if (MASK) {
+#pragma unroll
+      for (int j = 0; j < BKS; ++j) xa[j] *= xm[MASK ? j : 0] > 0.f ? mpos : mneg;
+      xl *= xml > 0.f ? mpos : mneg;
+    }
     if (pin) {
       if (IN_SCALE) {
 #pragma unroll
@@ -1840,7 +1857,21 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
   const bool sc = a.in_scale != nullptr;
   const ConvArgs full = a;
   if (a.splitk > 1) a.act = 0;                              // atomically combined partials: activation afterwards
-  if (narrow && tpix == 256) {
+  if (a.mask_ref) {          // limbs == 2 (checked by the caller)
+    if (narrow && tpix == 256) {
+      if (sc) conv3x3_patch_kernel<2, true, 256, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 256, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+    } else if (narrow) {
+      if (sc) conv3x3_patch_kernel<2, true, 128, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 128, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+    } else if (tpix == 256) {
+      if (sc) conv3x3_patch_kernel<2, true, 256, 2, true><<<grid, 512, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 256, 2, true><<<grid, 512, 0, st>>>(a, tw_log2);
+    } else {
+      if (sc) conv3x3_patch_kernel<2, true, 128, 2, true><<<grid, 256, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 128, 2, true><<<grid, 256, 0, st>>>(a, tw_log2);
+    }
+  } else if (narrow && tpix == 256) {
     if (sc) conv3x3_patch_kernel<2, true, 256, 1><<<grid, 512, 0, st>>>(a, tw_log2);
     else conv3x3_patch_kernel<2, false, 256, 1><<<grid, 512, 0, st>>>(a, tw_log2);
   } else if (narrow) {
@@ -1912,8 +1943,18 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   return gg::launch_status("convT3x3s2_patch");
 }
 
+constexpr int kNotFused = 1;      // masked-input request that no kernel serves: nothing was launched
+
 template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {
+  if (a.mask_ref) {
+    int tw_log2;
+    if (!(limbs == 2 && KS == 3 && mode == 0 && stride == 1 && pad == 1)) return kNotFused;
+    const long long tiles256 = (long long)a.batch * a.oh * a.ow / 256 * ((a.cout_g + 127) / 128) * a.groups;
+    if (tiles256 >= 2 * gg::kNumCu && patch_geometry(a, 256, tw_log2)) return launch_conv_patch(a, limbs, tw_log2, 256, st);
+    if (patch_geometry(a, 128, tw_log2)) return launch_conv_patch(a, limbs, tw_log2, 128, st);
+    return kNotFused;
+  }
   if (!a.act && limbs && KS == 3 && mode == 1 && pad <= 1 && a.w >= 4 && (a.w & (a.w - 1)) == 0 &&
       (long long)a.cin_g * a.h * a.w * 4 < (1LL << 31))
     return launch_convT_patch(a, limbs, pad, st);
@@ -1999,6 +2040,11 @@ extern "C" int gg_conv_pack_weight_f32(float* wmat, const float* w, int groups, 
 }
 
 namespace {
+struct MaskArgs {
+  const float* ref = nullptr;
+  float alpha = 0.f, gain = 1.f;
+};
+
 struct ActArgs {
   int on = 0;
   const float* noise = nullptr;
@@ -2010,7 +2056,7 @@ struct ActArgs {
 int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned short* wsplit, long long wsplit_stride,
                  int limbs, const float* in_scale, const float* out_scale, const float* bias, int batch, int groups,
                  int cin_g, int cout_g, int h, int w, int ksize, int stride, int pad, int mode, int out_h, int out_w,
-                 void* stream, const ActArgs& act = ActArgs()) {
+                 void* stream, const ActArgs& act = ActArgs(), const MaskArgs& mask = MaskArgs()) {
   if (batch <= 0 || groups <= 0 || cin_g <= 0 || cout_g <= 0) return 0;
   if (!y || !x || (!wmat && !wsplit) || h <= 0 || w <= 0) return gg::fail(-2, "conv2d: bad arguments");
   if (ksize != 1 && ksize != 3) return gg::fail(-2, "conv2d: kernel size %d not supported (1 or 3)", ksize);
@@ -2030,6 +2076,7 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   ConvArgs a;
   a.y = y; a.x = x; a.wmat = wmat; a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
   a.wsplit = wsplit; a.wsplit_stride = wsplit_stride;
+  a.mask_ref = mask.ref; a.mask_alpha = mask.alpha; a.mask_gain = mask.gain;
   a.act = act.on; a.act_noise = act.noise; a.act_noise_w = act.noise_w; a.act_bias = act.bias;
   a.act_alpha = act.alpha; a.act_gain = act.gain;
   a.batch = batch; a.groups = groups; a.cin_g = cin_g; a.cout_g = cout_g; a.h = h; a.w = w;
@@ -2080,6 +2127,18 @@ extern "C" int gg_modconv3x3_act_f32(float* y, const float* x, const float* wmat
   act.on = 1; act.noise = noise; act.noise_w = noise_weight; act.bias = act_bias; act.alpha = alpha; act.gain = gain;
   return conv2d_entry(y, x, limbs ? nullptr : wmat, limbs ? wsplit : nullptr, limb_stride, limbs, in_scale, out_scale,
                       nullptr, batch, 1, cin, cout, h, w, 3, 1, 1, 0, 0, 0, stream, act);
+}
+
+extern "C" int gg_conv3x3_masked_dgrad_f32(float* y, const float* x, const float* mask_ref, float alpha, float gain,
+                                           const unsigned short* wsplit, long long limb_stride, int limbs,
+                                           const float* in_scale, const float* out_scale, int batch, int cin,
+                                           int cout, int h, int w, void* stream) {
+  if (!mask_ref) return gg::fail(-2, "conv3x3_masked_dgrad: mask_ref missing");
+  if (limbs != 2) return kNotFused;
+  MaskArgs mask;
+  mask.ref = mask_ref; mask.alpha = alpha; mask.gain = gain;
+  return conv2d_entry(y, x, nullptr, wsplit, limb_stride, limbs, in_scale, out_scale, nullptr, batch, 1, cin, cout, h,
+                      w, 3, 1, 1, 0, 0, 0, stream, ActArgs(), mask);
 }
 
 extern "C" int gg_conv_pack_weights_many(const void* jobs, int njobs, void* stream) {

@@ -233,7 +233,8 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
 # backward adds the weight gradient straight into the slot (gg_conv2d_wgrad_acc_f32) and hands autograd no
 # gradient: no per-layer memset, no temporary and no AccumulateGrad add - two tiny launches less per layer.
 GRAD_SLOTS = {}
-# developer A/B switches (comma separated names in GG_DISABLE): slots, style_demod, fuse_act, wgrad_rows
+# developer A/B switches (comma separated names in GG_DISABLE): slots, style_demod, fuse_act, wgrad_rows, lpips_tail,
+# pack_registry, mask_dgrad
 DISABLED = frozenset(filter(None, os.environ.get('GG_DISABLE', '').split(',')))
 
 
@@ -377,8 +378,15 @@ class _Conv3x3BiasAct(Function):
         dy = dy.contiguous()
         n, cout, h, w = y.shape
         cin = x.shape[1]
+        need_db = has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[0] and not ctx.needs_input_grad[1] and not need_db:
+            # frozen layer (VGG backbone): only the data gradient is wanted - mask the gradient inside the conv
+            wm = packed(weight, 1, cin, cout, 3, 1, 1, wscale)
+            dx = masked_dgrad(dy, y, alpha, gain, wm, n, cout, cin, h, w)
+            if dx is not None:
+                return dx, None, None, None, None, None
         g = torch.empty_like(dy)
-        db = torch.empty(cout, dtype=torch.float32, device=dy.device) if (has_bias and ctx.needs_input_grad[2]) else None
+        db = torch.empty(cout, dtype=torch.float32, device=dy.device) if need_db else None
         _lib.call('gg_fused_lrelu_bwd_f32', g, db, dy, y, alpha, gain, n, cout, h * w)
         dx = dw = None
         if ctx.needs_input_grad[0]:
@@ -493,6 +501,20 @@ class _ModulatedConv(Function):
         return dx, dstyle, None, None, None, None, None, None, None
 
 
+def masked_dgrad(dy, y_act, alpha, gain, wmat_bwd, n, cin, cout, h, w, in_scale=None, out_scale=None):
+    """Data gradient of a 3x3 conv + leaky-ReLU layer with the activation's backward applied while the gradient is
+    gathered (gg_conv3x3_masked_dgrad_f32): no separate masked-gradient tensor.  `cin` = reduction channels (the
+    layer's output channels), `cout` = the layer's input channels.  None when the shape is not served."""
+    if _LIMBS[PRECISION] != 2 or 'mask_dgrad' in DISABLED or not isinstance(wmat_bwd, PackedWeight) or \
+            not wmat_bwd.split_ok():
+        return None
+    wbuf, stride_l = wmat_bwd.split(2)
+    dx = torch.empty((n, cout, h, w), dtype=torch.float32, device=dy.device)
+    rc = _lib.call('gg_conv3x3_masked_dgrad_f32', dx, dy, y_act, alpha, gain, wbuf, stride_l, 2, in_scale, out_scale,
+                   n, cin, cout, h, w, allow=(1,))
+    return dx if rc == 0 else None
+
+
 class _ModulatedConvAct(Function):
     """StyledConv without upsampling, in one kernel: lrelu(demod * conv(W, style * x) + nw * noise + b) * gain
     (networks.py:243-298, 344-350).  Used when no gradient is wanted for the style, the noise weight or the
@@ -524,10 +546,12 @@ class _ModulatedConvAct(Function):
             return (None,) * 12
         dy = dy.contiguous()
         n, cout, h, w = y.shape
-        g = torch.empty_like(dy)
-        _lib.call('gg_fused_lrelu_bwd_f32', g, None, dy, y, alpha, gain, n, cout, h * w)
-        dx = conv_forward(g, ctx.wmat_bwd, n, 1, cout, cin, 3, 1, 1, 0, in_scale=demod if demodulate else None,
-                          out_scale=style)
+        dx = masked_dgrad(dy, y, alpha, gain, ctx.wmat_bwd, n, cout, cin, h, w, demod if demodulate else None, style)
+        if dx is None:
+            g = torch.empty_like(dy)
+            _lib.call('gg_fused_lrelu_bwd_f32', g, None, dy, y, alpha, gain, n, cout, h * w)
+            dx = conv_forward(g, ctx.wmat_bwd, n, 1, cout, cin, 3, 1, 1, 0, in_scale=demod if demodulate else None,
+                              out_scale=style)
         return (dx,) + (None,) * 11
 
 

@@ -221,6 +221,14 @@ int gg_conv2d_f32(float* y, const float* x, const float* wmat, const float* in_s
  * Requires cin_g % 32 == 0; every other argument as gg_conv2d_f32. */
 int gg_conv_pack_weight_split(unsigned short* wsplit, const float* w, int groups, int cout_g, int cin_g, int kh,
                               int kw, int transpose_io, int flip, float scale, int limbs, void* stream);
+/* Data gradient of a "3x3 conv + leaky ReLU" layer with the activation's backward fused into the gather:
+ *   y = out_scale * conv3x3(W, in_scale * x * (mask_ref > 0 ? 1 : alpha) * gain)      (stride 1, pad 1, split precision)
+ * x = the incoming gradient, mask_ref = the layer's saved activation OUTPUT (same shape as x), W = the data-gradient
+ * pack (flipped / transposed taps).  Only the patch-reuse kernel carries the mask: the call returns 1 and launches
+ * NOTHING when the shape is not served by it (caller: gg_fused_lrelu_bwd_f32 followed by gg_conv2d_split_f32). */
+int gg_conv3x3_masked_dgrad_f32(float* y, const float* x, const float* mask_ref, float alpha, float gain,
+                                const unsigned short* wsplit, long long limb_stride, int limbs, const float* in_scale,
+                                const float* out_scale, int batch, int cin, int cout, int h, int w, void* stream);
 /* Many weight packs in one launch.  `jobs`: device array of `njobs` records
  *   struct { void* dst; const float* src; long long total, limb_stride;
  *            int cout_g, cin_g, kh, kw, transpose_io, flip, limbs; float scale; }          (64 bytes each)

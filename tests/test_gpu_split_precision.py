@@ -186,3 +186,26 @@ def test_conv3x3_bias_act_matches_unfused(shape, mode_name, cuda, precision):
         assert float((fused - ref).detach().abs().max()) <= 2e-6 * float(ref.detach().abs().max())
         for a_, r_ in zip(gf, gr):
             assert float((a_ - r_).abs().max()) <= 1e-5 * float(r_.abs().max()) + 1e-7
+
+
+def test_masked_dgrad_serves_patch_shapes_only(cuda, precision):
+    """gg_conv3x3_masked_dgrad_f32 fuses the leaky-ReLU backward into the data gradient where the patch-reuse kernel
+    runs, and reports "not served" (no launch) elsewhere; the result equals lrelu-backward followed by the conv."""
+    from gangealing_amd.op import conv_mfma as cm
+    from gangealing_amd import _lib
+    precision('bf16x3')
+    g = torch.Generator(device='cpu').manual_seed(21)
+    w = (torch.randn(64, 96, 3, 3, generator=g) / 30).to(cuda)            # layer: 96 -> 64 channels
+    pw = cm.PackedWeight(w, 1, 96, 64, 3, 1, 1, 1.0)                       # data-gradient pack (reduce over 64)
+    for res, served in ((32, True), (4, False)):
+        dy = torch.randn(2, 64, res, res, generator=g).to(cuda)
+        y = torch.randn(2, 64, res, res, generator=g).to(cuda)
+        dx = cm.masked_dgrad(dy, y, 0.2, 2 ** 0.5, pw, 2, 64, 96, res, res)
+        assert (dx is not None) == served
+        if served:
+            gm = torch.empty_like(dy)
+            _lib.call('gg_fused_lrelu_bwd_f32', gm, None, dy, y, 0.2, 2 ** 0.5, 2, 64, res * res)
+            ref = cm.conv_forward(gm, pw, 2, 1, 64, 96, 3, 1, 1, 0)
+            assert float((dx - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    precision('fp32')
+    assert cm.masked_dgrad(dy, y, 0.2, 1.0, pw, 2, 64, 96, 4, 4) is None
