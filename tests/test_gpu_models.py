@@ -340,3 +340,38 @@ def test_propagate_object_splat(cuda):
                                   mvals[i:i + 1].cpu().numpy()[:, keep], sigma[i:i + 1].cpu().numpy(), True)
         close(obj[i:i + 1], ref_obj, 1e-4, 1e-4)
         close(mask[i:i + 1], ref_mask, 1e-4, 1e-4)
+
+
+def test_trainer_shortcuts_are_consistent_across_optimizer_steps(cuda):
+    """At every one of three consecutive optimizer steps the loss and the gradient arena computed with all
+    caller-side shortcuts on (one-launch weight re-pack validated by version counters, wgrad accumulating into the
+    arena, fused epilogues / tails, masked data gradient) equal those recomputed on the SAME parameters with the
+    shortcuts off.  A stale weight pack after the raw-pointer Adam update would show up at step 2."""
+    from gangealing_amd.op import conv_mfma
+    from gangealing_amd.train_step import GangealingTrainer
+    tr = GangealingTrainer(cuda, gen_size=64, flow_size=64, batch=2, transform=('similarity', 'flow'), inject=3,
+                           ndirs=2, perturb_heads=0.02, seed=5)
+    off = frozenset(('slots', 'pack_registry', 'style_demod', 'fuse_act', 'lpips_tail', 'mask_dgrad', 'wgrad_rows'))
+
+    def loss_and_grad(disabled, seed):
+        old = conv_mfma.DISABLED
+        conv_mfma.DISABLED = disabled
+        try:
+            torch.manual_seed(seed)
+            tr.stn_arena.zero_grad()
+            tr.ll_arena.zero_grad()
+            total, _ = tr.loss(0.5)
+            total.backward()
+            return float(total.detach()), tr.stn_arena.grad.clone(), tr.ll_arena.grad.clone()
+        finally:
+            conv_mfma.DISABLED = old
+
+    for step in range(3):
+        l_off, g_off, gl_off = loss_and_grad(off, 100 + step)
+        l_on, g_on, gl_on = loss_and_grad(frozenset(), 100 + step)
+        assert abs(l_on - l_off) <= 2e-5 * abs(l_off), (step, l_on, l_off)
+        assert float((g_on - g_off).abs().max()) <= 2e-3 * float(g_off.abs().max()), step
+        assert float((gl_on - gl_off).abs().max()) <= 2e-3 * float(gl_off.abs().max()) + 1e-9, step
+        torch.manual_seed(100 + step)
+        tr.step(psi=0.5)                                   # optimizer + EMA + re-pack, shortcuts on
+    assert torch.isfinite(tr.stn_arena.param).all()
