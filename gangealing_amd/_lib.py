@@ -51,6 +51,7 @@ _PROTOS = {
     'gg_conv2d_wgrad_split_f32': 'pppiiiiiiiiifis',
     'gg_conv2d_wgrad_acc_f32': 'pppiiiiiiiiifis',
     'gg_conv2d_wgrad_ws_f32': 'pppiiiiiiiiifiipqs',
+    'gg_conv3x3_masked_wgrad_f32': 'pppppffiiiiifiipqs',
     'gg_style_demod_f32': 'pppqpppiiiifffs',
     'gg_lpips_tail_fwd_f32': 'pppiiqfs',
     'gg_lpips_tail_bwd_f32': 'ppppiiqfs',

@@ -1172,6 +1172,12 @@ struct WgradArgs {
   long long ktot;               // batch*oh*ow
   long long k_per_split;
   float scale;
+  // optional (row-streaming kernel): dy is the gradient w.r.t. a leaky-ReLU OUTPUT; the activation's backward
+  // dy * (mask_ref > 0 ? 1 : mask_alpha) * mask_gain is applied while dy is staged, and its per-channel sum (the
+  // bias gradient) is accumulated into dbias
+  const float* mask_ref;
+  float mask_alpha, mask_gain;
+  float* dbias;
 };
 
 template <int KS>
@@ -1472,9 +1478,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradArgs a
 constexpr int WR_XROW = 96;                  // bytes per x row slot: 48 bf16 = 8 halo + 32 + 8 halo
 constexpr int WR_XS = 3 * WR_XROW + 16;      // bytes per ci (odd multiple of 16 -> conflict-free lane stride)
 
-template <int LIMBS, int TCO, int TCI>
+template <int LIMBS, int TCO, int TCI, bool MASK = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradArgs a, int segs, int rblocks,
-                                                                    int rows_per_block, float* __restrict__ ws) {
+                                                                    int rows_per_block, float* __restrict__ ws,
+                                                                    float* __restrict__ dbws) {
   static_assert(TCO * TCI == 4096, "four waves of 32 co x 32 ci");
   constexpr int WCI = TCI / 32;                       // ci waves; co waves = 4 / WCI
   constexpr int DPARTS = 256 / TCO, DPX = 32 / DPARTS;        // dy: threads per row, pixels per thread
@@ -1501,13 +1508,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
   if (y1 > a.h) y1 = a.h;
   const int hw = a.h * a.w;
 
-  const float* dyn = a.dy + ((size_t)(n * a.groups + g) * a.cout_g) * hw;
   const float* xn = a.x + ((size_t)(n * a.groups + g) * a.cin_g) * hw;
 
   // ---- dy mover: row drow, pixels dpart*DPX .. +DPX
   const int drow = tid / DPARTS, dpart = tid % DPARTS;
   const bool d_ok = (co0 + drow) < a.cout_g;
-  const float* dsrc = dyn + (size_t)(d_ok ? co0 + drow : 0) * hw + c0 + dpart * DPX;
+  const size_t doff = ((size_t)(n * a.groups + g) * a.cout_g + (d_ok ? co0 + drow : 0)) * hw + c0 + dpart * DPX;
+  const float* dsrc = a.dy + doff;
+  const float* msrc = MASK ? a.mask_ref + doff : nullptr;
+  const float mpos = a.mask_gain, mneg = a.mask_gain * a.mask_alpha;
+  float bsum = 0.f;                               // this thread's share of the bias gradient (MASK)
   // ---- x mover: items (ci, 4-pixel group)
   int xci[XPT], xsub[XPT];
   bool x_ok[XPT];
@@ -1520,13 +1530,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
   }
 
   float4 rd[DPX / 4];
+  float4 rm[MASK ? DPX / 4 : 1];
   float4 rx[XPT];
   float rh[XPT];                                   // halo pixel (left for sub 0, right for sub 7)
   auto load_dy = [&](int y) {
     const bool ok = d_ok & (y < y1);
 #pragma unroll
-    for (int q = 0; q < DPX / 4; ++q)
+    for (int q = 0; q < DPX / 4; ++q) {
       rd[q] = ok ? *reinterpret_cast<const float4*>(dsrc + (size_t)y * a.w + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MASK)
+        rm[MASK ? q : 0] = ok ? *reinterpret_cast<const float4*>(msrc + (size_t)y * a.w + q * 4)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   };
   auto load_x = [&](int row) {
     const bool rok = (unsigned)row < (unsigned)a.h;
@@ -1544,6 +1559,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
     float v[DPX];
 #pragma unroll
     for (int q = 0; q < DPX / 4; ++q) { v[4 * q] = rd[q].x; v[4 * q + 1] = rd[q].y; v[4 * q + 2] = rd[q].z; v[4 * q + 3] = rd[q].w; }
+    if (MASK) {
+#pragma unroll
+      for (int q = 0; q < DPX / 4; ++q) {
+        const float4 m = rm[MASK ? q : 0];
+        v[4 * q] *= m.x > 0.f ? mpos : mneg;
+        v[4 * q + 1] *= m.y > 0.f ? mpos : mneg;
+        v[4 * q + 2] *= m.z > 0.f ? mpos : mneg;
+        v[4 * q + 3] *= m.w > 0.f ? mpos : mneg;
+      }
+#pragma unroll
+      for (int i = 0; i < DPX; ++i) bsum += v[i];
+    }
 #pragma unroll
     for (int l = 0; l < LIMBS; ++l) {
       unsigned pk[DPX / 2];
@@ -1642,6 +1669,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
     }
   }
 
+  if (MASK && dbws && tile_ci == 0) {
+    // bias gradient: per-row sums of this block (LDS atomics), one plain store per (split, channel); summed by
+    // wgrad_reduce_kernel.  (Global atomics onto the <= 512 bias addresses from every block serialise.)
+    float* sdb = reinterpret_cast<float*>(&sD[0][0]);          // the main loop's last barrier freed sD
+    if (tid < TCO) sdb[tid] = 0.f;
+    __syncthreads();
+    atomicAdd(&sdb[drow], bsum);
+    __syncthreads();
+    if (tid < TCO && co0 + tid < a.cout_g)
+      dbws[((size_t)blockIdx.y * a.groups + g) * a.cout_g + co0 + tid] = sdb[tid];
+  }
   if (ws) {
     // partial tile -> workspace [tile][split][tap][co][ci] (ci fastest: 128-byte runs per store); summed by
     // wgrad_reduce_kernel.  (Atomics straight into dw serialise: blocks x 36,864 adds onto few addresses.)
@@ -1674,9 +1712,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ ws,
                                                            int groups, int cout_g, int cin_g, int tiles_co,
                                                            int tiles_ci, int tco, int tci, int splits, float scale,
-                                                           int accumulate) {
+                                                           int accumulate, float* __restrict__ dbias,
+                                                           const float* __restrict__ dbws) {
   const size_t tile_elems = (size_t)9 * tco * tci;
   const size_t total = (size_t)groups * tiles_co * tiles_ci * tile_elems;
+  if (dbias) {        // bias gradient: dbias[c] += sum over splits of the per-block row sums
+    const int channels = groups * cout_g;
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < (size_t)channels; c += (size_t)gridDim.x * 256) {
+      float sum = 0.f;
+      for (int sidx = 0; sidx < splits; ++sidx) sum += dbws[(size_t)sidx * channels + c];
+      dbias[c] += sum;
+    }
+  }
   for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
     const size_t tile = o / tile_elems;
     const int e = (int)(o - tile * tile_elems);
@@ -2163,7 +2210,8 @@ extern "C" int gg_conv_pack_weight_split(unsigned short* wsplit, const float* w,
 namespace {
 int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g, int cout_g, int h,
                 int w, int ksize, int stride, int pad, float scale, int limbs, void* stream, bool accumulate = false,
-                float* workspace = nullptr, long long workspace_bytes = 0) {
+                float* workspace = nullptr, long long workspace_bytes = 0, const float* mask_ref = nullptr,
+                float mask_alpha = 0.f, float mask_gain = 1.f, float* dbias = nullptr) {
   if (groups <= 0 || cin_g <= 0 || cout_g <= 0) return 0;
   if (!dw || !x || !dy) return gg::fail(-2, "conv2d_wgrad: null pointer");
   if (ksize != 1 && ksize != 3) return gg::fail(-2, "conv2d_wgrad: kernel size must be 1 or 3");
@@ -2175,6 +2223,7 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
   a.oh = (h + 2 * pad - ksize) / stride + 1;
   a.ow = (w + 2 * pad - ksize) / stride + 1;
   a.stride = stride; a.pad = pad; a.scale = scale;
+  a.mask_ref = mask_ref; a.mask_alpha = mask_alpha; a.mask_gain = mask_gain; a.dbias = dbias;
   a.jtot = cin_g * ksize * ksize;
   auto zero_dw = [&]() -> int {  // the kernels combine their K-splits with atomic adds: start from zero unless adding
     if (accumulate) return 0;
@@ -2204,25 +2253,31 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
     const int rows_per_block = (int)((a.h + rblocks - 1) / rblocks);
     rblocks = (a.h + rows_per_block - 1) / rows_per_block;
     const long long splits = units * rblocks;
-    const long long need = tiles * splits * 9LL * 4096 * (long long)sizeof(float);
+    const long long need_dw = tiles * splits * 9LL * 4096 * (long long)sizeof(float);
+    const long long need = need_dw + (dbias ? splits * (long long)groups * cout_g * (long long)sizeof(float) : 0);
+    float* dbws = dbias ? workspace + need_dw / sizeof(float) : nullptr;
     if (workspace && workspace_bytes >= need && splits <= 65535 && (long long)a.tiles_co * a.tiles_j < (1LL << 31)) {
       dim3 grid((unsigned)(a.tiles_co * a.tiles_j), (unsigned)splits, (unsigned)groups);
-      if (limbs == 2) {
-        if (narrow) conv3x3_wgrad_rows_kernel<2, 64, 64><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace);
-        else conv3x3_wgrad_rows_kernel<2, 128, 32><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace);
+      if (a.mask_ref) {          // limbs == 2 (checked by the entry point)
+        if (narrow) conv3x3_wgrad_rows_kernel<2, 64, 64, true><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace, dbws);
+        else conv3x3_wgrad_rows_kernel<2, 128, 32, true><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace, dbws);
+      } else if (limbs == 2) {
+        if (narrow) conv3x3_wgrad_rows_kernel<2, 64, 64><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace, dbws);
+        else conv3x3_wgrad_rows_kernel<2, 128, 32><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace, dbws);
       } else {
-        if (narrow) conv3x3_wgrad_rows_kernel<3, 64, 64><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace);
-        else conv3x3_wgrad_rows_kernel<3, 128, 32><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace);
+        if (narrow) conv3x3_wgrad_rows_kernel<3, 64, 64><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace, dbws);
+        else conv3x3_wgrad_rows_kernel<3, 128, 32><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace, dbws);
       }
       int rc = gg::launch_status("conv3x3_wgrad_rows");
       if (rc) return rc;
       const long long total = tiles * 9LL * 4096;
       wgrad_reduce_kernel<<<gg::stream_grid(total, 256), 256, 0, st>>>(dw, workspace, groups, cout_g, cin_g, a.tiles_co,
                                                                       a.tiles_j, tco, tci, (int)splits, scale,
-                                                                      accumulate ? 1 : 0);
+                                                                      accumulate ? 1 : 0, dbias, dbws);
       return gg::launch_status("wgrad_reduce");
     }
   }
+  if (mask_ref) return kNotFused;          // only the row-streaming kernel applies the mask; nothing was launched
   if (int rc = zero_dw()) return rc;
   a.ktot = (long long)batch * a.oh * a.ow;
   a.tiles_co = (cout_g + WT - 1) / WT;
@@ -2278,6 +2333,16 @@ extern "C" int gg_conv2d_wgrad_ws_f32(float* dw, const float* x, const float* dy
                                       void* stream) {
   return wgrad_entry(dw, x, dy, batch, groups, cin_g, cout_g, h, w, ksize, stride, pad, scale, limbs, stream,
                      accumulate != 0, workspace, workspace_bytes);
+}
+
+extern "C" int gg_conv3x3_masked_wgrad_f32(float* dw, float* dbias, const float* x, const float* dy,
+                                           const float* mask_ref, float alpha, float gain, int batch, int cin,
+                                           int cout, int h, int w, float scale, int limbs, int accumulate,
+                                           float* workspace, long long workspace_bytes, void* stream) {
+  if (!mask_ref) return gg::fail(-2, "conv3x3_masked_wgrad: mask_ref missing");
+  if (limbs != 2 || (reinterpret_cast<uintptr_t>(mask_ref) & 15)) return kNotFused;
+  return wgrad_entry(dw, x, dy, batch, 1, cin, cout, h, w, 3, 1, 1, scale, limbs, stream, accumulate != 0, workspace,
+                     workspace_bytes, mask_ref, alpha, gain, dbias);
 }
 
 extern "C" int gg_plane_dot_f32(float* out, const float* a, const float* b, int planes, long long hw, void* stream) {

@@ -236,6 +236,10 @@ GRAD_SLOTS = {}
 # developer A/B switches (comma separated names in GG_DISABLE): slots, style_demod, fuse_act, wgrad_rows, lpips_tail,
 # pack_registry, mask_dgrad
 DISABLED = frozenset(filter(None, os.environ.get('GG_DISABLE', '').split(',')))
+# opt-in paths (GG_ENABLE): mask_wgrad - leaky-ReLU backward inside BOTH gradient kernels of a trainable conv+act layer
+# (gg_conv3x3_masked_wgrad_f32).  Measured 1 % SLOWER than the separate 5 TB/s mask pass on the STN shapes (the masked
+# kernels read a second tensor), so it is off by default; the frozen layers use the masked data gradient only.
+ENABLED = frozenset(filter(None, os.environ.get('GG_ENABLE', '').split(',')))
 
 
 _WORKSPACES = {}
@@ -385,6 +389,26 @@ class _Conv3x3BiasAct(Function):
             dx = masked_dgrad(dy, y, alpha, gain, wm, n, cout, cin, h, w)
             if dx is not None:
                 return dx, None, None, None, None, None
+        slot = None
+        if ctx.needs_input_grad[1]:
+            slot = GRAD_SLOTS.get(weight.data_ptr()) if (GRAD_SLOTS and 'slots' not in DISABLED) else None
+            if slot is not None and (slot.shape != weight.shape or not slot.is_contiguous()):
+                slot = None
+        if ctx.needs_input_grad[1] and _LIMBS[PRECISION] == 2 and w % 32 == 0 and 'mask_wgrad' in ENABLED \
+                and 'wgrad_rows' not in DISABLED:
+            # trainable layer on the row-streaming wgrad kernel: the leaky-ReLU backward rides in the loaders of both
+            # gradient kernels (and the bias gradient in the wgrad kernel), so the masked gradient is never written
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = masked_dgrad(dy, y, alpha, gain, packed(weight, 1, cin, cout, 3, 1, 1, wscale), n, cout, cin, h, w)
+            if dx is not None or not ctx.needs_input_grad[0]:
+                db = torch.zeros(cout, dtype=torch.float32, device=dy.device) if need_db else None
+                dw = slot if slot is not None else torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dy.device)
+                ws = _workspace(dy.device, 1200 * 147456)
+                rc = _lib.call('gg_conv3x3_masked_wgrad_f32', dw, db, x, dy, y, alpha, gain, n, cin, cout, h, w, wscale,
+                               2, 1 if slot is not None else 0, ws, ws.numel() * 4, allow=(1,))
+                if rc == 0:
+                    return dx, (None if slot is not None else dw), db, None, None, None
         g = torch.empty_like(dy)
         db = torch.empty(cout, dtype=torch.float32, device=dy.device) if need_db else None
         _lib.call('gg_fused_lrelu_bwd_f32', g, db, dy, y, alpha, gain, n, cout, h * w)
@@ -393,9 +417,6 @@ class _Conv3x3BiasAct(Function):
             wm = packed(weight, 1, cin, cout, 3, 1, 1, wscale)
             dx = conv_forward(g, wm, n, 1, cout, cin, 3, 1, 1, 0)
         if ctx.needs_input_grad[1]:
-            slot = GRAD_SLOTS.get(weight.data_ptr()) if (GRAD_SLOTS and 'slots' not in DISABLED) else None
-            if slot is not None and (slot.shape != weight.shape or not slot.is_contiguous()):
-                slot = None
             dw = conv_wgrad(x, g, n, 1, cin, cout, 3, 1, 1, wscale, into=slot)
         return dx, dw, db, None, None, None
 

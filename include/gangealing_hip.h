@@ -275,6 +275,14 @@ int gg_conv2d_wgrad_acc_f32(float* dw, const float* x, const float* dy, int batc
 int gg_conv2d_wgrad_ws_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g, int cout_g,
                            int h, int w, int ksize, int stride, int pad, float scale, int limbs, int accumulate,
                            float* workspace, long long workspace_bytes, void* stream);
+/* Weight (and bias) gradient of a "3x3 conv + bias + leaky ReLU" layer from the gradient of its OUTPUT: the
+ * activation's backward dy * (mask_ref > 0 ? 1 : alpha) * gain is applied while dy is staged (mask_ref = the saved
+ * output), dw (=/+=) as gg_conv2d_wgrad_ws_f32 and, if dbias != NULL, dbias[co] += sum of the masked gradient
+ * (dbias must be initialised by the caller).  Returns 1 and launches nothing when the row-streaming kernel does not
+ * serve the shape (W % 32 != 0, limbs != 2, workspace too small ...). */
+int gg_conv3x3_masked_wgrad_f32(float* dw, float* dbias, const float* x, const float* dy, const float* mask_ref,
+                                float alpha, float gain, int batch, int cin, int cout, int h, int w, float scale,
+                                int limbs, int accumulate, float* workspace, long long workspace_bytes, void* stream);
 /* Style modulation of one ModulatedConv2d layer in one launch (networks.py:214-216 EqualLinear + :244-249):
  *   style[n,ci] = sum_k latent[n*lat_stride + k] * w[ci,k] * w_scale + b[ci] * b_scale      (b may be NULL)
  *   demod[n,co] = rsqrt(sum_ci style[n,ci]^2 * wsq[co,ci] + eps)                             (demod may be NULL)

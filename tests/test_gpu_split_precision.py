@@ -163,7 +163,8 @@ def test_row_streaming_wgrad_matches_fp32_kernel(spec, mode_name, tol, cuda, pre
 
 
 @pytest.mark.parametrize('mode_name', ['fp32', 'bf16x3'])
-@pytest.mark.parametrize('shape', [(2, 64, 64, 32, 32), (1, 128, 96, 16, 16), (3, 32, 64, 8, 12), (1, 512, 512, 4, 4)],
+@pytest.mark.parametrize('shape', [(2, 64, 64, 32, 32), (1, 128, 96, 16, 16), (3, 32, 64, 8, 12), (1, 512, 512, 4, 4),
+                                   (2, 96, 160, 24, 64), (4, 64, 64, 128, 128)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_conv3x3_bias_act_matches_unfused(shape, mode_name, cuda, precision):
     """conv + bias + leaky ReLU in the convolution's epilogue (STN ConvLayer / VGG conv+ReLU) == conv, then
@@ -177,13 +178,15 @@ def test_conv3x3_bias_act_matches_unfused(shape, mode_name, cuda, precision):
     wt = torch.randn(cout, cin, 3, 3, generator=g).to(cuda).requires_grad_(True)
     b = torch.randn(cout, generator=g).to(cuda).requires_grad_(True)
     scale = (cin * 9) ** -0.5
-    for alpha, gain in ((0.2, 2 ** 0.5), (0.0, 1.0)):
+    for alpha, gain, opt_in in ((0.2, 2 ** 0.5, ()), (0.0, 1.0, ()), (0.2, 2 ** 0.5, ('mask_wgrad',))):
+        cm.ENABLED = frozenset(opt_in)           # opt-in: activation backward inside both gradient kernels
         fused = cm.conv3x3_bias_act(x, wt, b, alpha, gain, weight_scale=scale)
         go = torch.randn_like(fused)
         gf = torch.autograd.grad(fused, (x, wt, b), go)
         ref = fused_leaky_relu(cm.conv2d(x, wt, None, 1, 1, weight_scale=scale), b, alpha, gain)
         gr = torch.autograd.grad(ref, (x, wt, b), go)
         assert float((fused - ref).detach().abs().max()) <= 2e-6 * float(ref.detach().abs().max())
+        cm.ENABLED = frozenset()
         for a_, r_ in zip(gf, gr):
             assert float((a_ - r_).abs().max()) <= 1e-5 * float(r_.abs().max()) + 1e-7
 
