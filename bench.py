@@ -128,9 +128,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    # developer switches for exercising the multi-process path on a one-GPU box: all ranks on cuda:0 and a gloo
+    # process group (RCCL refuses two ranks on one device); the driver's runs use neither
+    if os.environ.get('GANGEALING_SHARE_DEVICE'):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    gdist.setup_distributed('nccl')
+    gdist.setup_distributed(os.environ.get('GANGEALING_DIST_BACKEND', 'nccl'))
     rank = gdist.get_rank()
 
     wl = dict(WORKLOADS[args.workload])
