@@ -102,8 +102,9 @@ class GangealingTrainer:
                  num_heads=1, flips=False, dim_latent=512, n_mlp=8, gen_channel_multiplier=2,
                  stn_channel_multiplier=0.5, inject=5, ndirs=1, padding_mode='reflection', tv_weight=1000.0,
                  flow_identity_weight=1.0, stn_lr=1e-3, ll_lr=1e-2, sample_from_full_res=False, freeze_ll=False,
-                 loss_fn='vgg_ssl', seed=0, perturb_heads=0.0):
+                 loss_fn='vgg_ssl', seed=0, perturb_heads=0.0, pipeline_update=None):
         self.device = device
+        self._pending = None
         self.batch = batch
         self.dim_latent = dim_latent
         self.num_heads = num_heads
@@ -147,6 +148,10 @@ class GangealingTrainer:
         # per-rank data stream (train.py:193-194)
         torch.manual_seed(seed * world + rank)
         self.world = world
+        # defer the STN optimizer step behind the next iteration's generator passes (see step()); only pays when there
+        # is a collective to hide
+        self.pipeline_update = (world > 1) if pipeline_update is None else bool(pipeline_update)
+        self.stn.register_forward_pre_hook(lambda module, inputs: self.flush())
 
     def loss(self, psi):
         common = dict(sample_from_full_res=self.sample_from_full_res, padding_mode=self.padding_mode)
@@ -167,19 +172,46 @@ class GangealingTrainer:
                        'f': idl.detach() if idl is not None else None}
 
     def step(self, psi=0.5):
-        """One iteration: loss forward, backward, gradient all-reduce, Adam x2, EMA (train.py:106-134)."""
-        self.stn_arena.zero_grad()
+        """One iteration: loss forward, backward, gradient all-reduce, Adam x2, EMA (train.py:106-134).
+
+        With `pipeline_update` (default: on when world > 1) the STN half of the update is deferred: the 172 MB
+        gradient all-reduce is started asynchronously after backward and the STN's Adam + EMA + weight re-pack run
+        right before the STN is next used (a forward pre-hook) - i.e. behind the next iteration's two generator
+        passes, which do not read the STN.  Parameter values seen by every forward are exactly those of the
+        un-pipelined order; call `flush()` before reading parameters from outside (checkpoints, evaluation)."""
+        if self._pending is None:
+            self.stn_arena.zero_grad()
         self.ll_arena.zero_grad()
-        total, parts = self.loss(psi)
+        total, parts = self.loss(psi)            # (its STN forward first applies a pending update and zeroes the grads)
         total.backward()
+        scale = 1.0 / self.world
         if self.world > 1:
-            gdist.all_reduce_mean_(self.stn_arena.grad)
-            gdist.all_reduce_mean_(self.ll_arena.grad)
-        adam_ema_step(self.stn_arena, self.stn_lr, self.ema_arena.param, self.ema_decay)
+            import torch.distributed as dist
+            dist.all_reduce(self.ll_arena.grad, op=dist.ReduceOp.SUM)
+            work = dist.all_reduce(self.stn_arena.grad, op=dist.ReduceOp.SUM, async_op=self.pipeline_update)
+        else:
+            work = None
         if not self.freeze_ll:
-            adam_ema_step(self.ll_arena, self.ll_lr)
-        conv_mfma.repack_trainable()         # all STN weight packs (forward + data-gradient layouts) in one launch
+            adam_ema_step(self.ll_arena, self.ll_lr, grad_scale=scale)
+        if self.pipeline_update:
+            self._pending = (work, scale)
+        else:
+            self._apply_stn_update(scale)
         return parts
+
+    def _apply_stn_update(self, scale):
+        adam_ema_step(self.stn_arena, self.stn_lr, self.ema_arena.param, self.ema_decay, grad_scale=scale)
+        conv_mfma.repack_trainable()         # all STN weight packs (forward + data-gradient layouts) in one launch
+
+    def flush(self):
+        """Apply a deferred STN update (no-op when nothing is pending)."""
+        if self._pending is not None:
+            work, scale = self._pending
+            self._pending = None
+            if work is not None:
+                work.wait()                      # the compute stream waits for the collective; the host does not
+            self._apply_stn_update(scale)
+            self.stn_arena.zero_grad()
 
 
 def smoke(device):

@@ -375,3 +375,46 @@ def test_trainer_shortcuts_are_consistent_across_optimizer_steps(cuda):
         torch.manual_seed(100 + step)
         tr.step(psi=0.5)                                   # optimizer + EMA + re-pack, shortcuts on
     assert torch.isfinite(tr.stn_arena.param).all()
+
+
+def test_pipelined_optimizer_update_matches_immediate_update(cuda):
+    """pipeline_update defers the STN's all-reduce + Adam + EMA + re-pack until the STN is next used (behind the next
+    iteration's generator passes).  One step + flush must leave the same parameters as the immediate update, the
+    second step must see the updated parameters, and nothing may be pending after flush()."""
+    from gangealing_amd.train_step import GangealingTrainer
+    kw = dict(gen_size=64, flow_size=64, batch=2, transform=('similarity', 'flow'), inject=3, ndirs=2,
+              perturb_heads=0.02, seed=9)
+
+    def run(pipelined):
+        tr = GangealingTrainer(cuda, pipeline_update=pipelined, **kw)
+        p0 = tr.stn_arena.param.clone()
+        torch.manual_seed(77)
+        tr.step(psi=0.5)
+        if pipelined:
+            assert tr._pending is not None and torch.equal(tr.stn_arena.param, p0)      # not applied yet
+        tr.flush()
+        assert tr._pending is None
+        p1 = tr.stn_arena.param.clone()
+        e1 = tr.ema_arena.param.clone()
+        torch.manual_seed(78)
+        parts = tr.step(psi=0.5)                  # the STN forward of this step applies nothing twice
+        tr.flush()
+        return p0, p1, e1, tr.stn_arena.param.clone(), float(parts['p'])
+
+    a0, a1, ae, a2, la = run(False)
+    b0, b1, be, b2, lb = run(True)
+    assert torch.equal(a0, b0)
+
+    def frac(x, y, tol):
+        return float(((x - y).abs() > tol).float().mean())
+
+    # Split-K atomics make gradients differ in the last bits from run to run, and Adam's first update is
+    # lr * sign(g) almost everywhere: two immediate-update runs differ in 0.1-0.7 % of the entries by up to 2 lr.
+    # The pipelined run has to sit in that band (a missing / doubled / mis-ordered update would move EVERY entry).
+    assert float((a1 - a0).abs().max()) > 0
+    assert frac(a1, b1, 1e-6) < 0.03 and float((a1 - b1).abs().max()) <= 2.1e-3
+    assert float((ae - be).abs().max()) <= 1e-4
+    assert abs(la - lb) <= 2e-2 * abs(la)
+    assert frac(a2, b2, 2e-4) < 0.05 and float((a2 - b2).abs().max()) <= 4.2e-3
+    moved = frac(a2, a1, 1e-6)
+    assert moved > 0.9 and frac(b2, b1, 1e-6) > 0.9, moved        # the second update was applied in both modes
