@@ -13,6 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libgangealing_hip.so')
 ABI_VERSION = 1
+NOT_SERVED = -1000            # GG_NOT_SERVED of the header
 
 # signature alphabet: p device pointer (tensor or None), i int, q long long, f float, d double, s stream
 _PROTOS = {
@@ -122,7 +123,7 @@ def _dev_ptr(t):
 def call(name, *args, allow=()):
     """Invoke a C-ABI entry point on torch's current HIP stream; the trailing stream argument is
     supplied here.  Tensors are passed as raw device pointers.  Returns the status code; codes other than 0 raise
-    unless listed in `allow` (e.g. 1 = "shape not served, nothing launched" of the optional fused entry points)."""
+    unless listed in `allow` (e.g. NOT_SERVED = "shape not served, nothing launched" of the optional fused entry points)."""
     lib = load()
     proto = _PROTOS[name]
     if len(args) != len(proto) - 1:

@@ -24,6 +24,16 @@
 // Stride-2 transposed convolution (the generator's up-convs and the dgrad of the STN's strided
 // convs) is decomposed by output parity into 4 dense sub-problems (2x2, 2x1, 1x2, 1x1 taps), so no
 // MFMA work is spent on the zero-stuffed positions.
+//
+// Kernel families in this file (DESIGN.md section 3 has the measurements):
+//   conv_igemm_kernel            exact fp32 MFMA implicit GEMM, every shape (parity mode; 3-channel stems, ToRGB)
+//   conv_split_kernel            split-precision (2 / 3 bf16 limbs per fp32 operand) generic shapes: 1x1, stride 2
+//   conv3x3_patch_kernel         split-precision 3x3 / stride 1 with input-patch reuse, fused StyledConv epilogue and
+//                                optional leaky-ReLU mask on the input (data gradients) - the dominant kernel
+//   convT3x3s2_patch_kernel      split-precision transposed 3x3 / stride 2, all four parity classes in one pass
+//   conv_wgrad_kernel / conv_wgrad_split_kernel / conv3x3_wgrad_rows_kernel   weight gradients (fp32 / generic split /
+//                                row-streaming 3x3 with workspace reduction)
+//   pack_weight*_kernel          GEMM / limb-plane weight layouts (single, or all trainable weights in one launch)
 #include "../../include/gangealing_hip.h"
 #include "gg_common.h"
 
@@ -1990,7 +2000,7 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   return gg::launch_status("convT3x3s2_patch");
 }
 
-constexpr int kNotFused = 1;      // masked-input request that no kernel serves: nothing was launched
+constexpr int kNotFused = GG_NOT_SERVED;      // masked-input request that no kernel serves: nothing was launched
 
 template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {

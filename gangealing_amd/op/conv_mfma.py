@@ -406,7 +406,7 @@ class _Conv3x3BiasAct(Function):
                 dw = slot if slot is not None else torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dy.device)
                 ws = _workspace(dy.device, 1200 * 147456)
                 rc = _lib.call('gg_conv3x3_masked_wgrad_f32', dw, db, x, dy, y, alpha, gain, n, cin, cout, h, w, wscale,
-                               2, 1 if slot is not None else 0, ws, ws.numel() * 4, allow=(1,))
+                               2, 1 if slot is not None else 0, ws, ws.numel() * 4, allow=(_lib.NOT_SERVED,))
                 if rc == 0:
                     return dx, (None if slot is not None else dw), db, None, None, None
         g = torch.empty_like(dy)
@@ -532,7 +532,7 @@ def masked_dgrad(dy, y_act, alpha, gain, wmat_bwd, n, cin, cout, h, w, in_scale=
     wbuf, stride_l = wmat_bwd.split(2)
     dx = torch.empty((n, cout, h, w), dtype=torch.float32, device=dy.device)
     rc = _lib.call('gg_conv3x3_masked_dgrad_f32', dx, dy, y_act, alpha, gain, wbuf, stride_l, 2, in_scale, out_scale,
-                   n, cin, cout, h, w, allow=(1,))
+                   n, cin, cout, h, w, allow=(_lib.NOT_SERVED,))
     return dx if rc == 0 else None
 
 

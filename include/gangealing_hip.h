@@ -8,7 +8,9 @@
  *
  * Conventions
  *   - return value: 0 on success; otherwise a hipError_t value (> 0) or a negative argument-error
- *     code.  gg_last_error() returns a thread-local, NUL-terminated description.
+ *     code.  gg_last_error() returns a thread-local, NUL-terminated description.  The optional fused
+ *     entry points gg_conv3x3_masked_dgrad_f32 / gg_conv3x3_masked_wgrad_f32 return GG_NOT_SERVED when
+ *     their kernel does not cover the shape: nothing was launched and the caller uses the unfused pair.
  *   - all tensors are dense row-major ("contiguous" in torch terms); NCHW unless noted.
  *   - kernels are enqueued on `stream` and never synchronise; nothing is allocated internally
  *     (workspaces are caller-provided), so every call is hipGraph-capturable.
@@ -20,6 +22,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#define GG_NOT_SERVED (-1000)
 
 int gg_abi_version(void);
 const char* gg_last_error(void);
@@ -224,8 +228,8 @@ int gg_conv_pack_weight_split(unsigned short* wsplit, const float* w, int groups
 /* Data gradient of a "3x3 conv + leaky ReLU" layer with the activation's backward fused into the gather:
  *   y = out_scale * conv3x3(W, in_scale * x * (mask_ref > 0 ? 1 : alpha) * gain)      (stride 1, pad 1, split precision)
  * x = the incoming gradient, mask_ref = the layer's saved activation OUTPUT (same shape as x), W = the data-gradient
- * pack (flipped / transposed taps).  Only the patch-reuse kernel carries the mask: the call returns 1 and launches
- * NOTHING when the shape is not served by it (caller: gg_fused_lrelu_bwd_f32 followed by gg_conv2d_split_f32). */
+ * pack (flipped / transposed taps).  Only the patch-reuse kernel carries the mask: the call returns GG_NOT_SERVED and
+ * launches NOTHING when the shape is not served by it (caller: gg_fused_lrelu_bwd_f32 followed by gg_conv2d_split_f32). */
 int gg_conv3x3_masked_dgrad_f32(float* y, const float* x, const float* mask_ref, float alpha, float gain,
                                 const unsigned short* wsplit, long long limb_stride, int limbs, const float* in_scale,
                                 const float* out_scale, int batch, int cin, int cout, int h, int w, void* stream);
@@ -278,7 +282,7 @@ int gg_conv2d_wgrad_ws_f32(float* dw, const float* x, const float* dy, int batch
 /* Weight (and bias) gradient of a "3x3 conv + bias + leaky ReLU" layer from the gradient of its OUTPUT: the
  * activation's backward dy * (mask_ref > 0 ? 1 : alpha) * gain is applied while dy is staged (mask_ref = the saved
  * output), dw (=/+=) as gg_conv2d_wgrad_ws_f32 and, if dbias != NULL, dbias[co] += sum of the masked gradient
- * (dbias must be initialised by the caller).  Returns 1 and launches nothing when the row-streaming kernel does not
+ * (dbias must be initialised by the caller).  Returns GG_NOT_SERVED and launches nothing when the row-streaming kernel does not
  * serve the shape (W % 32 != 0, limbs != 2, workspace too small ...). */
 int gg_conv3x3_masked_wgrad_f32(float* dw, float* dbias, const float* x, const float* dy, const float* mask_ref,
                                 float alpha, float gain, int batch, int cin, int cout, int h, int w, float scale,
