@@ -1485,17 +1485,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradArgs a
 // Each wave owns 32 co x 32 ci and keeps the nine 32x32 accumulators (one per tap): 54 MFMAs per slab.
 // K-splits (image, strip, row block) are combined with fp32 atomics into dw (torch layout [co][ci][3][3]).
 // ------------------------------------------------------------------------------------------------
-constexpr int WR_XROW = 96;                  // bytes per x row slot: 48 bf16 = 8 halo + 32 + 8 halo
-constexpr int WR_XS = 3 * WR_XROW + 16;      // bytes per ci (odd multiple of 16 -> conflict-free lane stride)
-
-template <int LIMBS, int TCO, int TCI, bool MASK = false>
+// SW = strip width: 32 (one image row segment per 32-pixel slab) or 16 (16-wide images: a slab is TWO full rows, the
+// window holds 4 rows and the k-half of a fragment selects the row instead of the column)
+template <int LIMBS, int TCO, int TCI, bool MASK = false, int SW = 32>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradArgs a, int segs, int rblocks,
-                                                                    int rows_per_block, float* __restrict__ ws,
+                                                                    int rows_per_block, int units_per_block,
+                                                                    float* __restrict__ ws,
                                                                     float* __restrict__ dbws) {
   static_assert(TCO * TCI == 4096, "four waves of 32 co x 32 ci");
   constexpr int WCI = TCI / 32;                       // ci waves; co waves = 4 / WCI
   constexpr int DPARTS = 256 / TCO, DPX = 32 / DPARTS;        // dy: threads per row, pixels per thread
-  constexpr int XPT = TCI / 32;                       // x (ci, 4-px group) items per thread
+  constexpr int XPT = TCI / 32;                       // x (ci, row, 4-px group) items per thread
+  constexpr int ROWS = 32 / SW, NSLOT = ROWS + 2;     // image rows per slab, rows in the rolling window
+  constexpr int SUBS = SW / 4;                        // 4-pixel groups per row
+  constexpr int WR_XROW = (8 + SW + 8) * 2;           // bytes per x row slot: 8 halo + SW + 8 halo bf16
+  constexpr int WR_XS = NSLOT * WR_XROW + 16;         // bytes per ci (odd multiple of 16 -> conflict-free lane stride)
   __shared__ __attribute__((aligned(16))) unsigned char sD[LIMBS][TCO * ROWB];
   __shared__ __attribute__((aligned(16))) unsigned char sX[LIMBS][TCI * WR_XS];
 
@@ -1507,42 +1511,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
   const int tile_co = logical % a.tiles_co, tile_ci = logical / a.tiles_co;
   const int co0 = tile_co * TCO, ci0 = tile_ci * TCI;
   const int g = blockIdx.z;
-  // split -> (image, strip, row block)
-  int sp = blockIdx.y;
-  const int rb = sp % rblocks; sp /= rblocks;
-  const int seg = sp % segs;
-  const int n = sp / segs;
-  const int c0 = seg * 32;
-  const int y0 = rb * rows_per_block;
-  int y1 = y0 + rows_per_block;
-  if (y1 > a.h) y1 = a.h;
+  // A block sums over `units_per_block` consecutive K-units; unit -> (image, strip, row block).  (Small images: one
+  // unit is only a few slabs, so several are chained to amortise the tile's epilogue.)
   const int hw = a.h * a.w;
-
-  const float* xn = a.x + ((size_t)(n * a.groups + g) * a.cin_g) * hw;
+  const int total_units = a.batch * segs * rblocks;
+  int n = 0, c0 = 0, y0 = 0, y1 = 0;
+  const float* xn = nullptr;
+  const float* dsrc = nullptr;
+  const float* msrc = nullptr;
 
   // ---- dy mover: row drow, pixels dpart*DPX .. +DPX
   const int drow = tid / DPARTS, dpart = tid % DPARTS;
   const bool d_ok = (co0 + drow) < a.cout_g;
-  const size_t doff = ((size_t)(n * a.groups + g) * a.cout_g + (d_ok ? co0 + drow : 0)) * hw + c0 + dpart * DPX;
-  const float* dsrc = a.dy + doff;
-  const float* msrc = MASK ? a.mask_ref + doff : nullptr;
   const float mpos = a.mask_gain, mneg = a.mask_gain * a.mask_alpha;
   float bsum = 0.f;                               // this thread's share of the bias gradient (MASK)
+  auto set_unit = [&](int unit) {
+    int sp = unit;
+    const int rb = sp % rblocks; sp /= rblocks;
+    const int sg = sp % segs;
+    n = sp / segs;
+    c0 = sg * SW;
+    y0 = rb * rows_per_block;
+    y1 = y0 + rows_per_block;
+    if (y1 > a.h) y1 = a.h;
+    xn = a.x + ((size_t)(n * a.groups + g) * a.cin_g) * hw;
+    const size_t doff = ((size_t)(n * a.groups + g) * a.cout_g + (d_ok ? co0 + drow : 0)) * hw + c0 + dpart * DPX;
+    dsrc = a.dy + doff;
+    msrc = MASK ? a.mask_ref + doff : nullptr;
+  };
   // ---- x mover: items (ci, 4-pixel group)
-  int xci[XPT], xsub[XPT];
+  int xci[XPT], xsub[XPT], xrr[XPT];
   bool x_ok[XPT];
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
     const int item = tid + 256 * i;
     xci[i] = item >> 3;
-    xsub[i] = item & 7;
+    xsub[i] = item & (SUBS - 1);
+    xrr[i] = (item & 7) / SUBS;                     // row inside the slab (0 for SW = 32)
     x_ok[i] = (ci0 + xci[i]) < a.cin_g;
   }
 
   float4 rd[DPX / 4];
   float4 rm[MASK ? DPX / 4 : 1];
   float4 rx[XPT];
-  float rh[XPT];                                   // halo pixel (left for sub 0, right for sub 7)
+  float rh[XPT];                                   // halo pixel (left for the first group, right for the last)
   auto load_dy = [&](int y) {
     const bool ok = d_ok & (y < y1);
 #pragma unroll
@@ -1553,15 +1565,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
                               : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto load_x = [&](int row) {
-    const bool rok = (unsigned)row < (unsigned)a.h;
+  auto load_x = [&](int rowbase) {                  // rows rowbase .. rowbase + ROWS - 1
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
-      const bool ok = rok & x_ok[i];
+      const int row = rowbase + xrr[i];
+      const bool ok = ((unsigned)row < (unsigned)a.h) & x_ok[i];
       const float* src = xn + (size_t)(ok ? ci0 + xci[i] : 0) * hw + (size_t)(ok ? row : 0) * a.w + c0;
       rx[i] = ok ? *reinterpret_cast<const float4*>(src + xsub[i] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const int hc = xsub[i] == 0 ? c0 - 1 : c0 + 32;
-      const bool hok = ok & ((xsub[i] == 0) | (xsub[i] == 7)) & ((unsigned)hc < (unsigned)a.w);
+      const int hc = xsub[i] == 0 ? c0 - 1 : c0 + SW;
+      const bool hok = ok & ((xsub[i] == 0) | (xsub[i] == SUBS - 1)) & ((unsigned)hc < (unsigned)a.w);
       rh[i] = hok ? src[hc - c0] : 0.f;
     }
   };
@@ -1594,10 +1606,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
       for (int q = 0; q < DPX / 8; ++q) dst[q] = U4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
     }
   };
-  auto store_x = [&](int row) {
-    const int slot = (row + 3) % 3;
+  auto store_x = [&](int rowbase) {
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
+      const int slot = (rowbase + xrr[i] + NSLOT) % NSLOT;
       float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
       float hv = rh[i];
       unsigned char* base = nullptr;
@@ -1608,7 +1620,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
         *reinterpret_cast<uint2*>(base + (8 + xsub[i] * 4) * 2) = make_uint2(p0, p1);
         const __bf16 hb = (__bf16)hv;
         if (xsub[i] == 0) *reinterpret_cast<__bf16*>(base + 7 * 2) = hb;
-        if (xsub[i] == 7) *reinterpret_cast<__bf16*>(base + 40 * 2) = hb;
+        if (xsub[i] == SUBS - 1) *reinterpret_cast<__bf16*>(base + (8 + SW) * 2) = hb;
         if (l + 1 < LIMBS) {
           v[0] -= bf16_lo(p0); v[1] -= bf16_hi(p0); v[2] -= bf16_lo(p1); v[3] -= bf16_hi(p1);
           hv -= (float)hb;
@@ -1625,22 +1637,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
 
   const int kh = lane >> 5, l31 = lane & 31;
   const int a_off = (wco * 32 + l31) * ROWB + kh * 16;               // + ks*32
-  const int b_off = (wci * 32 + l31) * WR_XS + (8 + kh * 8) * 2;     // + slot*WR_XROW + ks*32
+  const int b_off = (wci * 32 + l31) * WR_XS + (8 + kh * 8) * 2;     // + slot*WR_XROW (+ ks*32 for SW = 32)
 
-  if (y0 < y1) {
+  for (int u = 0; u < units_per_block; ++u) {
+    const int unit = blockIdx.y * units_per_block + u;
+    if (unit >= total_units) break;
+    set_unit(unit);
+    if (y0 >= y1) continue;
     // prologue: rows y0-1 and y0 of x
-    load_x(y0 - 1);
-    store_x(y0 - 1);
-    load_x(y0);
-    store_x(y0);
+    for (int r = y0 - 1; r < y0 + 1; r += ROWS) {
+      load_x(r);
+      store_x(r);
+    }
     load_dy(y0);
     load_x(y0 + 1);
-    for (int y = y0; y < y1; ++y) {
+    for (int y = y0; y < y1; y += ROWS) {
       store_dy();
       store_x(y + 1);
       __syncthreads();
-      load_dy(y + 1);
-      load_x(y + 2);
+      load_dy(y + ROWS);
+      load_x(y + ROWS + 1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 fa[LIMBS];
@@ -1648,11 +1664,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
         for (int l = 0; l < LIMBS; ++l) fa[l] = *reinterpret_cast<const bf16x8*>(&sD[l][a_off + ks * 32]);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-          const int slot = (y + ky + 2) % 3;                          // row y + ky - 1
+          // the slab's k-half ks is columns 16 ks.. of row y (SW = 32) or the whole row y + ks (SW = 16)
+          const int slot = (y + (SW == 16 ? ks : 0) + ky - 1 + NSLOT) % NSLOT;
           bf16x8 fb[LIMBS][3];
 #pragma unroll
           for (int l = 0; l < LIMBS; ++l) {
-            const unsigned char* p = &sX[l][b_off + slot * WR_XROW + ks * 32];
+            const unsigned char* p = &sX[l][b_off + slot * WR_XROW + (SW == 32 ? ks * 32 : 0)];
             const U4 mid = *reinterpret_cast<const U4*>(p);
             const unsigned prev = *reinterpret_cast<const unsigned*>(p - 4);
             const unsigned next = *reinterpret_cast<const unsigned*>(p + 16);
@@ -2246,13 +2263,15 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
     if ((a.oh * a.ow) % BKS != 0 || a.ow % 4 != 0 || (reinterpret_cast<uintptr_t>(dy) & 15))
       return gg::fail(-2, "conv2d_wgrad_split: needs OH*OW %% 32 == 0, OW %% 4 == 0 and 16-byte aligned dy");
   }
-  if (limbs && ksize == 3 && stride == 1 && pad == 1 && a.w % 32 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+  const bool strip16 = a.w == 16 && a.h % 2 == 0 && !mask_ref;            // 16-wide images: two rows per slab
+  if (limbs && ksize == 3 && stride == 1 && pad == 1 && (a.w % 32 == 0 || strip16) &&
+      (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     // row-streaming kernel: (128 co x 32 ci) tiles, or (64 x 64) for narrow outputs
     const bool narrow = cout_g <= 64;
     const int tco = narrow ? 64 : 128, tci = narrow ? 64 : 32;
     a.tiles_co = (cout_g + tco - 1) / tco;
     a.tiles_j = (cin_g + tci - 1) / tci;
-    const int segs = a.w / 32;
+    const int segs = strip16 ? 1 : a.w / 32;
     const long long tiles = (long long)a.tiles_co * a.tiles_j * groups;
     const long long units = (long long)batch * segs;
     // two resident blocks per CU; more blocks only add partial tiles to write and reduce
@@ -2260,23 +2279,37 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
     const long long max_rb = (a.h + 7) / 8;                             // >= 8 rows per block
     if (rblocks > max_rb) rblocks = max_rb;
     if (rblocks < 1) rblocks = 1;
-    const int rows_per_block = (int)((a.h + rblocks - 1) / rblocks);
+    int rows_per_block = (int)((a.h + rblocks - 1) / rblocks);
+    if (strip16) rows_per_block += rows_per_block & 1;
     rblocks = (a.h + rows_per_block - 1) / rows_per_block;
-    const long long splits = units * rblocks;
+    const long long total_units = units * rblocks;
+    // chain K-units per block when there are more blocks than two per CU (small images: a unit is a few slabs)
+    long long upb = tiles * total_units / (2LL * gg::kNumCu);
+    if (upb < 1) upb = 1;
+    if (upb > 8) upb = 8;
+    const long long splits = (total_units + upb - 1) / upb;
     const long long need_dw = tiles * splits * 9LL * 4096 * (long long)sizeof(float);
     const long long need = need_dw + (dbias ? splits * (long long)groups * cout_g * (long long)sizeof(float) : 0);
     float* dbws = dbias ? workspace + need_dw / sizeof(float) : nullptr;
     if (workspace && workspace_bytes >= need && splits <= 65535 && (long long)a.tiles_co * a.tiles_j < (1LL << 31)) {
       dim3 grid((unsigned)(a.tiles_co * a.tiles_j), (unsigned)splits, (unsigned)groups);
-      if (a.mask_ref) {          // limbs == 2 (checked by the entry point)
-        if (narrow) conv3x3_wgrad_rows_kernel<2, 64, 64, true><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace, dbws);
-        else conv3x3_wgrad_rows_kernel<2, 128, 32, true><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace, dbws);
+      if (strip16) {
+        if (limbs == 2) {
+          if (narrow) conv3x3_wgrad_rows_kernel<2, 64, 64, false, 16><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
+          else conv3x3_wgrad_rows_kernel<2, 128, 32, false, 16><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
+        } else {
+          if (narrow) conv3x3_wgrad_rows_kernel<3, 64, 64, false, 16><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
+          else conv3x3_wgrad_rows_kernel<3, 128, 32, false, 16><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
+        }
+      } else if (a.mask_ref) {   // limbs == 2 (checked by the entry point)
+        if (narrow) conv3x3_wgrad_rows_kernel<2, 64, 64, true><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
+        else conv3x3_wgrad_rows_kernel<2, 128, 32, true><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
       } else if (limbs == 2) {
-        if (narrow) conv3x3_wgrad_rows_kernel<2, 64, 64><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace, dbws);
-        else conv3x3_wgrad_rows_kernel<2, 128, 32><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace, dbws);
+        if (narrow) conv3x3_wgrad_rows_kernel<2, 64, 64><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
+        else conv3x3_wgrad_rows_kernel<2, 128, 32><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
       } else {
-        if (narrow) conv3x3_wgrad_rows_kernel<3, 64, 64><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace, dbws);
-        else conv3x3_wgrad_rows_kernel<3, 128, 32><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, workspace, dbws);
+        if (narrow) conv3x3_wgrad_rows_kernel<3, 64, 64><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
+        else conv3x3_wgrad_rows_kernel<3, 128, 32><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
       }
       int rc = gg::launch_status("conv3x3_wgrad_rows");
       if (rc) return rc;

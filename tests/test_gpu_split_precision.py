@@ -139,7 +139,8 @@ def test_styled_conv_fused_activation_matches_unfused(shape, mode_name, cuda, pr
 
 @pytest.mark.parametrize('mode_name,tol', [('bf16x3', 3e-5), ('bf16x6', 1e-5)])
 @pytest.mark.parametrize('spec', [(2, 64, 64, 32, 32, 1), (1, 48, 72, 40, 64, 1), (3, 160, 136, 9, 32, 1),
-                                  (2, 64, 192, 16, 96, 2), (16, 64, 64, 128, 128, 1)],
+                                  (2, 64, 192, 16, 96, 2), (16, 64, 64, 128, 128, 1),
+                                  (3, 96, 160, 16, 16, 1), (2, 64, 64, 6, 16, 1), (16, 512, 512, 16, 16, 1)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_row_streaming_wgrad_matches_fp32_kernel(spec, mode_name, tol, cuda, precision):
     """3x3 / stride 1 / pad 1 weight gradient (conv3x3_wgrad_rows_kernel: rolling x window, alignbit-shifted taps)
