@@ -1735,6 +1735,57 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
   }
 }
 
+// 1x1 / stride 1 weight gradient with very few input channels (the STN's 3 -> 64 RGB stem): dW[co][ci] =
+// sum_pixels dy[co][p] * x[ci][p] is a bandwidth-bound reduction of dy (67 MB at 128^2, batch 16) - the GEMM kernels
+// spent 0.17 ms on it with 3 of their 128 columns in use.  Lanes run along pixels, a wave owns 16 output channels and
+// keeps the 16 x CIN partial sums in registers; per-block partials go to the workspace and are summed by
+// partial_sum_kernel.
+template <int CIN>
+__global__ __launch_bounds__(256) void wgrad_1x1_smallcin_kernel(float* __restrict__ ws, const float* __restrict__ x,
+                                                                 const float* __restrict__ dy, int batch, int cout,
+                                                                 long long hw) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int co0 = blockIdx.y * 64 + wid * 16;
+  float acc[16][CIN];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) acc[r][c] = 0.f;
+  const long long chunks_per_img = hw / 64, chunks = (long long)batch * chunks_per_img;
+  for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+    const long long n = ch / chunks_per_img, p = (ch - n * chunks_per_img) * 64 + lane;
+    float xv[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) xv[c] = x[((size_t)n * CIN + c) * hw + p];
+    const float* dyn = dy + ((size_t)n * cout) * hw + p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = (co0 + r < cout) ? dyn[(size_t)(co0 + r) * hw] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) acc[r][c] += d * xv[c];
+    }
+  }
+  float* dst = ws + (size_t)blockIdx.x * cout * CIN;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      const float t = gg::wave_sum(acc[r][c]);
+      if (lane == 0 && co0 + r < cout) dst[(co0 + r) * CIN + c] = t;
+    }
+}
+
+// out[i] (+)= scale * sum_b ws[b * count + i]: one wave per output element, lanes stride over the partials
+__global__ __launch_bounds__(256) void partial_sum_kernel(float* __restrict__ out, const float* __restrict__ ws,
+                                                          int nblocks, int count, float scale, int accumulate) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= count) return;
+  float sum = 0.f;
+  for (int b = lane; b < nblocks; b += 64) sum += ws[(size_t)b * count + i];
+  sum = gg::wave_sum(sum);
+  if (lane == 0) out[i] = (accumulate ? out[i] : 0.f) + sum * scale;
+}
+
 // dw[g][co][ci][tap] (+)= scale * sum_split ws[tile][split][tap][co_l][ci_l]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ ws,
                                                            int groups, int cout_g, int cin_g, int tiles_co,
@@ -2262,6 +2313,26 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
     if (limbs != 2 && limbs != 3) return gg::fail(-2, "conv2d_wgrad_split: limbs must be 2 or 3");
     if ((a.oh * a.ow) % BKS != 0 || a.ow % 4 != 0 || (reinterpret_cast<uintptr_t>(dy) & 15))
       return gg::fail(-2, "conv2d_wgrad_split: needs OH*OW %% 32 == 0, OW %% 4 == 0 and 16-byte aligned dy");
+  }
+  if (ksize == 1 && stride == 1 && pad == 0 && groups == 1 && cin_g <= 4 && !mask_ref && ((long long)h * w) % 64 == 0) {
+    // few-input-channel 1x1 stem: streaming reduction (fp32 exact in every precision mode)
+    const int nblocks = 2 * gg::kNumCu;
+    const long long need = (long long)nblocks * cout_g * cin_g * (long long)sizeof(float);
+    if (workspace && workspace_bytes >= need) {
+      dim3 grid((unsigned)nblocks, (unsigned)((cout_g + 63) / 64));
+      const long long hw = (long long)h * w;
+      switch (cin_g) {
+        case 1: wgrad_1x1_smallcin_kernel<1><<<grid, 256, 0, st>>>(workspace, x, dy, batch, cout_g, hw); break;
+        case 2: wgrad_1x1_smallcin_kernel<2><<<grid, 256, 0, st>>>(workspace, x, dy, batch, cout_g, hw); break;
+        case 3: wgrad_1x1_smallcin_kernel<3><<<grid, 256, 0, st>>>(workspace, x, dy, batch, cout_g, hw); break;
+        default: wgrad_1x1_smallcin_kernel<4><<<grid, 256, 0, st>>>(workspace, x, dy, batch, cout_g, hw); break;
+      }
+      int rc = gg::launch_status("wgrad_1x1_smallcin");
+      if (rc) return rc;
+      const int count = cout_g * cin_g;
+      partial_sum_kernel<<<(count + 3) / 4, 256, 0, st>>>(dw, workspace, nblocks, count, scale, accumulate ? 1 : 0);
+      return gg::launch_status("partial_sum");
+    }
   }
   const bool strip16 = a.w == 16 && a.h % 2 == 0 && !mask_ref;            // 16-wide images: two rows per slab
   if (limbs && ksize == 3 && stride == 1 && pad == 1 && (a.w % 32 == 0 || strip16) &&

@@ -260,7 +260,8 @@ def conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, pad, scale=1.0, i
     limbs = _LIMBS[PRECISION]
     split = bool(limbs and (oh * ow) % 32 == 0 and ow % 4 == 0 and cout_g >= 32 and cin_g * k * k >= 32
                  and dy.data_ptr() % 16 == 0)
-    if split and k == 3 and stride == 1 and pad == 1 and (w % 32 == 0 or (w == 16 and h % 2 == 0)) \
+    stem = k == 1 and stride == 1 and pad == 0 and groups == 1 and cin_g <= 4 and (h * w) % 64 == 0   # RGB stem
+    if (stem or (split and k == 3 and stride == 1 and pad == 1 and (w % 32 == 0 or (w == 16 and h % 2 == 0)))) \
             and 'wgrad_rows' not in DISABLED:
         # row-streaming kernel; its K-split partials go through a workspace (one per device, grown on demand)
         ws = _workspace(x.device, 1200 * 147456)

@@ -213,3 +213,24 @@ def test_masked_dgrad_serves_patch_shapes_only(cuda, precision):
             assert float((dx - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
     precision('fp32')
     assert cm.masked_dgrad(dy, y, 0.2, 1.0, pw, 2, 64, 96, 4, 4) is None
+
+
+@pytest.mark.parametrize('mode_name', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('spec', [(16, 3, 64, 128, 128), (2, 3, 70, 8, 8), (3, 1, 16, 16, 32), (2, 4, 130, 24, 8)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_pointwise_small_cin_wgrad(spec, mode_name, cuda, precision):
+    """1x1 weight gradient of the few-input-channel stems (streaming reduction kernel) against float64 einsum."""
+    from gangealing_amd.op import conv_mfma as cm
+    n, cin, cout, h, w = spec
+    precision(mode_name)
+    g = torch.Generator(device='cpu').manual_seed(17)
+    x = torch.randn(n, cin, h, w, generator=g)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    ref = 0.25 * torch.einsum('nohw,nihw->oi', dy.double(), x.double())
+    out = cm.conv_wgrad(x.to(cuda), dy.to(cuda), n, 1, cin, cout, 1, 1, 0, 0.25)
+    assert out.shape == (cout, cin, 1, 1)
+    np.testing.assert_allclose(out.cpu().numpy().reshape(cout, cin), ref.numpy(), rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+    slot = torch.full((cout, cin, 1, 1), 2.0, device=cuda)
+    cm.conv_wgrad(x.to(cuda), dy.to(cuda), n, 1, cin, cout, 1, 1, 0, 0.25, into=slot)
+    np.testing.assert_allclose(slot.cpu().numpy().reshape(cout, cin) - 2.0, ref.numpy(), rtol=2e-5,
+                               atol=2e-5 * float(ref.abs().max()))
