@@ -1787,6 +1787,10 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(float* __restrict__ ou
 }
 
 // dw[g][co][ci][tap] (+)= scale * sum_split ws[tile][split][tap][co_l][ci_l]
+// RG lanes share one output element and each sums every RG-th split (then a shuffle reduction): with one thread per
+// element the narrow layers (one tile, 512 splits) were a 512-long chain of dependent loads on half a block per CU.
+// RG = 1 (one element per lane, fully coalesced) serves the many-tile / few-split layers.
+template <int RG>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ ws,
                                                            int groups, int cout_g, int cin_g, int tiles_co,
                                                            int tiles_ci, int tco, int tci, int splits, float scale,
@@ -1802,17 +1806,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
       dbias[c] += sum;
     }
   }
-  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
-    const size_t tile = o / tile_elems;
-    const int e = (int)(o - tile * tile_elems);
+  // thread t: element (t / 64) * (64 / RG) ... : lanes [0, 64/RG) of each RG-row are consecutive elements
+  const int lane = threadIdx.x & 63, sub = lane / (64 / RG), el = lane % (64 / RG);
+  const size_t waves = (size_t)gridDim.x * 4;
+  for (size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / RG); base < total; base += waves * (64 / RG)) {
+    const size_t o = base + el;
+    float sum = 0.f;
+    size_t tile = 0;
+    int e = 0;
+    const bool ok = o < total;
+    if (ok) {
+      tile = o / tile_elems;
+      e = (int)(o - tile * tile_elems);
+      const float* src = ws + tile * splits * tile_elems + e;
+      for (int sidx = sub; sidx < splits; sidx += RG) sum += src[(size_t)sidx * tile_elems];
+    }
+#pragma unroll
+    for (int m = 64 / RG; m < 64; m <<= 1) sum += __shfl_xor(sum, m, 64);
+    if (!ok || sub != 0) continue;
     const int ci_l = e % tci, co_l = (e / tci) % tco, t = e / (tci * tco);
     const int tile_ci = (int)(tile % tiles_ci), tile_co = (int)((tile / tiles_ci) % tiles_co);
     const int g = (int)(tile / ((size_t)tiles_ci * tiles_co));
     const int co = tile_co * tco + co_l, ci = tile_ci * tci + ci_l;
     if (co >= cout_g || ci >= cin_g) continue;
-    const float* src = ws + tile * splits * tile_elems + e;
-    float sum = 0.f;
-    for (int sidx = 0; sidx < splits; ++sidx) sum += src[(size_t)sidx * tile_elems];
     float* dst = dw + (((size_t)g * cout_g + co) * cin_g + ci) * 9 + t;
     *dst = (accumulate ? *dst : 0.f) + sum * scale;
   }
@@ -2385,9 +2401,14 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
       int rc = gg::launch_status("conv3x3_wgrad_rows");
       if (rc) return rc;
       const long long total = tiles * 9LL * 4096;
-      wgrad_reduce_kernel<<<gg::stream_grid(total, 256), 256, 0, st>>>(dw, workspace, groups, cout_g, cin_g, a.tiles_co,
-                                                                      a.tiles_j, tco, tci, (int)splits, scale,
-                                                                      accumulate ? 1 : 0, dbias, dbws);
+      if (splits >= 64)
+        wgrad_reduce_kernel<8><<<gg::stream_grid(total * 8, 256), 256, 0, st>>>(
+            dw, workspace, groups, cout_g, cin_g, a.tiles_co, a.tiles_j, tco, tci, (int)splits, scale, accumulate ? 1 : 0,
+            dbias, dbws);
+      else
+        wgrad_reduce_kernel<1><<<gg::stream_grid(total, 256), 256, 0, st>>>(
+            dw, workspace, groups, cout_g, cin_g, a.tiles_co, a.tiles_j, tco, tci, (int)splits, scale, accumulate ? 1 : 0,
+            dbias, dbws);
       return gg::launch_status("wgrad_reduce");
     }
   }
