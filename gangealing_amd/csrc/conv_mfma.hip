@@ -1927,6 +1927,9 @@ int launch_conv(const ConvArgs& a, int tile, hipStream_t st) {
 // 256-pixel tiles (8 waves) halve the weight stream per output; use them while they still give >= 2 blocks per CU
 int split_tile(const ConvArgs& a, int limbs) {
   const long long tiles256 = ((long long)a.batch * a.mh * a.mw + 255) / 256 * ((a.cout_g + 127) / 128) * a.groups;
+  // (A patch-reuse kernel was costed for stride 2 and dropped: a 128-pixel output tile needs a (2TH+1) x (2TW+1) input
+  // patch = 4.5 input pixels per output, which only fits LDS with 16-channel chunks, i.e. 12 MFMAs per barrier
+  // interval - no better than this kernel's 24 with its per-tap gathers.)
   // stride-2 correlations re-gather per tap: two unsynchronised 4-wave blocks per CU overlap gather and MFMA phases
   // better than one 8-wave block (measured 175 -> 205 TF/s on the generator's up-conv data gradients)
   if (a.bs == 2) return 0;
