@@ -56,6 +56,7 @@ _PROTOS = {
     'gg_style_demod_f32': 'pppqpppiiiifffs',
     'gg_lpips_tail_fwd_f32': 'pppiiqfs',
     'gg_lpips_tail_bwd_f32': 'ppppiiqfs',
+    'gg_torgb_dgrad_add_f32': 'ppppfiiqs',
     'gg_plane_dot_f32': 'pppiqs',
     'gg_adam_ema_f32': 'pppppqffffiffs',
 }

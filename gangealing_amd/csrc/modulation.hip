@@ -96,6 +96,48 @@ void launch_rowdot(dim3 grid, hipStream_t st, float* out, const float* in, long 
 
 }  // namespace
 
+namespace {
+// g[n,c,p] += sum_{k<3} (w[k,c] * wscale * style[n,c]) * r[n,k,p]: the data gradient of a modulated 1x1 "ToRGB"
+// convolution (networks.py:352-372, demodulate = False) added straight into the gradient that the other consumer of
+// the same activation produced.  Replaces: ToRGB dgrad conv (writes a full-size tensor) + autograd's 3-pass add.
+__global__ __launch_bounds__(256) void torgb_dgrad_add_kernel(float* __restrict__ g, const float* __restrict__ r,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ style, float wscale, int c,
+                                                              long long hw4) {
+  const int plane = blockIdx.y;                        // n * c + ch
+  const int n = plane / c, ch = plane - n * c;
+  const float s = style[(size_t)n * c + ch] * wscale;
+  const float m0 = w[ch] * s, m1 = w[c + ch] * s, m2 = w[2 * c + ch] * s;
+  float4* gp = reinterpret_cast<float4*>(g + (size_t)plane * hw4 * 4);
+  const float4* r0 = reinterpret_cast<const float4*>(r + ((size_t)n * 3 + 0) * hw4 * 4);
+  const float4* r1 = reinterpret_cast<const float4*>(r + ((size_t)n * 3 + 1) * hw4 * 4);
+  const float4* r2 = reinterpret_cast<const float4*>(r + ((size_t)n * 3 + 2) * hw4 * 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < hw4; i += (long long)gridDim.x * 256) {
+    float4 v = gp[i];
+    const float4 a = r0[i], b = r1[i], d = r2[i];
+    v.x += m0 * a.x + m1 * b.x + m2 * d.x;
+    v.y += m0 * a.y + m1 * b.y + m2 * d.y;
+    v.z += m0 * a.z + m1 * b.z + m2 * d.z;
+    v.w += m0 * a.w + m1 * b.w + m2 * d.w;
+    gp[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int gg_torgb_dgrad_add_f32(float* g, const float* grad_rgb, const float* w, const float* style, float wscale,
+                                      int n, int c, long long hw, void* stream) {
+  if (n <= 0 || c <= 0 || hw <= 0) return 0;
+  if (!g || !grad_rgb || !w || !style) return gg::fail(-2, "torgb_dgrad_add: null pointer");
+  if (hw % 4 != 0 || (reinterpret_cast<uintptr_t>(g) & 15) || (reinterpret_cast<uintptr_t>(grad_rgb) & 15))
+    return gg::fail(-2, "torgb_dgrad_add: hw must be a multiple of 4 and g / grad_rgb 16-byte aligned");
+  long long bx = (hw / 4 + 255) / 256;
+  if (bx > 64) bx = 64;
+  dim3 grid((unsigned)bx, (unsigned)(n * c));
+  if ((long long)n * c > 65535) return gg::fail(-2, "torgb_dgrad_add: more than 65535 planes");
+  torgb_dgrad_add_kernel<<<grid, 256, 0, gg::as_stream(stream)>>>(g, grad_rgb, w, style, wscale, c, hw / 4);
+  return gg::launch_status("torgb_dgrad_add");
+}
+
 extern "C" int gg_style_demod_f32(float* style, float* demod, const float* latent, long long lat_stride,
                                   const float* w, const float* b, const float* wsq, int n, int style_dim, int cin,
                                   int cout, float w_scale, float b_scale, float eps, void* stream) {

@@ -234,7 +234,7 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
 # gradient: no per-layer memset, no temporary and no AccumulateGrad add - two tiny launches less per layer.
 GRAD_SLOTS = {}
 # developer A/B switches (comma separated names in GG_DISABLE): slots, style_demod, fuse_act, wgrad_rows, lpips_tail,
-# pack_registry, mask_dgrad
+# pack_registry, mask_dgrad, torgb_fuse
 DISABLED = frozenset(filter(None, os.environ.get('GG_DISABLE', '').split(',')))
 # opt-in paths (GG_ENABLE): mask_wgrad - leaky-ReLU backward inside BOTH gradient kernels of a trainable conv+act layer
 # (gg_conv3x3_masked_wgrad_f32).  Measured 1 % SLOWER than the separate 5 TB/s mask pass on the STN shapes (the masked
@@ -576,6 +576,61 @@ class _ModulatedConvAct(Function):
             dx = conv_forward(g, ctx.wmat_bwd, n, 1, cout, cin, 3, 1, 1, 0, in_scale=demod if demodulate else None,
                               out_scale=style)
         return (dx,) + (None,) * 11
+
+
+class _StyledConvToRGB(Function):
+    """(y, rgb) = one-kernel StyledConv (see _ModulatedConvAct) followed by the ToRGB layer's modulated 1x1 convolution
+    on y (networks.py:352-372).  For resolutions where y also feeds the next up-sampling layer: the backward receives
+    the next layer's data gradient and the RGB gradient together and adds the ToRGB branch into the former in one
+    read-modify-write pass (gg_torgb_dgrad_add_f32) instead of materialising a second full-size gradient and letting
+    autograd add the two (a 1x1 dgrad conv + a 3-pass element-wise add per resolution)."""
+
+    @staticmethod
+    def forward(ctx, x, style, wmat_fwd, wmat_bwd, wsq, demodulate, noise, noise_weight, act_bias, alpha, gain,
+                demod_pre, rgb_style, rgb_wmat, rgb_weight, rgb_scale):
+        x = x.contiguous()
+        style = style.contiguous()
+        n, cin, h, w = x.shape
+        cout = wmat_fwd.cout_g
+        demod = None
+        if demodulate:
+            demod = demod_pre if demod_pre is not None else torch.rsqrt((style * style) @ wsq.t() + 1e-8)
+        y = conv_forward(x, wmat_fwd, n, 1, cin, cout, 3, 1, 1, 0, in_scale=style, out_scale=demod,
+                         act=(noise.contiguous(), noise_weight.contiguous(), act_bias.contiguous(), alpha, gain))
+        rgb_style = rgb_style.contiguous()
+        rgb = conv_forward(y, rgb_wmat, n, 1, cout, 3, 1, 1, 0, 0, in_scale=rgb_style)
+        ctx.save_for_backward(style, demod if demod is not None else style.new_empty(0), y, rgb_style, rgb_weight)
+        ctx.wmat_bwd = wmat_bwd
+        ctx.conf = (demodulate, alpha, gain, cin, rgb_scale)
+        return y, rgb
+
+    @staticmethod
+    def backward(ctx, gy, grgb):
+        style, demod, y, rgb_style, rgb_weight = ctx.saved_tensors
+        demodulate, alpha, gain, cin, rgb_scale = ctx.conf
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 16
+        n, cout, h, w = y.shape
+        if gy is None:
+            g = torch.zeros_like(y)
+        else:
+            g = gy.contiguous()              # produced for this node only (y's other consumer is internal): updated in place
+        if grgb is not None:
+            _lib.call('gg_torgb_dgrad_add_f32', g, grgb.contiguous(), rgb_weight, rgb_style, rgb_scale, n, cout, h * w)
+        dx = masked_dgrad(g, y, alpha, gain, ctx.wmat_bwd, n, cout, cin, h, w, demod if demodulate else None, style)
+        if dx is None:
+            gm = torch.empty_like(g)
+            _lib.call('gg_fused_lrelu_bwd_f32', gm, None, g, y, alpha, gain, n, cout, h * w)
+            dx = conv_forward(gm, ctx.wmat_bwd, n, 1, cout, cin, 3, 1, 1, 0, in_scale=demod if demodulate else None,
+                              out_scale=style)
+        return (dx,) + (None,) * 15
+
+
+def styled_conv_torgb(x, style, wmat_fwd, wmat_bwd, wsq, demodulate, act, demod, rgb_style, rgb_wmat, rgb_weight,
+                      rgb_scale):
+    noise, noise_weight, act_bias, alpha, gain = act
+    return _StyledConvToRGB.apply(x, style, wmat_fwd, wmat_bwd, wsq, demodulate, noise, noise_weight, act_bias, alpha,
+                                  gain, demod, rgb_style, rgb_wmat, rgb_weight, float(rgb_scale))
 
 
 def style_demod(latent, weight, bias, w_scale, b_scale, wsq=None, eps=1e-8):

@@ -183,21 +183,23 @@ class ModulatedConv2d(nn.Module):
             self._packed = (key, wmat_fwd, wmat_bwd, wsq)
         return self._packed[1:]
 
-    def forward(self, input, style, act=None):
-        """act = (noise, noise_weight, bias, negative_slope, scale): fuse StyledConv's NoiseInjection +
-        FusedLeakyReLU into the convolution (callers check `can_fuse_act` first)."""
-        wmat_fwd, wmat_bwd, wsq = self._weights()
+    def modulate(self, input, style, wsq):
+        """latent slot -> (style (N, Cin), demodulation (N, Cout) or None when left to the convolution function)."""
         mod = self.modulation
-        demod = None
         if ('style_demod' not in conv_mfma.DISABLED and input.dtype == torch.float32 and style.dtype == torch.float32 and
                 mod.activation is None and
                 not (torch.is_grad_enabled() and (style.requires_grad or mod.weight.requires_grad or
                                                   (mod.bias is not None and mod.bias.requires_grad)))):
             # no gradient wanted for the style: EqualLinear + demodulation in one launch (csrc/modulation.hip)
-            style, demod = conv_mfma.style_demod(style, mod.weight, mod.bias, mod.scale, mod.lr_mul,
-                                                 wsq if self.demodulate else None, self.eps)
-        else:
-            style = mod(style)                                          # (N, Cin)
+            return conv_mfma.style_demod(style, mod.weight, mod.bias, mod.scale, mod.lr_mul,
+                                         wsq if self.demodulate else None, self.eps)
+        return mod(style), None
+
+    def forward(self, input, style, act=None):
+        """act = (noise, noise_weight, bias, negative_slope, scale): fuse StyledConv's NoiseInjection +
+        FusedLeakyReLU into the convolution (callers check `can_fuse_act` first)."""
+        wmat_fwd, wmat_bwd, wsq = self._weights()
+        style, demod = self.modulate(input, style, wsq)
         if self.upsample and act is not None:
             # up-sampling layer: the activation follows the blur, so it rides in the blur kernel instead
             out = conv_mfma.modulated_conv2d(input, style, wmat_fwd, wmat_bwd, wsq, self.kernel_size,
@@ -285,6 +287,33 @@ class StyledConv(nn.Module):
         return self.activate(out)
 
 
+def styled_conv_with_rgb(styled, to_rgb, input, style, rgb_latent, noise=None):
+    """StyledConv (no up-sampling) + the ToRGB convolution of the same resolution as ONE autograd node
+    (conv_mfma._StyledConvToRGB); returns (activation, raw rgb) or None when the pair cannot be fused (a style that
+    needs a gradient, trainable generator weights, shapes off the fused path)."""
+    conv, rgb_conv = styled.conv, to_rgb.conv
+    if 'torgb_fuse' in conv_mfma.DISABLED or not torch.is_grad_enabled() or not input.requires_grad:
+        return None
+    if not conv.can_fuse_act(input, style, styled.noise.weight, styled.activate.bias) or conv.upsample:
+        return None
+    if rgb_latent.requires_grad or rgb_conv.modulation.weight.requires_grad or rgb_conv.weight.requires_grad:
+        return None
+    n, _, h, w = input.shape
+    if noise is None:
+        noise = input.new_empty(n, 1, h, w).normal_()
+    elif noise.shape[0] != n:
+        noise = noise.expand(n, -1, -1, -1)
+    wmat_fwd, wmat_bwd, wsq = conv._weights()
+    s_c, demod = conv.modulate(input, style, wsq)
+    rgb_fwd, _, _ = rgb_conv._weights()
+    s_rgb, _ = rgb_conv.modulate(input, rgb_latent, None)
+    act = (noise.type(input.dtype), styled.noise.weight, styled.activate.bias, styled.activate.negative_slope,
+           styled.activate.scale)
+    w_rgb = rgb_conv.weight.detach().reshape(3, rgb_conv.in_channel).contiguous()
+    return conv_mfma.styled_conv_torgb(input, s_c, wmat_fwd, wmat_bwd, wsq, conv.demodulate, act, demod, s_rgb, rgb_fwd,
+                                       w_rgb, rgb_conv.scale)
+
+
 class ToRGB(nn.Module):
     def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=(1, 3, 3, 1), normalize=False):
         super().__init__()
@@ -294,7 +323,11 @@ class ToRGB(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
     def forward(self, input, style, skip=None):
-        out = self.conv(input, style) + self.bias.type(input.dtype)
+        return self.finish(self.conv(input, style), skip)
+
+    def finish(self, rgb, skip=None):
+        """bias + up-sampled skip connection around the raw modulated 1x1 convolution output."""
+        out = rgb + self.bias.type(rgb.dtype)
         if skip is not None:
             out = out.float() + self.upsample(skip)
         return out
@@ -427,7 +460,14 @@ class Generator(nn.Module):
         for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2],
                                                        self.to_rgbs):
             out = conv_up(out, lat[i], noise=n_up)
-            out = conv(out, lat[i + 1], noise=n_conv)
-            skip = to_rgb(out, lat[i + 2], skip)
+            last = to_rgb is self.to_rgbs[-1]
+            # every resolution but the last: the activation feeds ToRGB AND the next up-sampling layer -> one node
+            pair = None if last else styled_conv_with_rgb(conv, to_rgb, out, lat[i + 1], lat[i + 2], noise=n_conv)
+            if pair is not None:
+                out, rgb = pair
+                skip = to_rgb.finish(rgb, skip)
+            else:
+                out = conv(out, lat[i + 1], noise=n_conv)
+                skip = to_rgb(out, lat[i + 2], skip)
             i += 2
         return (skip, latent) if return_latents else (skip, None)

@@ -302,6 +302,13 @@ int gg_lpips_tail_fwd_f32(float* out, const float* feats, const float* lin, int 
                           void* stream);
 int gg_lpips_tail_bwd_f32(float* dfeats, const float* feats, const float* lin, const float* grad_out, int n, int c,
                           long long hw, float eps, void* stream);
+/* Data gradient of a modulated 1x1 ToRGB convolution (networks.py:352-372, no demodulation) ADDED into an existing
+ * gradient:  g[n,c,p] += sum_{k<3} w[k,c] * wscale * style[n,c] * grad_rgb[n,k,p].
+ * g (n,c,hw) accumulates, grad_rgb (n,3,hw), w (3,c) = the ToRGB weight, style (n,c) its modulation; hw % 4 == 0,
+ * n*c <= 65535.  Used where the activation feeds both the next layer and ToRGB: the next layer's data gradient is
+ * the running sum and the ToRGB branch is added in one read-modify-write pass. */
+int gg_torgb_dgrad_add_f32(float* g, const float* grad_rgb, const float* w, const float* style, float wscale, int n,
+                           int c, long long hw, void* stream);
 /* Per-(n,c) dot products over the spatial plane: out[n*c] = sum_hw a*b (style / demod gradients). */
 int gg_plane_dot_f32(float* out, const float* a, const float* b, int planes, long long hw, void* stream);
 

@@ -351,7 +351,8 @@ def test_trainer_shortcuts_are_consistent_across_optimizer_steps(cuda):
     from gangealing_amd.train_step import GangealingTrainer
     tr = GangealingTrainer(cuda, gen_size=64, flow_size=64, batch=2, transform=('similarity', 'flow'), inject=3,
                            ndirs=2, perturb_heads=0.02, seed=5)
-    off = frozenset(('slots', 'pack_registry', 'style_demod', 'fuse_act', 'lpips_tail', 'mask_dgrad', 'wgrad_rows'))
+    off = frozenset(('slots', 'pack_registry', 'style_demod', 'fuse_act', 'lpips_tail', 'mask_dgrad', 'wgrad_rows',
+                     'torgb_fuse'))
 
     def loss_and_grad(disabled, seed):
         old = conv_mfma.DISABLED

@@ -349,3 +349,23 @@ def test_lpips_tail_matches_torch_ops(n, c, h, w, use_lin, cuda):
     ref.backward(gout.double())
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=1e-7)
     np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-4, atol=2e-7 * float(xr.grad.abs().max()) * 50)
+
+
+def test_torgb_dgrad_add_matches_autograd(cuda):
+    """g += data gradient of the modulated 1x1 ToRGB convolution (gg_torgb_dgrad_add_f32) against autograd through
+    the reference's formulation (networks.py:243-281 with demodulate=False)."""
+    from gangealing_amd import _lib
+    g0 = torch.Generator(device='cpu').manual_seed(4)
+    n, c, h, w = 3, 40, 12, 20
+    x = torch.randn(n, c, h, w, generator=g0, dtype=torch.float64, requires_grad=True)
+    weight = torch.randn(3, c, generator=g0, dtype=torch.float64)
+    style = torch.randn(n, c, generator=g0, dtype=torch.float64)
+    grad_rgb = torch.randn(n, 3, h, w, generator=g0, dtype=torch.float64)
+    scale = c ** -0.5
+    rgb = torch.einsum('nkc,nchw->nkhw', weight[None] * scale * style[:, None, :], x)
+    (ref,) = torch.autograd.grad(rgb, x, grad_rgb)
+    running = torch.randn(n, c, h, w, generator=g0)
+    g = running.clone().to(cuda)
+    _lib.call('gg_torgb_dgrad_add_f32', g, grad_rgb.float().to(cuda), weight.float().to(cuda), style.float().to(cuda),
+              scale, n, c, h * w)
+    np.testing.assert_allclose(g.cpu().numpy(), (running.double() + ref).numpy(), rtol=1e-5, atol=1e-5)
