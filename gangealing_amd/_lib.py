@@ -31,6 +31,7 @@ _PROTOS = {
     'gg_mip_downsample2x_bwd_f32': 'ppiiis',
     'gg_mipmap_warp_fwd_f32': 'pppppppiiiiiiiiiffiis',
     'gg_mipmap_warp_bwd_f32': 'pppppppppppiiiiiiiiiffiis',
+    'gg_mipmap_warp_indices_f32': 'pppppiiiiiffiis',
     'gg_affine_grid_f32': 'ppiiis',
     'gg_affine_grid_bwd_f32': 'ppiiis',
     'gg_flow_compose_fwd_f32': 'pppppiiiis',

@@ -98,7 +98,8 @@ class ResnetClassifier(nn.Module):
     def load_state_dict(self, state_dict, strict=True):
         # the bilinear kernels are buffers derived from the constructor arguments
         skip = {'input_downsample.kernel_horz', 'input_downsample.kernel_vert'}
-        return super().load_state_dict({k: v for k, v in state_dict.items() if k not in skip}, False)
+        from .spatial_transformers.spatial_transformer import load_filtered_state_dict
+        return load_filtered_state_dict(self, state_dict, strict, skip)
 
 
 def cluster_classifier_step(classifier, generator, t_ema, ll, loss_fn, resize_fake2stn, batch, dim_latent, num_heads,

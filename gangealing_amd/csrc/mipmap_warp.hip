@@ -317,6 +317,38 @@ __global__ __launch_bounds__(256) void mipmap_warp_fwd_kernel(
   }
 }
 
+// Integer by-products of the sampling, produced by the SAME device functions the forward / backward kernels call
+// (make_taps, mip_level): floor(ix), floor(iy) after unnormalise + padding-mode coordinate transform
+// (GridSampler.h:143-160 + floor in grid_sampler_2d), floor / ceil of the clamped mip level
+// (antialiased_sampling.py:226-227).
+__global__ __launch_bounds__(256) void mipmap_warp_indices_kernel(int* __restrict__ ix_nw, int* __restrict__ iy_nw,
+                                                                  int* __restrict__ lvl_floor,
+                                                                  int* __restrict__ lvl_ceil,
+                                                                  const float* __restrict__ grid, int n, int h, int w,
+                                                                  int ho, int wo, float max_level, float min_level,
+                                                                  int padding_mode, int antialias) {
+  const long long total = (long long)n * ho * wo;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const int ox = (int)(o % wo);
+    const long long q = o / wo;
+    const int oy = (int)(q % ho);
+    const int s = (int)(q / ho);
+    const float* grid_n = grid + (size_t)s * ho * wo * 2;
+    int lo = 0, hi = 0;
+    if (antialias) {
+      const LevelInfo li = mip_level(grid_n, oy, ox, ho, wo, h, w, max_level, min_level);
+      lo = li.lo;
+      hi = li.hi;
+    }
+    const Taps t = make_taps(grid_n + ((size_t)oy * wo + ox) * 2, h, w, padding_mode);
+    if (ix_nw) ix_nw[o] = t.x0;
+    if (iy_nw) iy_nw[o] = t.y0;
+    if (lvl_floor) lvl_floor[o] = lo;
+    if (lvl_ceil) lvl_ceil[o] = hi;
+  }
+}
+
 // ---------------------------------------------------------------- backward
 
 __device__ __forceinline__ void scatter_taps(float* __restrict__ gimg, int wl, const Axis ay[2], const Axis ax[2],
@@ -461,6 +493,19 @@ extern "C" int gg_mipmap_warp_fwd_f32(float* out, float* levels_out, const float
   mipmap_warp_fwd_kernel<<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(
       out, levels_out, pyr, grid, n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, padding_mode, antialias);
   return gg::launch_status("mipmap_warp_fwd");
+}
+
+extern "C" int gg_mipmap_warp_indices_f32(int* ix_nw, int* iy_nw, int* lvl_floor, int* lvl_ceil, const float* grid,
+                                          int n, int h, int w, int ho, int wo, float max_level, float min_level,
+                                          int padding_mode, int antialias, void* stream) {
+  if (n < 0 || h <= 0 || w <= 0 || ho < 0 || wo < 0 || !grid) return gg::fail(-2, "mipmap_warp_indices: bad sizes");
+  if (padding_mode < 0 || padding_mode > 2) return gg::fail(-2, "mipmap_warp_indices: padding_mode must be 0, 1 or 2");
+  if (antialias && max_level > 3.f) return gg::fail(-2, "mipmap_warp_indices: max_level <= 3");
+  const long long total = (long long)n * ho * wo;
+  if (total == 0) return 0;
+  mipmap_warp_indices_kernel<<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(
+      ix_nw, iy_nw, lvl_floor, lvl_ceil, grid, n, h, w, ho, wo, max_level, min_level, padding_mode, antialias);
+  return gg::launch_status("mipmap_warp_indices");
 }
 
 extern "C" int gg_mipmap_warp_bwd_f32(float* grad_grid, float* grad_pyr0, float* grad_pyr1, float* grad_pyr2,

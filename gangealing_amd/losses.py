@@ -108,62 +108,222 @@ def lpips_tail(feats, lin=None, eps=1e-10):
 
 
 VGG16_CFG = [(64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512)]
+# positions of the conv layers inside torchvision's vgg16().features, grouped by the reference's slices
+# (lpips_backbones.py:109-118): slice1 = features[0:4], slice2 = [4:9], slice3 = [9:16], slice4 = [16:23], slice5 = [23:30]
+_VGG16_SLICES = [(0, 4), (4, 9), (9, 16), (16, 23), (23, 30)]
+_VGG16_FEATURES = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
 
 
-class VGGPerceptualLoss(nn.Module):
-    """LPIPS-style distance on VGG16 features (relu1_2 ... relu5_3), lpips=False branch:
-    unit-normalise channels, squared difference, channel sum, spatial mean, summed over the 5 taps,
-    divided by 18 (lpips.py:13-17,26-28,181-206).  Weights are random unless a state_dict in
-    torchvision's vgg16().features layout is loaded (no checkpoint is reachable offline)."""
+def vgg16_feature_layers():
+    """[(index in torchvision's vgg16().features, module)] for indices 0..29 (conv / ReLU / max-pool)."""
+    layers, cin = [], 3
+    for v in _VGG16_FEATURES:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return list(enumerate(layers))[:30]
 
-    def __init__(self, seed=0):
+
+class vgg16(nn.Module):
+    """VGG16 trunk with the module names of the reference wrapper (lpips_backbones.py:98-140: `slice1`..`slice5`,
+    children named by their torchvision `features` index), so both torchvision-layout `features` state_dicts
+    (`pretrained_weights`, e.g. simclr_vgg_phase150.pt: keys "0.weight", "2.weight", ...) and reference LPIPS
+    checkpoints (keys "net.slice1.0.weight", ...) load.  Convolutions run on the MFMA kernels with bias + ReLU in
+    the epilogue; torchvision itself is not needed."""
+
+    def __init__(self, requires_grad=False, pretrained=True, pretrained_weights=None, seed=0):
         super().__init__()
+        layers = vgg16_feature_layers()
+        for si, (lo, hi) in enumerate(_VGG16_SLICES):
+            seq = nn.Sequential()
+            for idx, mod in layers[lo:hi]:
+                seq.add_module(str(idx), mod)
+            setattr(self, f'slice{si + 1}', seq)
+        self.N_slices = 5
+        self.weights_loaded = False
         gen = torch.Generator().manual_seed(seed)
-        self.convs = nn.ModuleList()
-        cin = 3
-        for stage in VGG16_CFG:
-            for cout in stage:
-                conv = nn.Conv2d(cin, cout, 3, padding=1)
-                with torch.no_grad():
-                    conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (cin * 9)) ** 0.5)
-                    conv.bias.zero_()
-                self.convs.append(conv)
-                cin = cout
-        self.register_buffer('shift', torch.tensor([-.030, -.088, -.188])[None, :, None, None])
-        self.register_buffer('scale', torch.tensor([.458, .448, .450])[None, :, None, None])
-        self.requires_grad_(False)
+        with torch.no_grad():                      # seeded He initialisation until real weights are loaded
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    fan_in = m.in_channels * 9
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * (2.0 / fan_in) ** 0.5)
+                    m.bias.zero_()
+        if pretrained_weights is not None:
+            self.load_features_state_dict(torch.load(pretrained_weights, map_location='cpu'), strict=True)
+        elif pretrained:
+            raise FileNotFoundError('vgg16(pretrained=True) would need torchvision\'s ImageNet weights, which cannot be '
+                                    'downloaded here; pass pretrained_weights=<features state_dict file> or pretrained=False')
+        if not requires_grad:
+            self.requires_grad_(False)
 
-    def features(self, x):
-        x = (x - self.shift) / self.scale
-        feats, i = [], 0
-        for si, stage in enumerate(VGG16_CFG):
-            if si > 0:
-                x = F.max_pool2d(x, 2, 2)
-            for _ in stage:
-                conv = self.convs[i]
-                if x.shape[1] % 32 == 0:     # conv + bias + ReLU in one kernel (alpha 0, gain 1)
-                    x = conv_mfma.conv3x3_bias_act(x, conv.weight, conv.bias, 0.0, 1.0)
-                else:                        # 3-channel stem: fp32 kernel + separate ReLU
-                    x = F.relu(conv_mfma.conv2d(x, conv.weight, conv.bias, stride=1, padding=1))
-                i += 1
+    def load_features_state_dict(self, sd, strict=True):
+        """`sd`: state_dict of torchvision's vgg16().features ("<idx>.weight" / "<idx>.bias"; a "features." prefix
+        is accepted)."""
+        sd = {k[len('features.'):] if k.startswith('features.') else k: v for k, v in sd.items()}
+        mapped, expected = {}, set()
+        for si, (lo, hi) in enumerate(_VGG16_SLICES):
+            for idx, mod in getattr(self, f'slice{si + 1}').named_children():
+                if isinstance(mod, nn.Conv2d):
+                    for leaf in ('weight', 'bias'):
+                        expected.add(f'{idx}.{leaf}')
+                        if f'{idx}.{leaf}' in sd:
+                            mapped[f'slice{si + 1}.{idx}.{leaf}'] = sd[f'{idx}.{leaf}']
+        unexpected = sorted(set(sd) - expected)
+        missing = sorted(expected - set(sd))
+        if strict and (unexpected or missing):
+            raise RuntimeError(f'VGG16 features state_dict: missing {missing}, unexpected {unexpected}')
+        result = self.load_state_dict(mapped, strict=False)
+        self.weights_loaded = True
+        return result
+
+    def forward(self, x):
+        feats = []
+        for si in range(5):
+            for mod in getattr(self, f'slice{si + 1}'):
+                if isinstance(mod, nn.Conv2d):
+                    if x.shape[1] % 32 == 0:     # conv + bias + ReLU in one kernel (alpha 0, gain 1)
+                        x = conv_mfma.conv3x3_bias_act(x, mod.weight, mod.bias, 0.0, 1.0)
+                    else:                        # 3-channel stem: fp32 kernel + separate ReLU
+                        x = F.relu(conv_mfma.conv2d(x, mod.weight, mod.bias, stride=1, padding=1))
+                elif isinstance(mod, nn.MaxPool2d):
+                    x = F.max_pool2d(x, 2, 2)
+                # nn.ReLU: applied in the convolution above
             feats.append(x)
         return feats
 
-    def forward(self, in0, in1):
+
+class ScalingLayer(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer('shift', torch.Tensor([-.030, -.088, -.188])[None, :, None, None])
+        self.register_buffer('scale', torch.Tensor([.458, .448, .450])[None, :, None, None])
+
+    def forward(self, inp):
+        return (inp - self.shift) / self.scale
+
+
+class NetLinLayer(nn.Module):
+    """1x1 convolution to one channel (lpips.py:235-245); evaluated inside the fused tail kernel."""
+
+    def __init__(self, chn_in, chn_out=1, use_dropout=False):
+        super().__init__()
+        layers = [nn.Dropout()] if use_dropout else []
+        layers += [nn.Conv2d(chn_in, chn_out, 1, stride=1, padding=0, bias=False)]
+        self.model = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class LPIPS(nn.Module):
+    """Perceptual distance on VGG16 features (models/losses/lpips.py:121-223), net='vgg' only.
+
+    lpips=False ("baseline", what --loss_fn vgg_ssl uses with the SimCLR-trained trunk): unit-normalise the channels
+    of each of the 5 taps, squared difference, channel sum, spatial mean, summed over taps.  lpips=True: the learned
+    non-negative 1x1 `lin` layers weight the channels instead of the plain sum.  normalize -> diff^2 -> lin / sum ->
+    spatial mean is one kernel per tap (csrc/lpips.hip); both images go through the trunk as one batch."""
+
+    def __init__(self, pretrained=True, net='vgg', version='0.1', lpips=True, spatial=False, pnet_rand=False,
+                 pnet_tune=False, use_dropout=True, model_path='pretrained/lpips_vgg_v0.1.pt', eval_mode=True,
+                 verbose=False, pretrained_weights=None):
+        super().__init__()
+        if net not in ('vgg', 'vgg16'):
+            raise NotImplementedError(f'LPIPS trunk {net!r}: GANgealing only uses VGG16 (lpips.py:15,19)')
+        if spatial:
+            raise NotImplementedError('spatial LPIPS maps are not used on the training path')
+        self.pnet_type, self.pnet_tune, self.pnet_rand = net, pnet_tune, pnet_rand
+        self.spatial, self.lpips, self.version = spatial, lpips, version
+        self.scaling_layer = ScalingLayer()
+        self.chns = [64, 128, 256, 512, 512]
+        self.L = len(self.chns)
+        self.net = vgg16(pretrained=not pnet_rand, requires_grad=pnet_tune, pretrained_weights=pretrained_weights)
+        self.lins_loaded = False
+        if lpips:
+            self.lin0 = NetLinLayer(self.chns[0], use_dropout=use_dropout)
+            self.lin1 = NetLinLayer(self.chns[1], use_dropout=use_dropout)
+            self.lin2 = NetLinLayer(self.chns[2], use_dropout=use_dropout)
+            self.lin3 = NetLinLayer(self.chns[3], use_dropout=use_dropout)
+            self.lin4 = NetLinLayer(self.chns[4], use_dropout=use_dropout)
+            self.lins = nn.ModuleList([self.lin0, self.lin1, self.lin2, self.lin3, self.lin4])
+            if pretrained:
+                self.load_state_dict(torch.load(model_path, map_location='cpu'), strict=False)
+                self.lins_loaded = True
+        if eval_mode:
+            self.eval()
+
+    def forward(self, in0, in1, retPerLayer=False, normalize=False):
+        if normalize:
+            in0, in1 = 2 * in0 - 1, 2 * in1 - 1
         n = in0.shape[0]
-        feats = self.features(torch.cat([in0, in1], 0))       # one batched pass for both images
-        val = 0
-        for f in feats:
+        x = torch.cat([in0, in1], 0)                      # one batched pass for both images
+        if self.version == '0.1':
+            x = self.scaling_layer(x)
+        feats = self.net(x)
+        res = []
+        for kk, f in enumerate(feats):
+            lin = None
+            if self.lpips:
+                if self.training and any(isinstance(m, nn.Dropout) for m in self.lins[kk].model):
+                    raise NotImplementedError('LPIPS lin layers with active dropout (training mode) are not fused')
+                lin = self.lins[kk].model[-1].weight
             if f.dtype == torch.float32 and 'lpips_tail' not in conv_mfma.DISABLED:
-                val = val + lpips_tail(f).view(n, 1, 1, 1)     # normalize -> diff^2 -> channel sum -> mean, one kernel
+                res.append(lpips_tail(f, lin).view(n, 1, 1, 1))
                 continue
             f = f / (torch.sqrt(torch.sum(f ** 2, dim=1, keepdim=True)) + 1e-10)
             d = (f[:n] - f[n:]) ** 2
-            val = val + d.sum(dim=1, keepdim=True).mean(dim=(2, 3), keepdim=True)
-        return val / 18.0
+            d = d.sum(dim=1, keepdim=True) if lin is None else F.conv2d(d, lin)
+            res.append(d.mean(dim=(2, 3), keepdim=True))
+        val = res[0]
+        for r in res[1:]:
+            val = val + r
+        return (val, res) if retPerLayer else val
 
 
-def get_perceptual_loss(loss_fn, device):
-    if loss_fn not in ('vgg_ssl', 'lpips'):
-        raise NotImplementedError(loss_fn)
-    return VGGPerceptualLoss().to(device)
+class _Scaled(nn.Module):
+    """loss_fn(x, y) / 18 as a module (get_perceptual_loss wraps vgg_ssl in a lambda, lpips.py:13-17)."""
+
+    def __init__(self, inner, divisor):
+        super().__init__()
+        self.inner, self.divisor = inner, divisor
+
+    def forward(self, x, y):
+        return self.inner(x, y) / self.divisor
+
+
+VGG_SSL_WEIGHTS = 'pretrained/simclr_vgg_phase150.pt'
+LPIPS_WEIGHTS = 'pretrained/lpips_vgg_v0.1.pt'
+
+
+def get_perceptual_loss(loss_fn, device, weights=None, allow_random=True):
+    """lpips.py:11-23.  The reference downloads its weights; here they must already be on disk (`weights`, default the
+    reference's `pretrained/...` path).  Without them: `allow_random` -> a warning and a seeded random trunk (the
+    synthetic benchmark / parity configuration), else FileNotFoundError."""
+    import os
+    import warnings
+    if loss_fn == 'vgg_ssl':
+        path = VGG_SSL_WEIGHTS if weights is None else weights
+        have = os.path.isfile(path)
+        if not have and not allow_random:
+            raise FileNotFoundError(f'{path}: SimCLR VGG16 weights not found')
+        if not have:
+            warnings.warn(f'perceptual loss: {path} not found - using a RANDOMLY INITIALISED VGG16 trunk '
+                          f'(synthetic benchmark configuration; not a training objective)')
+        model = LPIPS(net='vgg', lpips=False, pnet_rand=True, pretrained_weights=path if have else None)
+        return _Scaled(model, 18.0).to(device)
+    if loss_fn == 'lpips':
+        path = LPIPS_WEIGHTS if weights is None else weights
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f'{path}: LPIPS needs its learned lin layers and an ImageNet VGG16 trunk; neither '
+                                    f'can be downloaded here.  Build LPIPS(...) yourself and load a state_dict.')
+        model = LPIPS(net='vgg', pnet_rand=True, pretrained=False)
+        model.load_state_dict(torch.load(path, map_location='cpu'), strict=False)
+        model.lins_loaded = True
+        return model.to(device)
+    raise NotImplementedError(loss_fn)
+
+
+# round-1 name (bench / tests): the vgg_ssl form with a random trunk
+def VGGPerceptualLoss(seed=0):
+    return _Scaled(LPIPS(net='vgg', lpips=False, pnet_rand=True), 18.0)

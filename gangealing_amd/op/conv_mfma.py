@@ -228,11 +228,51 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
     return y
 
 
-# Gradient slots: weight storage address -> the tensor its gradient is ACCUMULATED into (a view of the trainer's
-# flat, zero-initialised gradient arena; train_step.FlatArena registers them).  For a registered weight the
-# backward adds the weight gradient straight into the slot (gg_conv2d_wgrad_acc_f32) and hands autograd no
-# gradient: no per-layer memset, no temporary and no AccumulateGrad add - two tiny launches less per layer.
+# Gradient slots: weight storage address -> (the tensor its gradient is ACCUMULATED into, weak reference to the
+# parameter).  The slot is a view of the trainer's flat, zero-initialised gradient arena; train_step.FlatArena
+# registers the trainable conv weights.  Inside a `with grad_slots():` block (the trainer wraps its own backward in
+# one) the backward of a registered weight adds the weight gradient straight into the slot
+# (gg_conv2d_wgrad_acc_f32) and hands autograd no gradient: no per-layer memset, no temporary and no AccumulateGrad
+# add - two tiny launches less per layer.  Outside such a block (torch.autograd.grad, a diagnostic backward, a
+# second loss) the registry is ignored and the gradient is returned to autograd as usual.
 GRAD_SLOTS = {}
+_SLOTS_ACTIVE = False
+
+
+class grad_slots:
+    """Context manager: weight gradients of registered parameters accumulate into their arena slots."""
+
+    def __enter__(self):
+        global _SLOTS_ACTIVE
+        self.prev = _SLOTS_ACTIVE
+        _SLOTS_ACTIVE = True
+        return self
+
+    def __exit__(self, *exc):
+        global _SLOTS_ACTIVE
+        _SLOTS_ACTIVE = self.prev
+        return False
+
+
+def register_grad_slot(param, slot):
+    import weakref
+    GRAD_SLOTS[param.data_ptr()] = (slot, weakref.ref(param))
+
+
+def _slot_for(weight):
+    """The registered accumulation slot of `weight`, or None (registry off / not registered / the address now
+    belongs to some other tensor)."""
+    if not _SLOTS_ACTIVE or 'slots' in DISABLED:
+        return None
+    ent = GRAD_SLOTS.get(weight.data_ptr())
+    if ent is None:
+        return None
+    slot, ref = ent
+    owner = ref()
+    if owner is None or owner.data_ptr() != weight.data_ptr() or owner.shape != weight.shape or \
+            slot.shape != weight.shape or not slot.is_contiguous():
+        return None
+    return slot
 # developer A/B switches (comma separated names in GG_DISABLE): slots, style_demod, fuse_act, wgrad_rows, lpips_tail,
 # pack_registry, mask_dgrad, torgb_fuse
 DISABLED = frozenset(filter(None, os.environ.get('GG_DISABLE', '').split(',')))
@@ -345,9 +385,7 @@ class _Conv2d(Function):
                     dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 0)
                     dx = dx[..., :h, :w].contiguous() if dx.shape[-2:] != (h, w) else dx
         if ctx.needs_input_grad[1]:
-            slot = GRAD_SLOTS.get(weight.data_ptr()) if (GRAD_SLOTS and 'slots' not in DISABLED) else None
-            if slot is not None and (slot.shape != weight.shape or not slot.is_contiguous()):
-                slot = None
+            slot = _slot_for(weight)
             if not transposed:
                 dw = conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, padding, wscale, into=slot)
             else:
@@ -393,9 +431,7 @@ class _Conv3x3BiasAct(Function):
                 return dx, None, None, None, None, None
         slot = None
         if ctx.needs_input_grad[1]:
-            slot = GRAD_SLOTS.get(weight.data_ptr()) if (GRAD_SLOTS and 'slots' not in DISABLED) else None
-            if slot is not None and (slot.shape != weight.shape or not slot.is_contiguous()):
-                slot = None
+            slot = _slot_for(weight)
         if ctx.needs_input_grad[1] and _LIMBS[PRECISION] == 2 and w % 32 == 0 and 'mask_wgrad' in ENABLED \
                 and 'wgrad_rows' not in DISABLED:
             # trainable layer on the row-streaming wgrad kernel: the leaky-ReLU backward rides in the loaders of both

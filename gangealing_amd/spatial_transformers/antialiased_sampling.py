@@ -112,6 +112,20 @@ def _reflect_pad_adjoint(g, pad_l, pad_r):
     return gx
 
 
+def warp_indices(grid, height, width, max_num_levels=3.5, min_level=0.0, padding_mode='border', antialias=True):
+    """The integer by-products of MipmapWarp / Warp for `grid` (N,ho,wo,2) sampling an (height, width) image:
+    (ix_nw, iy_nw, floor(level), ceil(level)) as int32 (N,ho,wo) tensors, computed by the device functions the
+    sampling kernels use (gg_mipmap_warp_indices_f32).  The number of stack levels the reference would build is
+    `int(ceil_level.max()) + 1` (antialiased_sampling.py:52)."""
+    _check(grid, 'warp_indices')
+    grid = grid.contiguous()
+    n, ho, wo, _ = grid.shape
+    outs = [torch.empty((n, ho, wo), dtype=torch.int32, device=grid.device) for _ in range(4)]
+    _lib.call('gg_mipmap_warp_indices_f32', outs[0], outs[1], outs[2], outs[3], grid, n, height, width, ho, wo,
+              float(max_num_levels - 1.0), float(min_level), _PAD_MODES[padding_mode], int(antialias))
+    return tuple(outs)
+
+
 class Warp(nn.Module):
     """Spatial transform without anti-aliasing == F.grid_sample(..., align_corners=False) (:9-16)."""
 

@@ -13,6 +13,22 @@ from ..stylegan2.networks import EqualLinear, ConvLayer, ResBlock, CHANNELS
 from .point_transfer import ComposedStnPointOps, SingleStnPointOps, unravel_index  # noqa: F401
 
 
+def load_filtered_state_dict(module, state_dict, strict, ignore):
+    """The reference drops a few derived buffers from the checkpoint and then loads NON-strictly
+    (spatial_transformer.py:378-385,722-726; cluster_classifier.py:98-101), so a truncated or wrong-architecture
+    checkpoint loads silently.  Same filtering here, but with strict=True (the default) a missing PARAMETER or a key
+    the module does not know raises, as nn.Module.load_state_dict would; derived buffers may be absent."""
+    filtered = {k: v for k, v in state_dict.items() if k not in ignore}
+    result = nn.Module.load_state_dict(module, filtered, strict=False)
+    if strict:
+        params = {n for n, _ in module.named_parameters()}
+        missing = [k for k in result.missing_keys if k in params]
+        if missing or result.unexpected_keys:
+            raise RuntimeError(f'Error(s) in loading state_dict for {module.__class__.__name__}: '
+                               f'missing parameter(s) {missing}, unexpected key(s) {list(result.unexpected_keys)}')
+    return result
+
+
 def get_stn(transforms, **stn_kwargs):
     assert isinstance(transforms, (str, list))
     if isinstance(transforms, str):
@@ -68,7 +84,7 @@ class SpatialTransformer(SingleStnPointOps, nn.Module):
     def load_state_dict(self, state_dict, strict=True):
         ignore = {'warp_head.one_hot', 'input_downsample.kernel_horz', 'input_downsample.kernel_vert',
                   'warp_head.rebias'}
-        return super().load_state_dict({k: v for k, v in state_dict.items() if k not in ignore}, False)
+        return load_filtered_state_dict(self, state_dict, strict, ignore)
 
     def forward(self, input_img, output_resolution=None, iters=1, return_warp=False, return_flow=False,
                 return_intermediates=False, return_out_of_bounds=False, intermediate_output_resolution=None,
@@ -130,7 +146,7 @@ class ComposedSTN(ComposedStnPointOps, nn.Module):
         for i in range(len(self.stns)):
             ignore |= {f'stns.{i}.input_downsample.kernel_horz', f'stns.{i}.input_downsample.kernel_vert',
                        f'stns.{i}.warp_head.rebias'}
-        return super().load_state_dict({k: v for k, v in state_dict.items() if k not in ignore}, False)
+        return load_filtered_state_dict(self, state_dict, strict, ignore)
 
     def forward(self, input_img, return_warp=None, return_flow=False, return_sim=False, return_intermediates=False,
                 output_resolution=None, unfold=False, iters=1, alpha=None, warp_policy='cartesian',

@@ -17,6 +17,7 @@ import torch.nn as nn
 from . import _lib
 from .op import conv_mfma
 from . import distributed as gdist
+from .annealing import DecayingCosineAnnealingWarmRestarts, get_psi_annealing_fn
 from .latent_learner import DirectionInterpolator
 from .losses import gangealing_loss, gangealing_cluster_loss, flow_losses, get_perceptual_loss
 from .spatial_transformers.antialiased_sampling import BilinearDownsample
@@ -44,8 +45,9 @@ class FlatArena:
                 self.param[off:off + n].copy_(p.reshape(-1))
                 p.data = self.param[off:off + n].view(p.shape)
                 p.grad = self.grad[off:off + n].view(p.shape)
-                if p.dim() == 4:         # conv weights: the backward adds straight into the arena (conv_mfma.GRAD_SLOTS)
-                    conv_mfma.GRAD_SLOTS[p.data_ptr()] = p.grad
+                if p.dim() == 4 and p.requires_grad:
+                    # trainable conv weights: inside `with conv_mfma.grad_slots():` the backward adds straight into the arena
+                    conv_mfma.register_grad_slot(p, p.grad)
                 off += n
         self.params = params
         self.step_count = 0
@@ -53,9 +55,9 @@ class FlatArena:
     def release(self):
         """Forget the gradient slots of this arena (the registry would otherwise keep the arena alive)."""
         for p in getattr(self, 'params', ()):
-            slot = conv_mfma.GRAD_SLOTS.get(p.data_ptr())
-            if slot is not None and slot.data_ptr() >= self.grad.data_ptr() and \
-                    slot.data_ptr() < self.grad.data_ptr() + 4 * self.numel:
+            ent = conv_mfma.GRAD_SLOTS.get(p.data_ptr())
+            if ent is not None and ent[0].data_ptr() >= self.grad.data_ptr() and \
+                    ent[0].data_ptr() < self.grad.data_ptr() + 4 * self.numel:
                 del conv_mfma.GRAD_SLOTS[p.data_ptr()]
 
     def __del__(self):
@@ -71,20 +73,70 @@ class FlatArena:
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + n].view(p.shape)
-                if p.dim() == 4:
-                    conv_mfma.GRAD_SLOTS[p.data_ptr()] = p.grad
+                if p.dim() == 4 and p.requires_grad:
+                    conv_mfma.register_grad_slot(p, p.grad)
             off += n
 
+    def touch(self):
+        """Tell autograd that the arena was rewritten through raw pointers.  `p.data = view` gave every parameter its
+        OWN version counter (bumping the arena tensor's does not reach them), and everything cached against parameter
+        values - conv_mfma's weight packs, EqualLinear's scaled weights - is keyed on those counters."""
+        torch.autograd.graph.increment_version(self.params)
+        torch.autograd.graph.increment_version(self.param)
 
-def adam_ema_step(arena, lr, ema_flat=None, ema_decay=0.0, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    # ---- torch.optim.Adam-compatible optimiser state (train.py:22-28 stores t_optim / ll_optim state_dicts) ----
+    def optim_state_dict(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        state, off = {}, 0
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            state[i] = {'step': torch.tensor(float(self.step_count)),
+                        'exp_avg': self.exp_avg[off:off + n].view(p.shape).clone(),
+                        'exp_avg_sq': self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+            off += n
+        group = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                     capturable=False, differentiable=False, fused=None, params=list(range(len(self.params))))
+        return {'state': state, 'param_groups': [group]}
+
+    def load_optim_state_dict(self, sd):
+        """Accepts the state_dict of a torch.optim.Adam over the same parameter list (reference checkpoints).
+        -> the stored learning rate."""
+        groups = sd['param_groups']
+        order = [i for g in groups for i in g['params']]
+        if len(order) != len(self.params):
+            raise ValueError(f'optimizer state has {len(order)} parameters, the arena {len(self.params)}')
+        steps, off = set(), 0
+        with torch.no_grad():
+            for idx, p in zip(order, self.params):
+                n = p.numel()
+                st = sd['state'].get(idx)
+                if st is None:                       # parameter never stepped
+                    self.exp_avg[off:off + n].zero_()
+                    self.exp_avg_sq[off:off + n].zero_()
+                else:
+                    if tuple(st['exp_avg'].shape) != tuple(p.shape):
+                        raise ValueError(f'optimizer state {idx}: shape {tuple(st["exp_avg"].shape)} vs {tuple(p.shape)}')
+                    self.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1))
+                    self.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+                    steps.add(int(float(st['step'])))
+                off += n
+        if len(steps) > 1:
+            raise ValueError(f'per-parameter step counts differ ({sorted(steps)}): the fused kernel keeps one')
+        self.step_count = steps.pop() if steps else 0
+        return groups[0]['lr']
+
+
+def adam_ema_step(arena, lr, ema_arena=None, ema_decay=0.0, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    """Adam over `arena` and (optionally) the EMA update of `ema_arena` (a FlatArena of the same layout) in one
+    streaming kernel."""
     arena.step_count += 1
-    _lib.call('gg_adam_ema_f32', arena.param, arena.exp_avg, arena.exp_avg_sq, ema_flat, arena.grad, arena.numel,
+    _lib.call('gg_adam_ema_f32', arena.param, arena.exp_avg, arena.exp_avg_sq,
+              None if ema_arena is None else ema_arena.param, arena.grad, arena.numel,
               lr, betas[0], betas[1], eps, arena.step_count, ema_decay, grad_scale)
-    # the kernel wrote through raw pointers: tell autograd's version counters (shared by the parameter views), so
-    # that anything cached against the old values - e.g. conv_mfma's weight packs - is recognised as stale
-    torch.autograd.graph.increment_version(arena.param)
-    if ema_flat is not None:
-        torch.autograd.graph.increment_version(ema_flat)
+    # the kernel wrote through raw pointers: bump the version counters of the parameters themselves, so that
+    # anything cached against the old values (weight packs, scaled EqualLinear weights) is recognised as stale
+    arena.touch()
+    if ema_arena is not None:
+        ema_arena.touch()
 
 
 def cosine_psi(step, total):
@@ -102,7 +154,8 @@ class GangealingTrainer:
                  num_heads=1, flips=False, dim_latent=512, n_mlp=8, gen_channel_multiplier=2,
                  stn_channel_multiplier=0.5, inject=5, ndirs=1, padding_mode='reflection', tv_weight=1000.0,
                  flow_identity_weight=1.0, stn_lr=1e-3, ll_lr=1e-2, sample_from_full_res=False, freeze_ll=False,
-                 loss_fn='vgg_ssl', seed=0, perturb_heads=0.0, pipeline_update=None):
+                 loss_fn='vgg_ssl', seed=0, perturb_heads=0.0, pipeline_update=None, anneal_psi=150000,
+                 anneal_fn='cosine', period=37500, decay=0.9, tm=2):
         self.device = device
         self._pending = None
         self.batch = batch
@@ -152,6 +205,11 @@ class GangealingTrainer:
         # is a collective to hide
         self.pipeline_update = (world > 1) if pipeline_update is None else bool(pipeline_update)
         self.stn.register_forward_pre_hook(lambda module, inputs: self.flush())
+        # psi annealing + learning-rate schedules (train.py:206-207, 92-97, 129-132)
+        self.anneal_psi, self.period = anneal_psi, period
+        self.anneal_fn = get_psi_annealing_fn(anneal_fn)
+        self.t_sched = DecayingCosineAnnealingWarmRestarts(stn_lr, T_0=1, T_mult=tm, decay=decay)
+        self.ll_sched = DecayingCosineAnnealingWarmRestarts(ll_lr, T_0=1, T_mult=tm, decay=decay)
 
     def loss(self, psi):
         common = dict(sample_from_full_res=self.sample_from_full_res, padding_mode=self.padding_mode)
@@ -171,7 +229,49 @@ class GangealingTrainer:
         return total, {'p': ploss.detach(), 'tv': tv.detach() if tv is not None else None,
                        'f': idl.detach() if idl is not None else None}
 
-    def step(self, psi=0.5):
+    def train_iteration(self, i):
+        """Iteration `i` (1-based, as train.py:89-134 counts): psi from the annealing schedule while i <= anneal_psi,
+        then psi = 0 and the two learning-rate schedulers advance by the fractional epoch (i - anneal_psi) / period
+        after the optimizer steps.  -> (loss parts, psi)."""
+        if i <= self.anneal_psi:
+            psi, psi_is_fixed = float(self.anneal_fn(i, 1.0, 0.0, self.anneal_psi)), False
+        else:
+            psi, psi_is_fixed = 0.0, True
+        parts = self.step(psi, stn_lr=self.t_sched.get_last_lr()[0], ll_lr=self.ll_sched.get_last_lr()[0])
+        if psi_is_fixed:
+            epoch = max(0, (i - self.anneal_psi) / self.period)
+            self.t_sched.step(epoch)
+            self.ll_sched.step(epoch)
+        return parts, psi
+
+    def state_dict(self):
+        """Checkpoint in the reference's layout (train.py:22-28; `args` is the caller's to add)."""
+        self.flush()
+        return {'g_ema': self.generator.state_dict(), 't': self.stn.state_dict(), 't_ema': self.t_ema.state_dict(),
+                't_optim': self.stn_arena.optim_state_dict(self.t_sched.get_last_lr()[0]),
+                't_sched': self.t_sched.state_dict(), 'll': self.ll.state_dict(),
+                'll_optim': self.ll_arena.optim_state_dict(self.ll_sched.get_last_lr()[0]),
+                'll_sched': self.ll_sched.state_dict()}
+
+    def load_state_dict(self, ckpt, load_G_only=False):
+        """train.py:216-228: `g_ema` always; the rest unless load_G_only / absent (KeyError -> G only)."""
+        self.flush()
+        self.generator.load_state_dict(ckpt['g_ema'])
+        if load_G_only or 't' not in ckpt:
+            return False
+        self.stn.load_state_dict(ckpt['t'])
+        self.t_ema.load_state_dict(ckpt['t_ema'])
+        self.stn_arena.load_optim_state_dict(ckpt['t_optim'])
+        self.t_sched.load_state_dict(ckpt['t_sched'])
+        self.ll.load_state_dict(ckpt['ll'])
+        self.ll_arena.load_optim_state_dict(ckpt['ll_optim'])
+        self.ll_sched.load_state_dict(ckpt['ll_sched'])
+        for arena in (self.stn_arena, self.ema_arena, self.ll_arena):
+            arena.touch()                        # copy_ into the views already bumped them; cheap and explicit
+        conv_mfma.repack_trainable()
+        return True
+
+    def step(self, psi=0.5, stn_lr=None, ll_lr=None):
         """One iteration: loss forward, backward, gradient all-reduce, Adam x2, EMA (train.py:106-134).
 
         With `pipeline_update` (default: on when world > 1) the STN half of the update is deferred: the 172 MB
@@ -183,7 +283,8 @@ class GangealingTrainer:
             self.stn_arena.zero_grad()
         self.ll_arena.zero_grad()
         total, parts = self.loss(psi)            # (its STN forward first applies a pending update and zeroes the grads)
-        total.backward()
+        with conv_mfma.grad_slots():             # conv weight gradients accumulate straight into the arena
+            total.backward()
         scale = 1.0 / self.world
         if self.world > 1:
             import torch.distributed as dist
@@ -191,26 +292,27 @@ class GangealingTrainer:
             work = dist.all_reduce(self.stn_arena.grad, op=dist.ReduceOp.SUM, async_op=self.pipeline_update)
         else:
             work = None
+        stn_lr = self.stn_lr if stn_lr is None else stn_lr
         if not self.freeze_ll:
-            adam_ema_step(self.ll_arena, self.ll_lr, grad_scale=scale)
+            adam_ema_step(self.ll_arena, self.ll_lr if ll_lr is None else ll_lr, grad_scale=scale)
         if self.pipeline_update:
-            self._pending = (work, scale)
+            self._pending = (work, scale, stn_lr)
         else:
-            self._apply_stn_update(scale)
+            self._apply_stn_update(scale, stn_lr)
         return parts
 
-    def _apply_stn_update(self, scale):
-        adam_ema_step(self.stn_arena, self.stn_lr, self.ema_arena.param, self.ema_decay, grad_scale=scale)
+    def _apply_stn_update(self, scale, lr):
+        adam_ema_step(self.stn_arena, lr, self.ema_arena, self.ema_decay, grad_scale=scale)
         conv_mfma.repack_trainable()         # all STN weight packs (forward + data-gradient layouts) in one launch
 
     def flush(self):
         """Apply a deferred STN update (no-op when nothing is pending)."""
         if self._pending is not None:
-            work, scale = self._pending
+            work, scale, lr = self._pending
             self._pending = None
             if work is not None:
                 work.wait()                      # the compute stream waits for the collective; the host does not
-            self._apply_stn_update(scale)
+            self._apply_stn_update(scale, lr)
             self.stn_arena.zero_grad()
 
 

@@ -134,6 +134,15 @@ int gg_mipmap_warp_fwd_f32(float* out, float* levels_out,
                            const float* grid, int n, int c, int h, int w, int hp, int wp, int pad_l,
                            int ho, int wo, float max_level, float min_level,
                            int padding_mode, int antialias, void* stream);
+/* The integer by-products of the sampling above, per output pixel (N,ho,wo) int32, from the same device functions
+ * the forward / backward kernels use: ix_nw = floor(ix), iy_nw = floor(iy) with (ix, iy) the source coordinates after
+ * grid_sampler_compute_source_index (ATen GridSampler.h:143-160: unnormalise, then clip / reflect for the padding
+ * mode; 'zeros' leaves them unclipped, so the indices may lie outside the image), and floor / ceil of the clamped
+ * mip level (antialiased_sampling.py:49,208-209,226-227).  Any output pointer may be NULL.  north_star's "bit-exact
+ * warp grid indices" is tested on these (tests/test_gpu_indices.py). */
+int gg_mipmap_warp_indices_f32(int* ix_nw, int* iy_nw, int* lvl_floor, int* lvl_ceil, const float* grid,
+                               int n, int h, int w, int ho, int wo, float max_level, float min_level,
+                               int padding_mode, int antialias, void* stream);
 /* Backward.  grad_grid (N,ho,wo,2) is overwritten; grad_pyr{0..3} ACCUMULATE (pass NULL for all four
  * to skip the image gradient).  Includes the gradient that reaches the grid through the fractional
  * mip level (levels % 1.0 is differentiable in the reference's autograd graph). */

@@ -1,0 +1,205 @@
+"""BASELINE.json's own configurations as parity cases.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+One driver, `run_config(api, cfg, device)`, evaluates a training-loss step through an `api` namespace that holds the
+reference's public names (Generator, get_stn, DirectionInterpolator, LPIPS, BilinearDownsample, gangealing_loss,
+gangealing_cluster_loss, total_variation_loss, flow_identity_loss).  oracle/make_golden_configs.py passes the modules
+imported from /root/reference (authoring container, CPU) and stores what comes back under tests/golden/; the GPU tests
+pass gangealing_amd's modules and compare - the same code drives both, so the test reads like the reference's
+train.py:106-124.  Everything random is replaced by name-keyed deterministic arrays (oracle/det_weights.py): weights,
+z (torch.randn is patched for the (batch, dim_latent) draw of loss.py:24) and the per-layer noise images (the
+generator is called through NoiseFeeder, which turns `noise=None` into explicit lists).
+
+Configurations:
+  c2  LSUN Cats 256^2, similarity+flow STN at 128^2, per-GPU batch 16, vgg_ssl loss form      (the benchmark config)
+  c4  CelebA-HQ 512^2 flags (scripts/training/celeba.sh:4-6 at gen_size 512): BilinearDownsample(4), border padding,
+      inject 6, ndirs 512, sample_from_full_res, tv 2500, LPIPS with lin layers; batch 2
+  c5  LSUN Cars clustering (scripts/training/lsun_cars.sh:4-7): num_heads 4, flips, ndirs 5, inject 6,
+      sample_from_full_res, reflection padding, tv 2500, LPIPS with lin layers; batch 2 (G pass 2 at 8, flow STN and
+      VGG at 16 / 32 images)
+"""
+import contextlib
+import types
+
+import numpy as np
+import torch
+
+from .det_weights import det_array, det_state_dict
+
+STN_RULES = (('warp_head.linear', 0.02), ('flow_out.2', 0.02), ('mask_out', 0.5))
+
+CONFIGS = {
+    'c2': dict(gen_size=256, flow_size=128, real_size=256, batch=16, transform=['similarity', 'flow'], num_heads=1,
+               flips=False, inject=5, ndirs=1, padding_mode='reflection', tv_weight=1000.0, flow_identity_weight=1.0,
+               sample_from_full_res=False, loss='vgg_ssl', psi=0.5),
+    'c4': dict(gen_size=512, flow_size=128, real_size=512, batch=2, transform=['similarity', 'flow'], num_heads=1,
+               flips=False, inject=6, ndirs=512, padding_mode='border', tv_weight=2500.0, flow_identity_weight=1.0,
+               sample_from_full_res=True, loss='lpips', psi=0.3),
+    'c5': dict(gen_size=256, flow_size=128, real_size=256, batch=2, transform=['similarity', 'flow'], num_heads=4,
+               flips=True, inject=6, ndirs=5, padding_mode='reflection', tv_weight=2500.0, flow_identity_weight=1.0,
+               sample_from_full_res=True, loss='lpips', psi=0.7),
+}
+
+
+def T(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def det_lpips_state_dict(module):
+    """Name-keyed weights for an LPIPS module (reference key names): He-scaled trunk convolutions so the activations
+    stay O(1) through 13 layers, small biases, non-negative lin layers (as trained LPIPS lins are)."""
+    sd = {}
+    for name, p in module.named_parameters():
+        if name.startswith('lins.'):
+            continue                                   # aliases of lin0..lin4
+        if 'lin' in name:
+            sd[name] = torch.from_numpy(np.abs(det_array(name, p.shape, 0.2)))
+        elif name.endswith('bias'):
+            sd[name] = torch.from_numpy(det_array(name, p.shape, 0.05))
+        else:
+            fan_in = p.shape[1] * p.shape[2] * p.shape[3]
+            sd[name] = torch.from_numpy(det_array(name, p.shape, (2.0 / fan_in) ** 0.5))
+    return sd
+
+
+class NoiseFeeder:
+    """Generator front that replaces `noise=None` by explicit, name-keyed noise images: call k of the step gets the
+    list noises[k] (loss.py:21-29 calls the generator twice per step with fresh noise each time)."""
+
+    def __init__(self, generator, tag, device):
+        self.generator, self.tag, self.device = generator, tag, device
+        self.n_latent = generator.n_latent
+        self.calls = 0
+        self.outputs = []
+
+    def noise_for(self, call, batch):
+        res = lambda i: 2 ** ((i + 5) // 2)
+        return [T(det_array(f'{self.tag}.noise{call}.{i}', (batch, 1, res(i), res(i))), self.device)
+                for i in range(self.generator.num_layers)]
+
+    def __call__(self, styles, noise=None, **kw):
+        batch = styles[0].shape[0]
+        out = self.generator(styles, noise=self.noise_for(self.calls, batch), **kw)
+        self.calls += 1
+        self.outputs.append(out[0])
+        return out
+
+
+class Tap:
+    """Callable front of a module that records what it returned (the losses only hand back scalars)."""
+
+    def __init__(self, module):
+        self.module = module
+        self.outputs = []
+
+    def __call__(self, *args, **kw):
+        out = self.module(*args, **kw)
+        self.outputs.append(out)
+        return out
+
+
+@contextlib.contextmanager
+def det_randn(tag, batch, dim_latent):
+    """torch.randn(batch, dim_latent, ...) -> the name-keyed z of this configuration (loss.py:24)."""
+    real = torch.randn
+
+    def fake(*size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+        if shape == (batch, dim_latent):
+            return T(det_array(f'{tag}.z', shape), kw.get('device', 'cpu'))
+        return real(*size, **kw)
+    torch.randn = fake
+    try:
+        yield
+    finally:
+        torch.randn = real
+
+
+def build_models(api, cfg, tag, device):
+    """Generator (frozen), STN, latent learner, perceptual loss and the fake->STN resize, with name-keyed weights."""
+    gen = api.Generator(cfg['gen_size'], 512, 8, channel_multiplier=2)
+    torch.nn.Module.load_state_dict(gen, det_state_dict(gen), strict=False)
+    gen = gen.to(device).eval().requires_grad_(False)
+    stn = api.get_stn(list(cfg['transform']), flow_size=cfg['flow_size'], supersize=cfg['real_size'],
+                      channel_multiplier=0.5, num_heads=cfg['num_heads'])
+    torch.nn.Module.load_state_dict(stn, det_state_dict(stn, STN_RULES), strict=False)
+    stn = stn.to(device)
+    ll = api.DirectionInterpolator(None, cfg['ndirs'], cfg['inject'], gen.n_latent, cfg['num_heads'])
+    with torch.no_grad():
+        ll.directions.copy_(torch.from_numpy(det_array(f'{tag}.ll.directions', (cfg['ndirs'], 512))))
+        ll.lat_mean.copy_(torch.from_numpy(det_array(f'{tag}.ll.lat_mean', (1, 512))))
+        ll.coefficients.copy_(torch.from_numpy(det_array(f'{tag}.ll.coefficients', (cfg['num_heads'], cfg['ndirs']),
+                                                         0.3)))
+    ll = ll.to(device)
+    lpips = cfg['loss'] == 'lpips'
+    net = api.LPIPS(net='vgg', lpips=lpips, pnet_rand=True, pretrained=False, verbose=False)
+    torch.nn.Module.load_state_dict(net, det_lpips_state_dict(net), strict=False)
+    net = net.to(device).eval()
+    if lpips:
+        loss_fn = net
+    else:
+        loss_fn = lambda x, y: net(x, y) / 18.0                 # lpips.py:17
+    factor = cfg['gen_size'] // cfg['flow_size']
+    resize = api.BilinearDownsample(factor, 3).to(device) if factor > 1 else torch.nn.Sequential()
+    return gen, stn, ll, loss_fn, resize
+
+
+def run_config(api, name, device, backward=True):
+    """One loss evaluation + backward of configuration `name` (train.py:106-124).  -> dict of tensors / floats:
+    unaligned, target, pred, delta_flow (the regularised one), ploss, tv, identity, total, grads {param name: grad}."""
+    cfg = CONFIGS[name]
+    tag = f'cfg.{name}'
+    gen, stn, ll, loss_fn, resize = build_models(api, cfg, tag, device)
+    feeder = NoiseFeeder(gen, tag, device)
+    stn_tap = Tap(stn)
+    resize_tap = Tap(resize)
+    clustering = cfg['num_heads'] > 1 or cfg['flips']
+    with det_randn(tag, cfg['batch'], 512):
+        common = dict(sample_from_full_res=cfg['sample_from_full_res'], padding_mode=cfg['padding_mode'])
+        if clustering:
+            ploss, delta = api.gangealing_cluster_loss(feeder, stn_tap, ll, loss_fn, resize_tap, cfg['psi'], cfg['batch'],
+                                                       512, False, cfg['num_heads'], cfg['flips'], device, **common)
+        else:
+            ploss, delta = api.gangealing_loss(feeder, stn_tap, ll, loss_fn, resize_tap, cfg['psi'], cfg['batch'], 512,
+                                               False, device, **common)
+    tv = api.total_variation_loss(delta)
+    idl = api.flow_identity_loss(delta)
+    total = ploss + cfg['tv_weight'] * tv + cfg['flow_identity_weight'] * idl
+    out = dict(unaligned=feeder.outputs[0].detach(), target=resize_tap.outputs[0].detach(),
+               pred=stn_tap.outputs[0][0].detach(), stn_delta=stn_tap.outputs[0][1].detach(),
+               delta_flow=delta.detach(), ploss=ploss.detach(), tv=tv.detach(), identity=idl.detach(),
+               total=total.detach())
+    if backward:
+        params = [(n, p) for n, p in stn.named_parameters()] + [('ll.coefficients', ll.coefficients)]
+        grads = torch.autograd.grad(total, [p for _, p in params], allow_unused=True)
+        out['grads'] = {n: g.detach() for (n, _), g in zip(params, grads) if g is not None}
+    return out
+
+
+# ---- compact storage of large tensors: the same slices are taken from the reference (when the fixture is written)
+# ---- and from the HIP path (when it is compared)
+
+def pack_batch(t, prefix):
+    """(N, ...) tensor -> {first sample in full, a strided subsample of every sample, per-sample float64 sums}."""
+    t = t.detach().cpu()
+    n = t.shape[0]
+    flat = t.reshape(n, -1)
+    stride = max(1, flat.shape[1] // 16384)
+    off = 3 % stride if stride > 1 else 0
+    return {f'{prefix}_first': t[0].numpy().copy(), f'{prefix}_sub': flat[:, off::stride].numpy().copy(),
+            f'{prefix}_sum': flat.double().sum(1).numpy(), f'{prefix}_abssum': flat.double().abs().sum(1).numpy()}
+
+
+def pack_grads(grads):
+    """{name: grad} -> ({name: norm}, {key: array}) with small gradients in full and a strided sample of large ones."""
+    norms, arrays = {}, {}
+    for name, g in grads.items():
+        g = g.detach().cpu()
+        norms[name] = float(g.double().norm())
+        flat = g.reshape(-1)
+        stride = max(1, flat.numel() // 2048)
+        arrays['grad_' + name.replace('.', '_')] = flat[::stride].numpy().copy()
+    return norms, arrays
+
+
+def api_namespace(**kw):
+    return types.SimpleNamespace(**kw)

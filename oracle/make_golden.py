@@ -454,6 +454,189 @@ def gen_splat_selfcheck():
     save('splat2d', cases)
 
 
+
+# ---------------------------------------------------------------------------------------------
+# integer by-products of the anti-aliased sampling ("bit-exact warp grid indices")
+
+def aten_source_index(g, size, mode):
+    """grid_sampler_compute_source_index (ATen/native/GridSampler.h:27-35,58-60,89-105,143-160), align_corners=False,
+    evaluated with float32 torch ops in ATen's order."""
+    size_f = torch.tensor(float(size), dtype=torch.float32)
+    x = ((g + 1) * size_f - 1) / 2
+    if mode == 'border':
+        x = torch.minimum(torch.tensor(float(size - 1)), torch.maximum(x, torch.tensor(0.0)))
+    elif mode == 'reflection':
+        twice_low, twice_high = -1, 2 * size - 1
+        mn = torch.tensor(twice_low / 2.0, dtype=torch.float32)
+        span = torch.tensor((twice_high - twice_low) / 2.0, dtype=torch.float32)
+        x = (x - mn).abs()
+        extra = torch.fmod(x, span)
+        flips = torch.floor(x / span).to(torch.int64)
+        x = torch.where(flips % 2 == 0, extra + mn, span - extra + mn)
+        x = torch.minimum(torch.tensor(float(size - 1)), torch.maximum(x, torch.tensor(0.0)))
+    return x
+
+
+def _check_indices_against_aten(grid, size, mode, ix, iy):
+    """Authoring-time self check of aten_source_index against the real F.grid_sample: (i) the bilinear sample built
+    from floor(ix), floor(iy) reproduces grid_sample's output; (ii) so does the derivative with respect to the grid
+    on a piecewise-LINEAR-free random image - at integer coordinates the one-sided derivative depends on which cell
+    floor() selected, so a wrong floor shows up as an O(1) error there."""
+    n, r = grid.shape[0], grid.shape[1]
+    img = rnd(f'idx.img{size}', (n, 2, size, size))
+    gd = grid.clone().requires_grad_(True)
+    out = F.grid_sample(img, gd, padding_mode=mode, align_corners=False)          # float32: ATen's own index arithmetic
+    gout = rnd(f'idx.gout{size}', tuple(out.shape))
+    (gg,) = torch.autograd.grad(out, gd, gout)
+    x0, y0 = torch.floor(ix).long(), torch.floor(iy).long()
+    tx, ty = (ix - x0).double(), (iy - y0).double()
+    img = img.double()
+
+    def tap(yy, xx):
+        ok = (xx >= 0) & (xx < size) & (yy >= 0) & (yy < size)
+        v = img[torch.arange(n)[:, None, None], :, yy.clamp(0, size - 1), xx.clamp(0, size - 1)]   # (n,r,r,c)
+        return v * ok[..., None]
+    nw, ne, sw, se = tap(y0, x0), tap(y0, x0 + 1), tap(y0 + 1, x0), tap(y0 + 1, x0 + 1)
+    manual = (nw * ((1 - tx) * (1 - ty))[..., None] + ne * (tx * (1 - ty))[..., None] +
+              sw * ((1 - tx) * ty)[..., None] + se * (tx * ty)[..., None]).permute(0, 3, 1, 2)
+    assert float((manual - out.detach().double()).abs().max()) < 1e-4
+    if mode == 'zeros':       # no clip / reflect multipliers: d ix / d gx = size / 2 everywhere
+        dix = ((ne - nw) * (1 - ty)[..., None] + (se - sw) * ty[..., None])
+        man_gx = (dix * gout.double().permute(0, 2, 3, 1)).sum(-1) * (size / 2.0)
+        err = (man_gx - gg[..., 0].double()).abs()
+        assert float(err.max()) < 1e-3, float(err.max())
+
+
+def special_grid(size, r, seed):
+    """(1, r, r, 2) grid whose source coordinates hit integers, half-integers, the reflection seams (-0.5, size-0.5,
+    and their images further out), each also nudged by +-1 ulp of the grid value; the rest is uniform noise over
+    [-2.5, 2.5] (far outside the image on both sides)."""
+    halves = np.arange(-2 * size, 3 * size + 0.5, 0.5, dtype=np.float64)
+    g = ((2 * halves + 1) / size - 1).astype(np.float32)        # exact for power-of-two sizes
+    vals = np.concatenate([g, np.nextafter(g, np.float32(np.inf)), np.nextafter(g, np.float32(-np.inf))])
+    rs = np.random.RandomState(seed)
+    total = r * r
+    fill = (rs.rand(max(total - len(vals), 0)) * 5 - 2.5).astype(np.float32)
+    gx = np.concatenate([vals, fill])[:total]
+    gy = gx.copy()
+    rs.shuffle(gx)
+    rs.shuffle(gy)
+    return torch.from_numpy(np.stack([gx, gy], -1).reshape(1, r, r, 2))
+
+
+def level_edge_grids(size):
+    """(B, 2, 2, 2) grids for size = 2^k + 1 (level coordinates are then 2^(k-1) * (g + 1): an exact scaling).  In
+    sample b the two columns are the points (0, 0) and (dx, dy) (both rows equal), so every pixel's neighbour
+    distance is sqrt(dx^2 + dy^2): dx is the base distance (1, 2, 4: level exactly 0 / 1 / 2) or one float below it,
+    and dy is tuned in float32 so that dx^2 + dy^2 lands on each of the floats next to base^2 (-6 .. +6 ulps) - the
+    points where floor / ceil of the level can flip.  Plus plain distances across the whole range and the 2.5 clamp."""
+    assert (size - 1) & (size - 2) == 0
+    half = np.float32((size - 1) / 2.0)
+    f32 = np.float32
+
+    def coord(gv):                       # antialiased_sampling.py:192-193 in float32
+        return f32(f32(f32(size - 1) * f32(gv + f32(1))) / f32(2))
+
+    def step(v, k):
+        for _ in range(abs(k)):
+            v = np.nextafter(v, f32(np.inf) if k > 0 else f32(-np.inf))
+        return v
+    points, hit = [], []
+    for base in (1.0, 2.0, 4.0):
+        for k in range(-6, 7):
+            target_sq = step(f32(base * base), k)
+            gx = f32(base / half - 1.0)
+            if k < 0:
+                gx = step(gx, -1)
+            dx = coord(gx) - coord(f32(-1.0))
+            need = float(target_sq) - float(f32(dx * dx))
+            if need < 0:
+                continue
+            guess = f32(np.sqrt(need) / half - 1.0)
+            for st in range(0, 200):
+                for sgn in (1, -1):
+                    gy = step(guess, sgn * st)
+                    dy = coord(gy) - coord(f32(-1.0))
+                    if f32(f32(dx * dx) + f32(dy * dy)) == target_sq:
+                        points.append((gx, gy))
+                        hit.append((base, k))
+                        break
+                else:
+                    continue
+                break
+    for d in (0.25, 0.999, 1.0, 1.5, 2.0, 3.0, 4.0, 5.0, 5.6568542, 5.66, 6.0, 8.0, 11.0):
+        points.append((f32(d / half - 1.0), f32(-1.0)))
+    g = np.full((len(points), 2, 2, 2), -1.0, dtype=np.float32)
+    for b, (gx, gy) in enumerate(points):
+        g[b, :, 1] = (gx, gy)
+    return torch.from_numpy(g), hit
+
+
+def gen_warp_indices():
+    from models.spatial_transformers.antialiased_sampling import MipmapWarp
+    cases = []
+    specs = []
+    for size, r in ((32, 32), (64, 48)):
+        specs.append((f'special{size}', special_grid(size, r, size), size))
+    for name, grid in make_grids(2, 24).items():
+        specs.append((name, grid, 32))
+    specs.append(('zoom_out_4_nonpow2', make_grids(1, 16)['zoom_out_4'], 30))
+    for size in (17, 33):
+        grids, hit = level_edge_grids(size)
+        assert len(hit) >= 30, hit               # the ulp-neighbourhoods of level 0 / 1 / 2 were actually reached
+        specs.append((f'level_edges{size}', grids, size))
+    max_num_levels, min_level = 3.5, 0.0
+    for name, grid, size in specs:
+        grid = grid.float().contiguous()
+        coords = MipmapWarp._get_coordinates(grid, size, size)
+        levels = MipmapWarp._get_mipmap_levels(coords, max_num_levels).clamp(min=min_level)
+        num_levels = int(levels.max().ceil().item()) + 1                      # antialiased_sampling.py:52
+        for mode in ('border', 'reflection', 'zeros'):
+            ix = aten_source_index(grid[..., 0], size, mode)
+            iy = aten_source_index(grid[..., 1], size, mode)
+            _check_indices_against_aten(grid, size, mode, ix, iy)
+            cases.append(dict(grid=grid, ix_nw=torch.floor(ix).to(torch.int32), iy_nw=torch.floor(iy).to(torch.int32),
+                              level_floor=levels.floor().to(torch.int32), level_ceil=levels.ceil().to(torch.int32),
+                              levels=levels,
+                              meta=dict(name=name, size=size, padding_mode=mode, max_num_levels=max_num_levels,
+                                        min_level=min_level, num_levels=num_levels)))
+    save('warp_indices', cases)
+
+
+# ---------------------------------------------------------------------------------------------
+
+def gen_annealing():
+    """psi annealing, lr_cycle_iters and the DecayingCosineAnnealingWarmRestarts learning-rate sequence exactly as
+    train.py drives them (:92-97,129-132), on a short mock schedule."""
+    from utils.annealing import DecayingCosineAnnealingWarmRestarts, lr_cycle_iters, get_psi_annealing_fn
+    import contextlib
+    import io
+    cases = []
+    for (anneal_psi, period, iters, tm, decay, base_lr) in [(10, 7.5, 120, 2, 0.9, 1e-3), (4, 3.0, 40, 1, 0.8, 1e-2),
+                                                            (6, 5.0, 200, 3, 0.5, 1.0)]:
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=base_lr)
+        sched = DecayingCosineAnnealingWarmRestarts(opt, T_0=1, T_mult=tm, decay=decay)
+        lrs, psis_cos, psis_lin = [], [], []
+        cos, lin = get_psi_annealing_fn('cosine'), get_psi_annealing_fn('linear')
+        for i in range(1, iters + 1):
+            lrs.append(opt.param_groups[0]['lr'])             # the rate the optimizer uses at iteration i
+            if i <= anneal_psi:
+                psis_cos.append(cos(i, 1.0, 0.0, anneal_psi).item())
+                psis_lin.append(lin(i, 1.0, 0.0, anneal_psi).item())
+            else:
+                sched.step(max(0, (i - anneal_psi) / period))
+        zero_iters = []
+        if tm > 1:                                            # (the reference divides by log(1) for tm == 1)
+            with contextlib.redirect_stdout(io.StringIO()):
+                zero_iters = lr_cycle_iters(anneal_psi, period, iters, tm)
+        cases.append(dict(lrs=np.array(lrs, dtype=np.float64), psi_cosine=np.array(psis_cos, dtype=np.float64),
+                          psi_linear=np.array(psis_lin, dtype=np.float64), zero_lr_iters=np.array(zero_iters),
+                          meta=dict(anneal_psi=anneal_psi, period=period, iters=iters, tm=tm, decay=decay,
+                                    base_lr=base_lr, sched_state=sched.state_dict()['T_i'])))
+    save('annealing', cases)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -463,7 +646,7 @@ if __name__ == '__main__':
     gens = dict(upfirdn2d=gen_upfirdn2d, fused_act=gen_fused_act, mipmap_warp=gen_mipmap_warp, heads=gen_heads,
                 misc=gen_misc, modconv=gen_modconv, generator=gen_generator, stn=gen_stn,
                 train_step=gen_train_step, splat=gen_splat_selfcheck, cluster_classifier=gen_cluster_classifier,
-                point_transfer=gen_point_transfer)
+                point_transfer=gen_point_transfer, warp_indices=gen_warp_indices, annealing=gen_annealing)
     for name, fn in gens.items():
         if only and name not in only:
             continue

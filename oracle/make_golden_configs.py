@@ -1,0 +1,150 @@
+"""Golden vectors at BASELINE.json's own configurations, produced by the REFERENCE on CPU.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py); authoring container only (needs /root/reference).
+
+    python oracle/make_golden_configs.py [c2_generator c2_stn c2 c4 c5 lpips]      # ~15 min on 8 cores for all
+
+Writes tests/golden/{c2_generator,c2_stn,cfg_c2,cfg_c4,cfg_c5,lpips}.npz.  The reference runs unmodified: its
+modules are imported exactly as oracle/make_golden.py does, plus a local VGG16 `features` stack placed where
+lpips_backbones.py:101 asks torchvision for one (torchvision is not installed; the layer list is torchvision's
+cfg 'D').  The loss steps are driven by oracle/config_cases.run_config - the same function the GPU tests call with
+gangealing_amd's modules.
+"""
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+from oracle.make_golden import import_reference, save, rnd          # noqa: E402
+from oracle.det_weights import det_state_dict                       # noqa: E402
+from oracle import config_cases as cc                               # noqa: E402
+
+
+def local_vgg16(pretrained=False, **kwargs):
+    """Stand-in for torchvision.models.vgg16: only `.features` is used (lpips_backbones.py:101)."""
+    cfg = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+    layers, cin = [], 3
+    for v in cfg:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return types.SimpleNamespace(features=nn.Sequential(*layers))
+
+
+def reference_api():
+    import_reference()
+    sys.modules['torchvision.models'].vgg16 = local_vgg16
+    from models.stylegan2.networks import Generator
+    from models.spatial_transformers.spatial_transformer import get_stn
+    from models.spatial_transformers.antialiased_sampling import BilinearDownsample
+    from models.latent_learner import DirectionInterpolator
+    from models.losses.lpips import LPIPS
+    from models.losses.loss import (gangealing_loss, gangealing_cluster_loss, total_variation_loss,
+                                    flow_identity_loss)
+    return cc.api_namespace(Generator=Generator, get_stn=get_stn, BilinearDownsample=BilinearDownsample,
+                            DirectionInterpolator=DirectionInterpolator, LPIPS=LPIPS, gangealing_loss=gangealing_loss,
+                            gangealing_cluster_loss=gangealing_cluster_loss, total_variation_loss=total_variation_loss,
+                            flow_identity_loss=flow_identity_loss)
+
+
+def gen_config(api, name):
+    t0 = time.time()
+    res = cc.run_config(api, name, 'cpu')
+    case = {}
+    for key in ('unaligned', 'target', 'pred', 'stn_delta', 'delta_flow'):
+        case.update(cc.pack_batch(res[key], key))
+    norms, arrays = cc.pack_grads(res['grads'])
+    case.update(arrays)
+    for key in ('ploss', 'tv', 'identity', 'total'):
+        case[key] = res[key]
+    case['meta'] = dict(config=name, cfg=cc.CONFIGS[name], grad_norms=norms, seconds=round(time.time() - t0, 1),
+                        shapes={k: list(res[k].shape) for k in ('unaligned', 'target', 'pred', 'stn_delta', 'delta_flow')})
+    save(f'cfg_{name}', [case])
+    print(f'  {name}: {time.time() - t0:.0f} s, total loss {float(res["total"]):.6f}')
+
+
+def gen_c2_generator(api, n=16):
+    """Generator(256) forward + the gradient with respect to w through every style path (networks.py:514-586)."""
+    g = api.Generator(256, 512, 8, channel_multiplier=2)
+    torch.nn.Module.load_state_dict(g, det_state_dict(g), strict=False)
+    g.eval().requires_grad_(False)
+    z = rnd('c2gen.z', (n, 512))
+    noise = [rnd(f'c2gen.noise{i}', (n, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2))) for i in range(g.num_layers)]
+    with torch.no_grad():
+        img, latent = g([z], return_latents=True, noise=noise)
+    w = latent[:, 0].detach().clone().requires_grad_(True)
+    img2, _ = g([w.unsqueeze(1).repeat(1, g.n_latent, 1)], input_is_latent=True, noise=noise)
+    gimg = rnd('c2gen.gimg', img2.shape)
+    (gw,) = torch.autograd.grad(img2, w, gimg)
+    case = dict(z=z, w=latent[:, 0], gw=gw, meta=dict(size=256, batch=n, num_layers=g.num_layers))
+    case.update(cc.pack_batch(img, 'img'))
+    case.update(cc.pack_batch(img2, 'img_from_w'))
+    save('c2_generator', [case])
+
+
+def gen_c2_stn(api, n=16):
+    """similarity+flow STN at the benchmark shapes (regression at 128^2, 256^2 input): forward + all gradients."""
+    from models.losses.loss import total_variation_loss, flow_identity_loss
+    cases = []
+    for ci, (full_res, mode) in enumerate([(False, 'reflection'), (True, 'border')]):
+        stn = api.get_stn(['similarity', 'flow'], flow_size=128, supersize=256, channel_multiplier=0.5, num_heads=1)
+        torch.nn.Module.load_state_dict(stn, det_state_dict(stn, cc.STN_RULES), strict=False)
+        x = rnd(f'c2stn.x{ci}', (n, 3, 256, 256), 0.5)
+        small = api.BilinearDownsample(2, 3)(x)
+        # train.py feeds the 128^2 resized fake; with --sample_from_full_res the 256^2 image is the sampling source
+        out, flow = stn(small, return_flow=True, padding_mode=mode, input_img_for_sampling=x if full_res else None)
+        gout = rnd(f'c2stn.g{ci}', out.shape)
+        loss = (out * gout).mean() + 10.0 * total_variation_loss(flow) + flow_identity_loss(flow)
+        params = list(stn.named_parameters())
+        grads = torch.autograd.grad(loss, [p for _, p in params])
+        norms, arrays = cc.pack_grads({n_: g for (n_, _), g in zip(params, grads)})
+        case = dict(loss=loss, meta=dict(batch=n, padding_mode=mode, sample_from_full_res=full_res, grad_norms=norms))
+        case.update(arrays)
+        case.update(cc.pack_batch(out, 'out'))
+        case.update(cc.pack_batch(flow, 'flow'))
+        cases.append(case)
+    save('c2_stn', cases)
+
+
+def gen_lpips(api):
+    """The reference LPIPS class (lpips.py:121-223) in both forms: baseline sum (vgg_ssl) and learned lin layers."""
+    cases = []
+    for lp in (False, True):
+        net = api.LPIPS(net='vgg', lpips=lp, pnet_rand=True, pretrained=False, verbose=False)
+        torch.nn.Module.load_state_dict(net, cc.det_lpips_state_dict(net), strict=False)
+        net.eval()
+        in0 = rnd('lpips.in0', (3, 3, 64, 64), 0.5).requires_grad_(True)
+        in1 = rnd('lpips.in1', (3, 3, 64, 64), 0.5)
+        val, per_layer = net(in0, in1, retPerLayer=True)
+        g = rnd('lpips.g', val.shape)
+        (gin0,) = torch.autograd.grad(val, in0, g)
+        cases.append(dict(in0=in0, in1=in1, val=val, g=g, gin0=gin0,
+                          per_layer=torch.cat([p.reshape(3, 1) for p in per_layer], 1),
+                          meta=dict(lpips=lp, state_dict_keys=sorted(net.state_dict().keys()),
+                                    shapes={k: list(v.shape) for k, v in net.state_dict().items()})))
+    save('lpips', cases)
+
+
+if __name__ == '__main__':
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    api = reference_api()
+    only = sys.argv[1:]
+    jobs = dict(lpips=lambda: gen_lpips(api), c2_generator=lambda: gen_c2_generator(api), c2_stn=lambda: gen_c2_stn(api),
+                c5=lambda: gen_config(api, 'c5'), c4=lambda: gen_config(api, 'c4'), c2=lambda: gen_config(api, 'c2'))
+    for name, fn in jobs.items():
+        if only and name not in only:
+            continue
+        t0 = time.time()
+        with torch.enable_grad():
+            fn()
+        print(f'{name}: done in {time.time() - t0:.0f} s')

@@ -42,3 +42,33 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     return torch.device('cuda:0')
+
+
+# ---- measured-parity report: GPU tests record the errors they observed (not just pass / fail); written at session end
+# ---- to gpurun_out/parity_report.json (copied to profiles/parity_rNN.json for the round's record)
+PARITY = {}
+
+
+def record_parity(test, mode, tensor, got, ref, extra=None):
+    """Store max |got - ref|, the reference scale and the relative figure; returns the max abs error."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    err = float(np.abs(got - ref).max()) if got.size else 0.0
+    scale = float(np.abs(ref).max()) if ref.size else 0.0
+    entry = dict(max_abs_err=err, ref_max_abs=scale, rel_to_max=(err / scale if scale > 0 else 0.0))
+    if extra:
+        entry.update(extra)
+    PARITY.setdefault(test, {}).setdefault(mode, {})[tensor] = entry
+    return err
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not PARITY:
+        return
+    out_dir = os.path.join(REPO, 'gpurun_out')
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, 'parity_report.json'), 'w') as f:
+            json.dump(PARITY, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

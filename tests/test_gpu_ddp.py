@@ -1,0 +1,134 @@
+"""The N>1 trainer path on the hardware a test box has: two ranks share cuda:0 and exchange over gloo (RCCL refuses
+two ranks on one device; the collective call sites are the same ones `backend='nccl'` runs on a multi-GPU node).
+Each rank runs GangealingTrainer with pipeline_update=True - asynchronous all-reduce of the flat gradient arena,
+Adam + EMA + re-pack deferred to the next STN forward - for three iterations and checks
+
+  (i)   the replicas hold bit-identical STN / EMA / latent-learner parameters after every flush();
+  (ii)  the gradient the optimiser consumed is exactly the sum of the two ranks' local gradients (the 1/world factor
+        is folded into the Adam kernel), and the ranks really computed different local gradients;
+  (iii) the run agrees with the same three iterations in the immediate-update order (pipeline_update=False).
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(gen_size=64, flow_size=64, batch=2, transform=('similarity', 'flow'), inject=3, ndirs=2, perturb_heads=0.02,
+          seed=11)
+STEPS = 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(trainer, dist, world, record):
+    """STEPS iterations; after each flush() append CPU copies of what the checks need to `record`."""
+    rank = dist.get_rank()
+    consumed = []
+    apply_update = trainer._apply_stn_update
+
+    def spy_update(scale, lr):
+        consumed.append(trainer.stn_arena.grad.clone())          # what Adam is about to read (after work.wait())
+        return apply_update(scale, lr)
+    trainer._apply_stn_update = spy_update
+    real_all_reduce = dist.all_reduce
+    local = []
+
+    def spy_all_reduce(tensor, *args, **kw):
+        if tensor.data_ptr() == trainer.stn_arena.grad.data_ptr():
+            local.append(tensor.clone())                          # this rank's own gradient, before the exchange
+        return real_all_reduce(tensor, *args, **kw)
+    dist.all_reduce = spy_all_reduce
+    try:
+        for step in range(STEPS):
+            torch.manual_seed(1000 * (rank + 1) + step)           # per-rank data stream
+            parts = trainer.step(psi=0.5)
+            trainer.flush()
+            record.append(dict(param=trainer.stn_arena.param.cpu(), ema=trainer.ema_arena.param.cpu(),
+                               ll=trainer.ll_arena.param.cpu(), consumed=consumed[-1].cpu(),
+                               local=local[-1].cpu() if local else None, loss=float(parts['p'])))
+    finally:
+        dist.all_reduce = real_all_reduce
+        trainer._apply_stn_update = apply_update
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    from gangealing_amd import distributed as gdist
+    from gangealing_amd.train_step import GangealingTrainer
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    assert gdist.setup_distributed('gloo') is True and gdist.get_world_size() == world
+    result = dict(rank=rank)
+    try:
+        piped, immediate = [], []
+        tr = GangealingTrainer(dev, pipeline_update=True, **KW)
+        assert tr.world == world and tr.pipeline_update
+        _run(tr, dist, world, piped)
+        tr2 = GangealingTrainer(dev, pipeline_update=False, **KW)
+        _run(tr2, dist, world, immediate)
+        ok_sync = ok_sum = True
+        distinct = False
+        for rec in piped:
+            for key in ('param', 'ema', 'll'):
+                both = [torch.empty_like(rec[key]) for _ in range(world)]
+                dist.all_gather(both, rec[key])
+                ok_sync = ok_sync and torch.equal(both[0], both[1])
+            locs = [torch.empty_like(rec['local']) for _ in range(world)]
+            dist.all_gather(locs, rec['local'])
+            ok_sum = ok_sum and torch.equal(rec['consumed'], locs[0] + locs[1])
+            distinct = distinct or not torch.equal(locs[0], locs[1])
+        # (iii): same iterations, immediate order.  Split-K atomics make gradients differ in the last bits from run to
+        # run and Adam's first steps are ~lr * sign(g), so two runs of the SAME order differ in a small fraction of
+        # entries by up to 2 lr per step; a missing / doubled / mis-ordered update would move every entry.
+        lr = 1e-3
+        frac = lambda a, b, tol: float(((a - b).abs() > tol).float().mean())
+        agree = []
+        for s, (a, b) in enumerate(zip(piped, immediate)):
+            agree.append((frac(a['param'], b['param'], 2e-4), float((a['param'] - b['param']).abs().max()),
+                          abs(a['loss'] - b['loss']) / max(abs(b['loss']), 1e-12)))
+        moved = frac(piped[-1]['param'], piped[0]['param'], 1e-6)
+        result.update(ok_sync=bool(ok_sync), ok_sum=bool(ok_sum), distinct=bool(distinct), agree=agree, moved=moved,
+                      lr=lr)
+    except Exception as e:          # surface the failure in the parent instead of a queue timeout
+        import traceback
+        result['error'] = ''.join(traceback.format_exception(type(e), e, e.__traceback__))[-3000:]
+    q.put(result)
+    gdist.synchronize()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_pipelined_trainer(cuda):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for res in results:
+        assert 'error' not in res, res['error']
+        assert res['ok_sync'], 'replicas diverged after flush()'
+        assert res['ok_sum'] and res['distinct'], (res['ok_sum'], res['distinct'])
+        for s, (fr, mx, dl) in enumerate(res['agree']):
+            assert fr < 0.05 and mx <= 2.1 * res['lr'] * (s + 1) and dl < 2e-2, (s, fr, mx, dl)
+        assert res['moved'] > 0.9
+    for p in procs:
+        assert p.exitcode == 0

@@ -419,3 +419,90 @@ def test_pipelined_optimizer_update_matches_immediate_update(cuda):
     assert frac(a2, b2, 2e-4) < 0.05 and float((a2 - b2).abs().max()) <= 4.2e-3
     moved = frac(a2, a1, 1e-6)
     assert moved > 0.9 and frac(b2, b1, 1e-6) > 0.9, moved        # the second update was applied in both modes
+
+
+def test_ema_network_forward_follows_the_optimizer(cuda):
+    """The fused Adam/EMA kernel rewrites the arenas through raw pointers.  The EMA STN (the network that is actually
+    evaluated: visualisation, cluster-classifier labels) is frozen, so its conv weight packs and scaled EqualLinear
+    weights are cached per parameter version - a forward after a step must see the NEW weights.  Checked against a
+    freshly built module loaded with the EMA state (no caches)."""
+    from gangealing_amd.train_step import GangealingTrainer
+    from gangealing_amd.spatial_transformers.spatial_transformer import get_stn
+    kw = dict(gen_size=64, flow_size=64, batch=2, transform=('similarity', 'flow'), inject=3, ndirs=2,
+              perturb_heads=0.05, seed=21)
+    tr = GangealingTrainer(cuda, stn_lr=2e-2, **kw)
+    tr.ema_decay = 0.0                                     # EMA = current parameters: a large, visible change per step
+    x = torch.randn(2, 3, 64, 64, device=cuda) * 0.5
+    with torch.no_grad():
+        out0, flow0 = tr.t_ema(x, return_flow=True, padding_mode='reflection')
+    for _ in range(2):
+        tr.step(psi=0.5)
+        tr.flush()
+        with torch.no_grad():
+            out1, flow1 = tr.t_ema(x, return_flow=True, padding_mode='reflection')
+        fresh = get_stn(['similarity', 'flow'], flow_size=64, supersize=64, channel_multiplier=0.5, num_heads=1).to(cuda)
+        fresh.load_state_dict(tr.t_ema.state_dict())
+        fresh.requires_grad_(False)
+        with torch.no_grad():
+            out_ref, flow_ref = fresh(x, return_flow=True, padding_mode='reflection')
+        assert float((flow1 - flow0).abs().max()) > 1e-4           # the update is visible at all
+        torch.testing.assert_close(flow1, flow_ref, atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(out1, out_ref, atol=1e-5, rtol=1e-5)
+        out0, flow0 = out1, flow1
+
+
+def test_grad_slots_only_inside_the_trainers_backward(cuda):
+    """Weight gradients go straight into the arena only inside `with conv_mfma.grad_slots()` (the trainer's own
+    backward).  torch.autograd.grad on the same graph - a diagnostic backward, a second loss - gets ordinary gradients
+    and leaves the arena untouched."""
+    from gangealing_amd.op import conv_mfma
+    from gangealing_amd.train_step import GangealingTrainer
+    tr = GangealingTrainer(cuda, gen_size=64, flow_size=64, batch=2, transform=('similarity', 'flow'), inject=3,
+                           ndirs=2, perturb_heads=0.02, seed=4)
+    weights = [(n, p) for n, p in tr.stn.named_parameters() if p.dim() == 4]
+    assert len(weights) > 10 and all(p.data_ptr() in conv_mfma.GRAD_SLOTS for _, p in weights)
+    assert not any(p.data_ptr() in conv_mfma.GRAD_SLOTS for p in tr.t_ema.parameters())     # frozen: never registered
+    tr.stn_arena.zero_grad()
+    torch.manual_seed(3)
+    total, _ = tr.loss(0.5)
+    grads = torch.autograd.grad(total, [p for _, p in weights], retain_graph=True)
+    assert all(g is not None and float(g.abs().max()) > 0 for g in grads)
+    assert float(tr.stn_arena.grad.abs().max()) == 0.0
+    with conv_mfma.grad_slots():
+        total.backward()
+    for (name, p), g in zip(weights, grads):
+        torch.testing.assert_close(p.grad, g, atol=2e-6 + 2e-3 * float(g.abs().max()), rtol=0, msg=name)
+
+
+def test_trainer_schedule_and_checkpoint_round_trip(cuda):
+    """train_iteration drives psi and the learning rates as train.py:92-97,129-132; state_dict()/load_state_dict()
+    carry weights, Adam moments, step counts and scheduler state in the reference's checkpoint layout."""
+    from gangealing_amd.train_step import GangealingTrainer
+    kw = dict(gen_size=64, flow_size=64, batch=2, transform=('similarity', 'flow'), inject=3, ndirs=2,
+              perturb_heads=0.02, seed=8, anneal_psi=2, period=1.5, tm=2, decay=0.5)
+    a = GangealingTrainer(cuda, **kw)
+    psis, lrs = [], []
+    for i in range(1, 6):
+        lrs.append(a.t_sched.get_last_lr()[0])
+        torch.manual_seed(50 + i)
+        _, psi = a.train_iteration(i)
+        psis.append(psi)
+    assert psis[0] == pytest.approx(0.5) and psis[1] == pytest.approx(0.0, abs=1e-7) and psis[2:] == [0.0, 0.0, 0.0]
+    assert lrs[:3] == [1e-3, 1e-3, 1e-3] and lrs[3] < 1e-3 and a.t_sched.get_last_lr()[0] != lrs[3]
+    ckpt = a.state_dict()
+    assert set(ckpt) == {'g_ema', 't', 't_ema', 't_optim', 't_sched', 'll', 'll_optim', 'll_sched'}
+    assert len(ckpt['t_optim']['state']) == len(list(a.stn.parameters()))
+    b = GangealingTrainer(cuda, **dict(kw, seed=99))                 # different initial weights
+    assert b.load_state_dict(ckpt) is True
+    for x, y in ((a.stn_arena, b.stn_arena), (a.ema_arena, b.ema_arena), (a.ll_arena, b.ll_arena)):
+        assert torch.equal(x.param, y.param) and torch.equal(x.exp_avg, y.exp_avg) and \
+            torch.equal(x.exp_avg_sq, y.exp_avg_sq) and x.step_count == y.step_count
+    assert b.t_sched.get_last_lr() == a.t_sched.get_last_lr()
+    # both continue identically (same data seed): losses agree and the parameters stay together
+    torch.manual_seed(500)
+    pa, _ = a.train_iteration(6)
+    torch.manual_seed(500)
+    pb, _ = b.train_iteration(6)
+    assert abs(float(pa['p']) - float(pb['p'])) <= 1e-4 * abs(float(pa['p']))
+    a.flush(), b.flush()
+    assert float(((a.stn_arena.param - b.stn_arena.param).abs() > 1e-5).float().mean()) < 0.03

@@ -119,3 +119,130 @@ def test_launcher_injects_ops_into_reference_imports():
         "print('ok')\n" % REPO)
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2: schedules, optimiser / checkpoint state, perceptual-loss layout, strict loading
+
+def test_annealing_and_lr_schedule_match_reference_golden():
+    """psi annealing, lr_cycle_iters and DecayingCosineAnnealingWarmRestarts driven as train.py:92-97,129-132 drives
+    them, against sequences produced by the reference classes (oracle/make_golden.py::gen_annealing)."""
+    from conftest import load_golden
+    from gangealing_amd.annealing import (DecayingCosineAnnealingWarmRestarts, get_psi_annealing_fn, lr_cycle_iters)
+    for c in load_golden('annealing'):
+        m = c['meta']
+        sched = DecayingCosineAnnealingWarmRestarts(m['base_lr'], T_0=1, T_mult=m['tm'], decay=m['decay'])
+        cos, lin = get_psi_annealing_fn('cosine'), get_psi_annealing_fn('linear')
+        lrs, pc, pl = [], [], []
+        for i in range(1, m['iters'] + 1):
+            lrs.append(sched.get_last_lr()[0])
+            if i <= m['anneal_psi']:
+                pc.append(cos(i, 1.0, 0.0, m['anneal_psi']))
+                pl.append(lin(i, 1.0, 0.0, m['anneal_psi']))
+            else:
+                sched.step(max(0, (i - m['anneal_psi']) / m['period']))
+        np.testing.assert_allclose(lrs, c['lrs'], rtol=1e-12, atol=1e-18)
+        np.testing.assert_allclose(pc, c['psi_cosine'], atol=1e-6)          # the reference evaluates cos in float32
+        np.testing.assert_allclose(pl, c['psi_linear'], atol=1e-6)
+        assert sched.T_i == m['sched_state']
+        if m['tm'] > 1:
+            assert lr_cycle_iters(m['anneal_psi'], m['period'], m['iters'], m['tm']) == list(c['zero_lr_iters'])
+        # state round trip (t_sched / ll_sched entries of a checkpoint, train.py:22-28)
+        other = DecayingCosineAnnealingWarmRestarts(m['base_lr'], T_0=1, T_mult=m['tm'], decay=m['decay'])
+        other.load_state_dict(sched.state_dict())
+        assert other.get_last_lr() == sched.get_last_lr() and other.T_cur == sched.T_cur
+
+
+def test_flat_arena_optimizer_state_round_trips_with_torch_adam():
+    """t_optim / ll_optim of a reference checkpoint are torch.optim.Adam state_dicts: they load into the arena's
+    moment buffers, and what the arena exports loads back into torch.optim.Adam."""
+    from gangealing_amd.train_step import FlatArena
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    opt = torch.optim.Adam(net.parameters(), lr=3e-3, betas=(0.9, 0.999), eps=1e-8)
+    for _ in range(3):
+        opt.zero_grad()
+        net(torch.randn(4, 5)).pow(2).sum().backward()
+        opt.step()
+    sd = opt.state_dict()
+    twin = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    twin.load_state_dict(net.state_dict())
+    arena = FlatArena(twin)
+    assert arena.load_optim_state_dict(sd) == 3e-3 and arena.step_count == 3
+    off = 0
+    for i, p in enumerate(net.parameters()):
+        n = p.numel()
+        torch.testing.assert_close(arena.exp_avg[off:off + n].view(p.shape), sd['state'][i]['exp_avg'])
+        torch.testing.assert_close(arena.exp_avg_sq[off:off + n].view(p.shape), sd['state'][i]['exp_avg_sq'])
+        off += n
+    back = arena.optim_state_dict(3e-3)
+    opt2 = torch.optim.Adam(twin.parameters(), lr=1.0)
+    opt2.load_state_dict(back)
+    assert opt2.param_groups[0]['lr'] == 3e-3
+    for i in range(4):
+        torch.testing.assert_close(opt2.state_dict()['state'][i]['exp_avg'], sd['state'][i]['exp_avg'])
+        assert float(opt2.state_dict()['state'][i]['step']) == 3.0
+    bad = {'state': {}, 'param_groups': [{'lr': 1.0, 'params': [0, 1]}]}
+    with pytest.raises(ValueError):
+        arena.load_optim_state_dict(bad)
+
+
+def test_arena_touch_bumps_parameter_versions():
+    """The fused optimiser writes through raw pointers; caches (weight packs, scaled EqualLinear weights) are keyed
+    on the PARAMETERS' version counters, which `p.data = view` decoupled from the arena tensor's."""
+    from gangealing_amd.train_step import FlatArena
+    net = torch.nn.Linear(3, 2)
+    arena = FlatArena(net)
+    before = [p._version for p in net.parameters()]
+    arena.touch()
+    assert all(p._version > b for p, b in zip(net.parameters(), before))
+
+
+def test_stn_strict_loading_rejects_wrong_checkpoints():
+    from gangealing_amd.spatial_transformers.spatial_transformer import get_stn
+    kw = dict(flow_size=64, supersize=128, channel_multiplier=0.5, num_heads=1)
+    stn = get_stn(['similarity', 'flow'], **kw)
+    sd = stn.state_dict()
+    sd['stns.0.input_downsample.kernel_horz'] = torch.zeros(1)        # derived buffers are dropped, as the reference does
+    stn.load_state_dict(sd)
+    missing = {k: v for k, v in sd.items() if k != 'stns.1.final_conv.0.weight'}
+    with pytest.raises(RuntimeError):
+        stn.load_state_dict(missing)
+    stn.load_state_dict(missing, strict=False)                        # the reference's (always non-strict) behaviour
+    extra = dict(sd)
+    extra['stns.1.not_a_key'] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        stn.load_state_dict(extra)
+
+
+def test_lpips_module_layout_matches_reference_and_loads_torchvision_features():
+    """State-dict keys and shapes equal those of the reference LPIPS class (tests/golden/lpips.npz records them from
+    the reference); a torchvision-layout `features` state_dict (simclr_vgg_phase150.pt format) loads strictly."""
+    from conftest import load_golden
+    from gangealing_amd.losses import LPIPS, vgg16, get_perceptual_loss
+    for case in load_golden('lpips'):
+        m = case['meta']
+        net = LPIPS(net='vgg', lpips=m['lpips'], pnet_rand=True, pretrained=False)
+        sd = net.state_dict()
+        assert sorted(sd) == m['state_dict_keys']
+        assert {k: list(v.shape) for k, v in sd.items()} == m['shapes']
+    trunk = vgg16(pretrained=False)
+    assert not trunk.weights_loaded
+    feats = {}
+    for name, p in trunk.state_dict().items():                        # slice3.12.weight -> 12.weight
+        feats[name.split('.', 1)[1]] = torch.full_like(p, 0.5)
+    trunk.load_features_state_dict(feats)
+    assert trunk.weights_loaded
+    assert all(float(p.min()) == 0.5 for p in trunk.parameters())
+    with pytest.raises(RuntimeError):
+        trunk.load_features_state_dict({k: v for k, v in feats.items() if k != '28.bias'})
+    with pytest.raises(RuntimeError):
+        trunk.load_features_state_dict(dict(feats, **{'30.weight': torch.zeros(1)}))
+    with pytest.raises(FileNotFoundError):
+        vgg16(pretrained=True)
+    with pytest.raises(FileNotFoundError):                            # 'lpips' never silently becomes another loss
+        get_perceptual_loss('lpips', 'cpu', weights='/nonexistent/lpips_vgg.pt')
+    with pytest.warns(UserWarning):
+        get_perceptual_loss('vgg_ssl', 'cpu', weights='/nonexistent/simclr.pt')
+    with pytest.raises(FileNotFoundError):
+        get_perceptual_loss('vgg_ssl', 'cpu', weights='/nonexistent/simclr.pt', allow_random=False)
