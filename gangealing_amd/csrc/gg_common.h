@@ -61,6 +61,26 @@ __device__ __forceinline__ T block_sum_256(T v, T* smem) {
   return r;
 }
 
+// Raw buffer access: address = resource base + voffset (per lane) + soffset (scalar).  A voffset at or beyond the
+// resource's num_records makes a load return 0 and a store vanish - kOobOffset selects that for masked lanes
+// (resources are < 2 GiB), which keeps bounds handling out of the control flow.  The descriptor words go through
+// readfirstlane so that the compiler can prove they are wave-uniform (otherwise every access is wrapped in a
+// waterfall loop).
+constexpr unsigned kOobOffset = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, int bytes) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                           __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ float buffer_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voffset, int soffset) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voffset, soffset, 0));
+}
+__device__ __forceinline__ void buffer_store_f32(float v, __amdgpu_buffer_rsrc_t r, unsigned voffset, int soffset) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voffset, soffset, 0);
+}
+
 // Exactly-rounded fp32 ops that the compiler may not contract into FMAs: the sampling-index math
 // must reproduce the IEEE sequence of the reference formulas bit for bit.
 __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }

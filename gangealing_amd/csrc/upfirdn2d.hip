@@ -16,6 +16,7 @@
 //     kernels, tiny planes): one output per thread, taps staged in LDS.
 #include "../../include/gangealing_hip.h"
 #include "gg_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -159,6 +160,161 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_tile(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming blur (up = down = 1, 4x4 taps), the default for the hot case.  No LDS, no barrier, no integer division:
+//   * one WAVE owns a strip of 61 output columns x SROWS output rows of one plane.  Lane l holds input column
+//     x0 + l (64 columns = 61 outputs + the 3-column halo); a row is one coalesced 256-byte wave load.
+//   * the horizontal 4-tap pass happens in registers when a row arrives: the three neighbours to the right come from
+//     `v_mov_b32_dpp ... wave_shl:1` (whole-wave shift, lane i <- lane i+1, zero shifted into lane 63), applied
+//     1x / 2x / 3x.  The vertical pass is a 4-deep register window sliding down the strip, so every input word is
+//     loaded exactly once per strip and every output row leaves as one 244-byte coalesced store.
+//   * rows are fetched eight at a time (eight independent loads in flight per wave) before they are consumed.
+// Separable taps (every Blur of the networks: make_kernel is an outer product, networks.py:34-41) cost 3 DPP moves +
+// 8 FMAs per output; general taps keep the three shifted copies of each window row (16 FMAs per output).
+// Read amplification: 64/61 columns x (SROWS+3)/SROWS rows = 1.15, served by L2.
+constexpr int SW_OUT = 61;      // outputs per wave row
+constexpr int SROWS = 32;       // output rows per wave
+
+__device__ __forceinline__ float wave_shl1(float v) {     // lane i <- lane i+1; lane 63 <- 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+template <bool EPI, bool PRO>
+__global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
+    float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ kernel,
+    int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0,
+    int strips_x, int chunks_y, unsigned nunits, const BlurFuse f) {
+  const int lane = threadIdx.x & 63;
+  // the wave index goes through readfirstlane: everything derived from it (plane, rows, buffer descriptors, scalar
+  // offsets) is then provably wave-uniform and lives in SGPRs
+  const unsigned unit = blockIdx.x * 4u + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (unit >= nunits) return;                               // whole wave leaves (no barriers in this kernel)
+  const int sx = (int)(unit % (unsigned)strips_x);
+  const unsigned q = unit / (unsigned)strips_x;
+  const int cy = (int)(q % (unsigned)chunks_y);
+  const unsigned plane = q / (unsigned)chunks_y;
+  float kf[16];                                             // flipped taps (wave-uniform scalar loads)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) kf[i] = kernel[15 - i];
+  bool sep = kf[0] != 0.f;
+  float ka[4], kb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) kb[c] = kf[c];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ka[r] = kf[r * 4] / kf[0];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sep = sep & (fabsf(ka[r] * kb[c] - kf[r * 4 + c]) <= 1e-6f * fabsf(kf[r * 4 + c]));
+
+  const int ox = sx * SW_OUT + lane;
+  const int ix = ox - pad_x0;                               // input column held by this lane
+  const int oy0 = cy * SROWS;
+  const int iy0 = oy0 - pad_y0;                             // input row of tap 0 for output row oy0
+  // bounds live in the buffer offsets (out-of-range -> load 0 / store dropped), not in branches: the eight row loads
+  // of a batch issue back to back
+  const unsigned in_off = (ix >= 0 && ix < in_w) ? (unsigned)ix * 4u : gg::kOobOffset;
+  const unsigned out_off = (lane < SW_OUT && ox < out_w) ? (unsigned)ox * 4u : gg::kOobOffset;
+  const int in_bytes = in_h * in_w * 4, out_bytes = out_h * out_w * 4;
+  const __amdgpu_buffer_rsrc_t src = gg::uniform_rsrc(in + (size_t)plane * in_h * in_w, in_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc = gg::uniform_rsrc(PRO ? f.ref + (size_t)plane * in_h * in_w : in, in_bytes);
+  const __amdgpu_buffer_rsrc_t dst = gg::uniform_rsrc(out + (size_t)plane * out_h * out_w, out_bytes);
+  float nw = 0.f, ab = 0.f;
+  const int n_img = EPI ? (int)(plane / f.channels) : 0;
+  const __amdgpu_buffer_rsrc_t nz = gg::uniform_rsrc(EPI ? f.noise + (size_t)n_img * out_h * out_w : in, out_bytes);
+  if (EPI) {
+    nw = f.noise_w[0];
+    ab = f.bias[plane - (unsigned)n_img * (unsigned)f.channels];
+  }
+  auto fetch = [&](int iy) -> float {
+    const bool row_ok = iy >= 0 && iy < in_h;               // wave-uniform
+    const unsigned vo = row_ok ? in_off : gg::kOobOffset;
+    const int so = row_ok ? iy * in_w * 4 : 0;
+    float v = gg::buffer_load_f32(src, vo, so);
+    if (PRO) v *= (gg::buffer_load_f32(rsrc, vo, so) > 0.f) ? f.gain : f.gain * f.alpha;
+    return v;
+  };
+  auto finish = [&](float acc, int oy) {
+    const bool row_ok = oy < out_h;
+    const unsigned vo = row_ok ? out_off : gg::kOobOffset;
+    const int so = row_ok ? oy * out_w * 4 : 0;
+    if (EPI) {
+      const float t = acc + nw * gg::buffer_load_f32(nz, vo, so) + ab;
+      acc = (t > 0.f ? t : t * f.alpha) * f.gain;
+    }
+    gg::buffer_store_f32(acc, dst, vo, so);
+  };
+  if (sep) {
+    auto hpass = [&](float v) -> float {
+      const float s1 = wave_shl1(v), s2 = wave_shl1(s1), s3 = wave_shl1(s2);
+      return v * kb[0] + s1 * kb[1] + s2 * kb[2] + s3 * kb[3];
+    };
+    float h0 = hpass(fetch(iy0)), h1 = hpass(fetch(iy0 + 1)), h2 = hpass(fetch(iy0 + 2));
+    for (int rr = 0; rr < SROWS; rr += 8) {
+      if (oy0 + rr >= out_h) break;
+      float nv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nv[u] = fetch(iy0 + 3 + rr + u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float h3 = hpass(nv[u]);
+        finish(h0 * ka[0] + h1 * ka[1] + h2 * ka[2] + h3 * ka[3], oy0 + rr + u);
+        h0 = h1; h1 = h2; h2 = h3;
+      }
+    }
+    return;
+  }
+  // general taps: window[row][shift]
+  float w[4][4];
+  auto shifts = [&](float v, float s[4]) {
+    s[0] = v; s[1] = wave_shl1(v); s[2] = wave_shl1(s[1]); s[3] = wave_shl1(s[2]);
+  };
+  shifts(fetch(iy0), w[0]);
+  shifts(fetch(iy0 + 1), w[1]);
+  shifts(fetch(iy0 + 2), w[2]);
+  for (int rr = 0; rr < SROWS; ++rr) {
+    if (oy0 + rr >= out_h) break;
+    shifts(fetch(iy0 + 3 + rr), w[3]);
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc += w[r][c] * kf[r * 4 + c];
+    finish(acc, oy0 + rr);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) w[r][c] = w[r + 1][c];
+  }
+}
+
+// A/B switch for measurements: GG_BLUR_TILE=1 selects the round-1 LDS tile kernel.
+inline bool blur_use_tile_kernel() {
+  static const bool v = [] { const char* e = getenv("GG_BLUR_TILE"); return e && e[0] == '1'; }();
+  return v;
+}
+
+template <bool EPI, bool PRO>
+int launch_blur4(float* out, const float* in, const float* kernel, long long planes, int in_h, int in_w, int out_h,
+                 int out_w, int pad_x0, int pad_y0, const BlurFuse& f, hipStream_t st) {
+  if (blur_use_tile_kernel()) {
+    const int tiles_x = (out_w + TILE - 1) / TILE, tiles_y = (out_h + TILE - 1) / TILE;
+    const long long ntiles = (long long)tiles_x * tiles_y * planes;
+    if (ntiles >= (1LL << 31)) return gg::fail(-2, "blur4: too many tiles");
+    upfirdn2d_blur4_tile<EPI, PRO><<<(unsigned)ntiles, 256, 0, st>>>(out, in, kernel, (int)planes, in_h, in_w, out_h,
+                                                                    out_w, pad_x0, pad_y0, tiles_x, tiles_y,
+                                                                    (unsigned)ntiles, f);
+    return gg::launch_status("upfirdn2d_blur4_tile");
+  }
+  const int strips_x = (out_w + SW_OUT - 1) / SW_OUT, chunks_y = (out_h + SROWS - 1) / SROWS;
+  const long long nunits = (long long)strips_x * chunks_y * planes;
+  if (nunits >= (1LL << 31)) return gg::fail(-2, "blur4: too many strips");
+  const long long blocks = (nunits + 3) / 4;
+  upfirdn2d_blur4_stream<EPI, PRO><<<(unsigned)blocks, 256, 0, st>>>(out, in, kernel, in_h, in_w, out_h, out_w, pad_x0,
+                                                                     pad_y0, strips_x, chunks_y, (unsigned)nunits, f);
+  return gg::launch_status("upfirdn2d_blur4_stream");
+}
+
 constexpr int MAX_LDS_TAPS = 1024;
 
 template <typename T>
@@ -213,16 +369,10 @@ int upfirdn2d_impl(T* out, const T* in, const T* kernel, int major, int in_h, in
   const long long total = (long long)major * out_h * out_w;
   const bool blur4 = sizeof(T) == 4 && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4 &&
                      out_h >= 24 && out_w >= 24;
-  if (blur4) {
-    const int tiles_x = (out_w + TILE - 1) / TILE, tiles_y = (out_h + TILE - 1) / TILE;
-    const long long ntiles = (long long)tiles_x * tiles_y * major;
-    if (ntiles < (1LL << 31)) {
-      upfirdn2d_blur4_tile<false, false><<<(unsigned)ntiles, 256, 0, st>>>(
-          reinterpret_cast<float*>(out), reinterpret_cast<const float*>(in), reinterpret_cast<const float*>(kernel),
-          major, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, (unsigned)ntiles, BlurFuse{});
-      return gg::launch_status("upfirdn2d_blur4_tile");
-    }
-  }
+  if (blur4)
+    return launch_blur4<false, false>(reinterpret_cast<float*>(out), reinterpret_cast<const float*>(in),
+                                      reinterpret_cast<const float*>(kernel), major, in_h, in_w, out_h, out_w, pad_x0,
+                                      pad_y0, BlurFuse{}, st);
   upfirdn2d_direct<T><<<gg::stream_grid(total, 256), 256, 0, st>>>(out, in, kernel, total, in_h, in_w, out_h, out_w,
                                                                   kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0);
   return gg::launch_status("upfirdn2d_direct");
@@ -246,26 +396,14 @@ extern "C" int gg_blur4_fused_f32(float* out, const float* in, const float* kern
   const bool epi = noise != nullptr, pro = ref != nullptr;
   if (epi && (!noise_weight || !act_bias)) return gg::fail(-2, "blur4_fused: noise weight / bias missing");
   if (epi && pro) return gg::fail(-2, "blur4_fused: epilogue and prologue are exclusive");
-  const int tiles_x = (out_w + TILE - 1) / TILE, tiles_y = (out_h + TILE - 1) / TILE;
-  const long long ntiles = (long long)tiles_x * tiles_y * n * c;
-  if (ntiles >= (1LL << 31)) return gg::fail(-2, "blur4_fused: too many tiles");
   BlurFuse f;
   f.noise = noise; f.noise_w = noise_weight; f.bias = act_bias; f.ref = ref; f.alpha = alpha; f.gain = gain;
   f.channels = c;
   hipStream_t st = gg::as_stream(stream);
-  if (epi)
-    upfirdn2d_blur4_tile<true, false><<<(unsigned)ntiles, 256, 0, st>>>(out, in, kernel, n * c, in_h, in_w, out_h,
-                                                                         out_w, pad_x0, pad_y0, tiles_x, tiles_y,
-                                                                         (unsigned)ntiles, f);
-  else if (pro)
-    upfirdn2d_blur4_tile<false, true><<<(unsigned)ntiles, 256, 0, st>>>(out, in, kernel, n * c, in_h, in_w, out_h,
-                                                                         out_w, pad_x0, pad_y0, tiles_x, tiles_y,
-                                                                         (unsigned)ntiles, f);
-  else
-    upfirdn2d_blur4_tile<false, false><<<(unsigned)ntiles, 256, 0, st>>>(out, in, kernel, n * c, in_h, in_w, out_h,
-                                                                          out_w, pad_x0, pad_y0, tiles_x, tiles_y,
-                                                                          (unsigned)ntiles, f);
-  return gg::launch_status("blur4_fused");
+  const long long planes = (long long)n * c;
+  if (epi) return launch_blur4<true, false>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+  if (pro) return launch_blur4<false, true>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+  return launch_blur4<false, false>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
 }
 extern "C" int gg_upfirdn2d_f64(double* out, const double* in, const double* kernel, int major, int in_h, int in_w,
                                 int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0,

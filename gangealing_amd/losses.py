@@ -275,9 +275,11 @@ class LPIPS(nn.Module):
             d = (f[:n] - f[n:]) ** 2
             d = d.sum(dim=1, keepdim=True) if lin is None else F.conv2d(d, lin)
             res.append(d.mean(dim=(2, 3), keepdim=True))
+        # the reference accumulates IN PLACE into res[0] (lpips.py:203-205: `val = res[0]; val += res[l]`), so with
+        # retPerLayer the first "per-layer" entry it hands back is the total - reproduced as is
         val = res[0]
         for r in res[1:]:
-            val = val + r
+            val += r
         return (val, res) if retPerLayer else val
 
 

@@ -40,8 +40,9 @@ CONFIGS = {
 }
 
 
-def T(a, device):
-    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+def T(a, device, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return t if dtype is None else t.to(dtype)
 
 
 def det_lpips_state_dict(module):
@@ -65,15 +66,15 @@ class NoiseFeeder:
     """Generator front that replaces `noise=None` by explicit, name-keyed noise images: call k of the step gets the
     list noises[k] (loss.py:21-29 calls the generator twice per step with fresh noise each time)."""
 
-    def __init__(self, generator, tag, device):
-        self.generator, self.tag, self.device = generator, tag, device
+    def __init__(self, generator, tag, device, dtype=None):
+        self.generator, self.tag, self.device, self.dtype = generator, tag, device, dtype
         self.n_latent = generator.n_latent
         self.calls = 0
         self.outputs = []
 
     def noise_for(self, call, batch):
         res = lambda i: 2 ** ((i + 5) // 2)
-        return [T(det_array(f'{self.tag}.noise{call}.{i}', (batch, 1, res(i), res(i))), self.device)
+        return [T(det_array(f'{self.tag}.noise{call}.{i}', (batch, 1, res(i), res(i))), self.device, self.dtype)
                 for i in range(self.generator.num_layers)]
 
     def __call__(self, styles, noise=None, **kw):
@@ -98,14 +99,14 @@ class Tap:
 
 
 @contextlib.contextmanager
-def det_randn(tag, batch, dim_latent):
+def det_randn(tag, batch, dim_latent, dtype=None):
     """torch.randn(batch, dim_latent, ...) -> the name-keyed z of this configuration (loss.py:24)."""
     real = torch.randn
 
     def fake(*size, **kw):
         shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
         if shape == (batch, dim_latent):
-            return T(det_array(f'{tag}.z', shape), kw.get('device', 'cpu'))
+            return T(det_array(f'{tag}.z', shape), kw.get('device', 'cpu'), dtype)
         return real(*size, **kw)
     torch.randn = fake
     try:
@@ -114,8 +115,10 @@ def det_randn(tag, batch, dim_latent):
         torch.randn = real
 
 
-def build_models(api, cfg, tag, device):
-    """Generator (frozen), STN, latent learner, perceptual loss and the fake->STN resize, with name-keyed weights."""
+def build_models(api, cfg, tag, device, dtype=None):
+    """Generator (frozen), STN, latent learner, perceptual loss and the fake->STN resize, with name-keyed weights.
+    dtype=torch.float64 (reference on CPU only) gives the double-precision evaluation the gradient checks use as
+    ground truth."""
     gen = api.Generator(cfg['gen_size'], 512, 8, channel_multiplier=2)
     torch.nn.Module.load_state_dict(gen, det_state_dict(gen), strict=False)
     gen = gen.to(device).eval().requires_grad_(False)
@@ -140,20 +143,25 @@ def build_models(api, cfg, tag, device):
         loss_fn = lambda x, y: net(x, y) / 18.0                 # lpips.py:17
     factor = cfg['gen_size'] // cfg['flow_size']
     resize = api.BilinearDownsample(factor, 3).to(device) if factor > 1 else torch.nn.Sequential()
+    if dtype is not None:
+        gen, stn, ll, net, resize = (m.to(dtype) for m in (gen, stn, ll, net, resize))
+        for m in stn.modules():                    # the reference keeps identity_flow as a plain tensor attribute
+            if isinstance(m.__dict__.get('identity_flow'), torch.Tensor):
+                m.identity_flow = m.identity_flow.to(dtype)
     return gen, stn, ll, loss_fn, resize
 
 
-def run_config(api, name, device, backward=True):
+def run_config(api, name, device, backward=True, dtype=None):
     """One loss evaluation + backward of configuration `name` (train.py:106-124).  -> dict of tensors / floats:
     unaligned, target, pred, delta_flow (the regularised one), ploss, tv, identity, total, grads {param name: grad}."""
     cfg = CONFIGS[name]
     tag = f'cfg.{name}'
-    gen, stn, ll, loss_fn, resize = build_models(api, cfg, tag, device)
-    feeder = NoiseFeeder(gen, tag, device)
+    gen, stn, ll, loss_fn, resize = build_models(api, cfg, tag, device, dtype)
+    feeder = NoiseFeeder(gen, tag, device, dtype)
     stn_tap = Tap(stn)
     resize_tap = Tap(resize)
     clustering = cfg['num_heads'] > 1 or cfg['flips']
-    with det_randn(tag, cfg['batch'], 512):
+    with det_randn(tag, cfg['batch'], 512, dtype):
         common = dict(sample_from_full_res=cfg['sample_from_full_res'], padding_mode=cfg['padding_mode'])
         if clustering:
             ploss, delta = api.gangealing_cluster_loss(feeder, stn_tap, ll, loss_fn, resize_tap, cfg['psi'], cfg['batch'],
@@ -189,7 +197,7 @@ def pack_batch(t, prefix):
             f'{prefix}_sum': flat.double().sum(1).numpy(), f'{prefix}_abssum': flat.double().abs().sum(1).numpy()}
 
 
-def pack_grads(grads):
+def pack_grads(grads, prefix='grad_'):
     """{name: grad} -> ({name: norm}, {key: array}) with small gradients in full and a strided sample of large ones."""
     norms, arrays = {}, {}
     for name, g in grads.items():
@@ -197,8 +205,16 @@ def pack_grads(grads):
         norms[name] = float(g.double().norm())
         flat = g.reshape(-1)
         stride = max(1, flat.numel() // 2048)
-        arrays['grad_' + name.replace('.', '_')] = flat[::stride].numpy().copy()
+        arrays[prefix + name.replace('.', '_')] = flat[::stride].numpy().copy()
     return norms, arrays
+
+
+def smooth_images(tag, n, size, device='cpu'):
+    """(n, 3, size, size) image-like test input: a 32x32 name-keyed random field bilinearly enlarged (smooth structure
+    at the scale of generator images) plus 5 % white noise (so that no two neighbouring pixels are equal)."""
+    low = torch.from_numpy(det_array(tag + '.low', (n, 3, 32, 32), 0.6))
+    x = torch.nn.functional.interpolate(low, size=(size, size), mode='bilinear', align_corners=False)
+    return (x + torch.from_numpy(det_array(tag + '.fine', (n, 3, size, size), 0.05))).to(device)
 
 
 def api_namespace(**kw):

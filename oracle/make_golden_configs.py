@@ -66,7 +66,14 @@ def gen_config(api, name):
     case.update(arrays)
     for key in ('ploss', 'tv', 'identity', 'total'):
         case[key] = res[key]
-    case['meta'] = dict(config=name, cfg=cc.CONFIGS[name], grad_norms=norms, seconds=round(time.time() - t0, 1),
+    # the same step in float64: ground truth for the gradient checks (how far is the reference's own float32
+    # evaluation from it?  the HIP path is held to a multiple of that distance)
+    res64 = cc.run_config(api, name, 'cpu', dtype=torch.float64)
+    norms64, arrays64 = cc.pack_grads(res64['grads'], 'grad64_')
+    case.update(arrays64)
+    case['total64'] = res64['total']
+    case['meta'] = dict(config=name, cfg=cc.CONFIGS[name], grad_norms=norms, grad_norms64=norms64,
+                        seconds=round(time.time() - t0, 1),
                         shapes={k: list(res[k].shape) for k in ('unaligned', 'target', 'pred', 'stn_delta', 'delta_flow')})
     save(f'cfg_{name}', [case])
     print(f'  {name}: {time.time() - t0:.0f} s, total loss {float(res["total"]):.6f}')
@@ -85,7 +92,11 @@ def gen_c2_generator(api, n=16):
     img2, _ = g([w.unsqueeze(1).repeat(1, g.n_latent, 1)], input_is_latent=True, noise=noise)
     gimg = rnd('c2gen.gimg', img2.shape)
     (gw,) = torch.autograd.grad(img2, w, gimg)
-    case = dict(z=z, w=latent[:, 0], gw=gw, meta=dict(size=256, batch=n, num_layers=g.num_layers))
+    g64 = g.double()
+    w64 = latent[:, 0].detach().double().clone().requires_grad_(True)
+    img64, _ = g64([w64.unsqueeze(1).repeat(1, g.n_latent, 1)], input_is_latent=True, noise=[t.double() for t in noise])
+    (gw64,) = torch.autograd.grad(img64, w64, gimg.double())
+    case = dict(z=z, w=latent[:, 0], gw=gw, gw64=gw64, meta=dict(size=256, batch=n, num_layers=g.num_layers))
     case.update(cc.pack_batch(img, 'img'))
     case.update(cc.pack_batch(img2, 'img_from_w'))
     save('c2_generator', [case])
@@ -96,21 +107,34 @@ def gen_c2_stn(api, n=16):
     from models.losses.loss import total_variation_loss, flow_identity_loss
     cases = []
     for ci, (full_res, mode) in enumerate([(False, 'reflection'), (True, 'border')]):
-        stn = api.get_stn(['similarity', 'flow'], flow_size=128, supersize=256, channel_multiplier=0.5, num_heads=1)
-        torch.nn.Module.load_state_dict(stn, det_state_dict(stn, cc.STN_RULES), strict=False)
-        x = rnd(f'c2stn.x{ci}', (n, 3, 256, 256), 0.5)
-        small = api.BilinearDownsample(2, 3)(x)
-        # train.py feeds the 128^2 resized fake; with --sample_from_full_res the 256^2 image is the sampling source
-        out, flow = stn(small, return_flow=True, padding_mode=mode, input_img_for_sampling=x if full_res else None)
-        gout = rnd(f'c2stn.g{ci}', out.shape)
-        loss = (out * gout).mean() + 10.0 * total_variation_loss(flow) + flow_identity_loss(flow)
-        params = list(stn.named_parameters())
-        grads = torch.autograd.grad(loss, [p for _, p in params])
-        norms, arrays = cc.pack_grads({n_: g for (n_, _), g in zip(params, grads)})
-        case = dict(loss=loss, meta=dict(batch=n, padding_mode=mode, sample_from_full_res=full_res, grad_norms=norms))
-        case.update(arrays)
-        case.update(cc.pack_batch(out, 'out'))
-        case.update(cc.pack_batch(flow, 'flow'))
+        case = {}
+        meta = dict(batch=n, padding_mode=mode, sample_from_full_res=full_res)
+        for dt, prefix in ((torch.float32, 'grad_'), (torch.float64, 'grad64_')):
+            stn = api.get_stn(['similarity', 'flow'], flow_size=128, supersize=256, channel_multiplier=0.5, num_heads=1)
+            torch.nn.Module.load_state_dict(stn, det_state_dict(stn, cc.STN_RULES), strict=False)
+            stn = stn.to(dt)
+            for m in stn.modules():
+                if isinstance(m.__dict__.get('identity_flow'), torch.Tensor):
+                    m.identity_flow = m.identity_flow.to(dt)
+            x = cc.smooth_images(f'c2stn.x{ci}', n, 256).to(dt)
+            small = api.BilinearDownsample(2, 3).to(dt)(x)
+            # train.py feeds the 128^2 resized fake; with --sample_from_full_res the 256^2 image is the sampling source
+            out, flow = stn(small, return_flow=True, padding_mode=mode, input_img_for_sampling=x if full_res else None)
+            gout = rnd(f'c2stn.g{ci}', out.shape).to(dt)
+            loss = (out * gout).mean() + 10.0 * total_variation_loss(flow) + flow_identity_loss(flow)
+            params = list(stn.named_parameters())
+            grads = torch.autograd.grad(loss, [p for _, p in params])
+            norms, arrays = cc.pack_grads({n_: g for (n_, _), g in zip(params, grads)}, prefix)
+            case.update(arrays)
+            if dt == torch.float32:
+                meta['grad_norms'] = norms
+                case['loss'] = loss
+                case.update(cc.pack_batch(out, 'out'))
+                case.update(cc.pack_batch(flow, 'flow'))
+            else:
+                meta['grad_norms64'] = norms
+                case['loss64'] = loss
+        case['meta'] = meta
         cases.append(case)
     save('c2_stn', cases)
 
@@ -127,7 +151,12 @@ def gen_lpips(api):
         val, per_layer = net(in0, in1, retPerLayer=True)
         g = rnd('lpips.g', val.shape)
         (gin0,) = torch.autograd.grad(val, in0, g)
-        cases.append(dict(in0=in0, in1=in1, val=val, g=g, gin0=gin0,
+        net64 = net.double()
+        in0_64 = in0.detach().double().requires_grad_(True)
+        val64 = net64(in0_64, in1.double())
+        (gin0_64,) = torch.autograd.grad(val64, in0_64, g.double())
+        net.float()
+        cases.append(dict(in0=in0, in1=in1, val=val, g=g, gin0=gin0, gin0_64=gin0_64, val64=val64,
                           per_layer=torch.cat([p.reshape(3, 1) for p in per_layer], 1),
                           meta=dict(lpips=lp, state_dict_keys=sorted(net.state_dict().keys()),
                                     shapes={k: list(v.shape) for k, v in net.state_dict().items()})))

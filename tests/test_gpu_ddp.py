@@ -79,6 +79,7 @@ def _worker(rank, world, port, q):
         piped, immediate = [], []
         tr = GangealingTrainer(dev, pipeline_update=True, **KW)
         assert tr.world == world and tr.pipeline_update
+        init = tr.stn_arena.param.cpu()
         _run(tr, dist, world, piped)
         tr2 = GangealingTrainer(dev, pipeline_update=False, **KW)
         _run(tr2, dist, world, immediate)
@@ -94,17 +95,21 @@ def _worker(rank, world, port, q):
             ok_sum = ok_sum and torch.equal(rec['consumed'], locs[0] + locs[1])
             distinct = distinct or not torch.equal(locs[0], locs[1])
         # (iii): same iterations, immediate order.  Split-K atomics make gradients differ in the last bits from run to
-        # run and Adam's first steps are ~lr * sign(g), so two runs of the SAME order differ in a small fraction of
-        # entries by up to 2 lr per step; a missing / doubled / mis-ordered update would move every entry.
-        lr = 1e-3
-        frac = lambda a, b, tol: float(((a - b).abs() > tol).float().mean())
+        # run and Adam's first steps are ~lr * sign(g), so entries whose gradient is near zero take different signs
+        # in two runs of even the SAME order: compare what is robust - the gradient the first update consumed (both
+        # runs start from identical parameters), each step's update direction and length, and the losses.  A missing
+        # or doubled update gives a norm ratio of 0 / 2, a mis-ordered one a different gradient.
+        g_p, g_i = piped[0]['consumed'], immediate[0]['consumed']
+        first_grad = float((g_p - g_i).abs().max() / g_i.abs().max())
         agree = []
-        for s, (a, b) in enumerate(zip(piped, immediate)):
-            agree.append((frac(a['param'], b['param'], 2e-4), float((a['param'] - b['param']).abs().max()),
-                          abs(a['loss'] - b['loss']) / max(abs(b['loss']), 1e-12)))
-        moved = frac(piped[-1]['param'], piped[0]['param'], 1e-6)
-        result.update(ok_sync=bool(ok_sync), ok_sum=bool(ok_sum), distinct=bool(distinct), agree=agree, moved=moved,
-                      lr=lr)
+        prev_p = prev_i = init
+        for a, b in zip(piped, immediate):
+            dp, di = (a['param'] - prev_p).double(), (b['param'] - prev_i).double()
+            cos = float((dp * di).sum() / (dp.norm() * di.norm()))
+            agree.append((cos, float(dp.norm() / di.norm()), abs(a['loss'] - b['loss']) / max(abs(b['loss']), 1e-12)))
+            prev_p, prev_i = a['param'], b['param']
+        result.update(ok_sync=bool(ok_sync), ok_sum=bool(ok_sum), distinct=bool(distinct), agree=agree,
+                      first_grad=first_grad)
     except Exception as e:          # surface the failure in the parent instead of a queue timeout
         import traceback
         result['error'] = ''.join(traceback.format_exception(type(e), e, e.__traceback__))[-3000:]
@@ -127,8 +132,10 @@ def test_two_ranks_one_gpu_pipelined_trainer(cuda):
         assert 'error' not in res, res['error']
         assert res['ok_sync'], 'replicas diverged after flush()'
         assert res['ok_sum'] and res['distinct'], (res['ok_sum'], res['distinct'])
-        for s, (fr, mx, dl) in enumerate(res['agree']):
-            assert fr < 0.05 and mx <= 2.1 * res['lr'] * (s + 1) and dl < 2e-2, (s, fr, mx, dl)
-        assert res['moved'] > 0.9
+        # same parameters, same data: the two orders consume the same gradient up to the arg-max routing of exactly
+        # tied mip-level distances, which last-bit noise of the split-K forward can flip
+        assert res['first_grad'] < 1e-2, res['first_grad']
+        for s, (cos, ratio, dl) in enumerate(res['agree']):
+            assert cos > 0.7 and 0.7 < ratio < 1.4 and dl < 2e-2, (s, cos, ratio, dl)
     for p in procs:
         assert p.exitcode == 0
