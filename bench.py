@@ -30,16 +30,18 @@ WORKLOADS = {
 }
 
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks
-MFMA_PEAK_TFLOPS = {'fp32': 157.3, 'bf16x3': 2500.0, 'bf16x6': 2500.0}
+MFMA_PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0, 'bf16x6': 2500.0}
 KERNEL_NAME = {
     'fp32': 'conv_igemm_kernel<3,0,2,2,2,2,*> (3x3 correlation, 128co x 128pix tile, v_mfma_f32_32x32x2_f32)',
     'bf16x3': 'conv3x3_patch_kernel<2, true, 256, 2, false> (3x3 stride-1 modulated conv + fused noise/bias/lrelu epilogue, '
               '128co x 256pix tile, input patch staged once per 32-channel chunk, v_mfma_f32_32x32x16_bf16, 2 bf16 '
               'limbs per fp32 operand = 3 MFMA products per algorithmic product)',
+    'bf16': 'conv3x3_patch_kernel<1, true, 256, 2, false> (same kernel and tile as bf16x3, one bf16 limb per operand = one '
+            'MFMA product per algorithmic product, fp32 accumulate)',
     'bf16x6': 'conv3x3_patch_kernel<3, true, 128, 2, false> (same layers, 128co x 128pix tile, 3 bf16 limbs per fp32 operand '
               '= 6 MFMA products per algorithmic product)',
 }
-MFMA_PRODUCTS = {'fp32': 1, 'bf16x3': 3, 'bf16x6': 6}
+MFMA_PRODUCTS = {'fp32': 1, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}
 
 
 def pmc_traffic(precision, workload, batch):
@@ -56,7 +58,7 @@ def pmc_traffic(precision, workload, batch):
     return rec.get('hbm_bytes_per_launch')
 
 
-DTYPE = {'fp32': 'f32', 'bf16x3': 'bf16x3 (fp32 operands split into 2 bf16 limbs, fp32 accumulate)',
+DTYPE = {'fp32': 'f32', 'bf16': 'bf16 (convolution operands rounded to bf16, fp32 accumulate, fp32 activations)', 'bf16x3': 'bf16x3 (fp32 operands split into 2 bf16 limbs, fp32 accumulate)',
          'bf16x6': 'bf16x6 (fp32 operands split into 3 bf16 limbs, fp32 accumulate)'}
 
 
@@ -111,8 +113,11 @@ def main():
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
     ap.add_argument('--precision', default=os.environ.get('GANGEALING_CONV_PRECISION', 'bf16x3'),
-                    choices=['fp32', 'bf16x3', 'bf16x6'],
+                    choices=['fp32', 'bf16', 'bf16x3', 'bf16x6'],
                     help='arithmetic of the implicit-GEMM convolutions (fp32 = exact fp32 MFMA parity mode)')
+    ap.add_argument('--graph', action='store_true',
+                    help='capture the whole iteration in a hipGraph and replay it (single GPU); the roofline entry is then '
+                         'timed on eager iterations run right after the timed region')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
@@ -140,18 +145,21 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl['batch'] = args.batch
-    trainer = GangealingTrainer(device, perturb_heads=0.02, seed=0, **wl)
+    trainer = GangealingTrainer(device, perturb_heads=0.02, seed=0, use_graph=args.graph and world == 1, **wl)
 
     def barrier():
         torch.cuda.synchronize()
         gdist.synchronize()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    graphed = trainer.use_graph
+    for _ in range(max(args.warmup, trainer._graph_warmup + 1 if graphed else 0)):
         trainer.step(psi=0.5)
     trainer.flush()
     barrier()
-    conv_mfma.PROFILER = prof = conv_mfma.LaunchProfiler()
+    prof = conv_mfma.LaunchProfiler()
+    if not graphed:
+        conv_mfma.PROFILER = prof        # HIP events around the dominant kernel's launches inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         parts = trainer.step(psi=0.5)
@@ -159,6 +167,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     conv_mfma.PROFILER = None
+    if graphed:
+        # events cannot be recorded inside a replayed graph: time the same launches on eager iterations of the same
+        # trainer right after the timed region (same kernels, same shapes, same data distribution)
+        loss_parts = {k: (v.clone() if v is not None else None) for k, v in parts.items()}
+        trainer.use_graph = False
+        conv_mfma.PROFILER = prof
+        for _ in range(3):
+            trainer.step(psi=0.5)
+        torch.cuda.synchronize()
+        conv_mfma.PROFILER = None
+        parts = loss_parts
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -186,6 +205,7 @@ def main():
                                    f'{wl["flow_size"]}^2, per-GPU batch {wl["batch"]}, VGG16-topology perceptual loss '
                                    f'(random weights), random-init frozen G, psi 0.5',
                        'global_batch': world * wl['batch'], 'parallelism': f'dp{world}',
+                       'launch': 'hipGraph replay of the whole iteration' if graphed else 'eager launches',
                        'loss': float(parts['p'])},
             'roofline': {
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS[args.precision],

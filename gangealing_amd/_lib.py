@@ -56,10 +56,14 @@ _PROTOS = {
     'gg_conv3x3_masked_wgrad_f32': 'pppppffiiiiifiipqs',
     'gg_style_demod_f32': 'pppqpppiiiifffs',
     'gg_lpips_tail_fwd_f32': 'pppiiqfs',
-    'gg_lpips_tail_bwd_f32': 'ppppiiqfs',
+    'gg_lpips_tail_bwd_f32': 'ppppiiqfis',
     'gg_torgb_dgrad_add_f32': 'ppppfiiqs',
     'gg_plane_dot_f32': 'pppiqs',
     'gg_adam_ema_f32': 'pppppqffffiffs',
+    'gg_adam_ema_dev_f32': 'pppppqpffffs',
+    'gg_upfirdn2d_add_f32': 'ppppiiiiiiiiiiiiis',
+    'gg_add_scale_f32': 'pppfqs',
+    'gg_style_bank_f32': 'ppqipiipiiis',
 }
 _CTYPE = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'q': ctypes.c_longlong, 'f': ctypes.c_float,
           'd': ctypes.c_double, 's': ctypes.c_void_p}

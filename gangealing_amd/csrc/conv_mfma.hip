@@ -1924,6 +1924,19 @@ int launch_conv(const ConvArgs& a, int tile, hipStream_t st) {
   return gg::launch_status("conv_igemm");
 }
 
+// One or two bf16 limbs per operand share the tile choices ("bf16": a single product, |error| ~ 2^-9 |a||b| - the
+// arithmetic BASELINE.json's benchmark configuration names; "bf16x3": see above).  LIMBS12 instantiates a launch for both.
+#define LIMBS12(limbs, ...)            \
+  do {                                 \
+    if ((limbs) == 1) {                \
+      constexpr int L = 1;             \
+      __VA_ARGS__;                     \
+    } else {                           \
+      constexpr int L = 2;             \
+      __VA_ARGS__;                     \
+    }                                  \
+  } while (0)
+
 // 256-pixel tiles (8 waves) halve the weight stream per output; use them while they still give >= 2 blocks per CU
 int split_tile(const ConvArgs& a, int limbs) {
   const long long tiles256 = ((long long)a.batch * a.mh * a.mw + 255) / 256 * ((a.cout_g + 127) / 128) * a.groups;
@@ -1933,7 +1946,7 @@ int split_tile(const ConvArgs& a, int limbs) {
   // stride-2 correlations re-gather per tap: two unsynchronised 4-wave blocks per CU overlap gather and MFMA phases
   // better than one 8-wave block (measured 175 -> 205 TF/s on the generator's up-conv data gradients)
   if (a.bs == 2) return 0;
-  return (limbs == 2 && tiles256 >= 2 * gg::kNumCu) ? 4 : 0;
+  return (limbs <= 2 && tiles256 >= 2 * gg::kNumCu) ? 4 : 0;
 }
 
 template <int KS, int MODE>
@@ -1941,12 +1954,12 @@ int launch_conv_split(const ConvArgs& a, int limbs, hipStream_t st) {
   if ((long long)a.tiles_pix * a.tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
-  if (limbs == 2 && a.tile_pixels == 256) {
-    if (sc) conv_split_kernel<KS, MODE, 2, true, 256><<<grid, 512, 0, st>>>(a);
-    else conv_split_kernel<KS, MODE, 2, false, 256><<<grid, 512, 0, st>>>(a);
-  } else if (limbs == 2) {
-    if (sc) conv_split_kernel<KS, MODE, 2, true, 128><<<grid, 256, 0, st>>>(a);
-    else conv_split_kernel<KS, MODE, 2, false, 128><<<grid, 256, 0, st>>>(a);
+  if (limbs <= 2 && a.tile_pixels == 256) {
+    if (sc) LIMBS12(limbs, conv_split_kernel<KS, MODE, L, true, 256><<<grid, 512, 0, st>>>(a));
+    else LIMBS12(limbs, conv_split_kernel<KS, MODE, L, false, 256><<<grid, 512, 0, st>>>(a));
+  } else if (limbs <= 2) {
+    if (sc) LIMBS12(limbs, conv_split_kernel<KS, MODE, L, true, 128><<<grid, 256, 0, st>>>(a));
+    else LIMBS12(limbs, conv_split_kernel<KS, MODE, L, false, 128><<<grid, 256, 0, st>>>(a));
   } else {
     if (sc) conv_split_kernel<KS, MODE, 3, true, 128><<<grid, 256, 0, st>>>(a);
     else conv_split_kernel<KS, MODE, 3, false, 128><<<grid, 256, 0, st>>>(a);
@@ -1980,7 +1993,7 @@ bool patch_geometry(const ConvArgs& a, int tpix, int& tw_log2, int limbs = 2) {
 int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t st) {
   // plan in units of 32-channel chunks
   a.mh = a.oh; a.mw = a.ow;
-  const bool narrow = limbs == 2 && a.cout_g <= 64;           // 64-channel tiles
+  const bool narrow = limbs <= 2 && a.cout_g <= 64;           // 64-channel tiles
   a.tiles_co = narrow ? 1 : (a.cout_g + 127) / 128;
   const long long tp = (long long)a.batch * a.oh * a.ow / tpix;
   if (tp * a.tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
@@ -2006,30 +2019,30 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
   if (a.splitk > 1) a.act = 0;                              // atomically combined partials: activation afterwards
   if (a.mask_ref) {          // limbs == 2 (checked by the caller)
     if (narrow && tpix == 256) {
-      if (sc) conv3x3_patch_kernel<2, true, 256, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
-      else conv3x3_patch_kernel<2, false, 256, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+      if (sc) LIMBS12(limbs, conv3x3_patch_kernel<L, true, 256, 1, true><<<grid, 512, 0, st>>>(a, tw_log2));
+      else LIMBS12(limbs, conv3x3_patch_kernel<L, false, 256, 1, true><<<grid, 512, 0, st>>>(a, tw_log2));
     } else if (narrow) {
-      if (sc) conv3x3_patch_kernel<2, true, 128, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
-      else conv3x3_patch_kernel<2, false, 128, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+      if (sc) LIMBS12(limbs, conv3x3_patch_kernel<L, true, 128, 1, true><<<grid, 256, 0, st>>>(a, tw_log2));
+      else LIMBS12(limbs, conv3x3_patch_kernel<L, false, 128, 1, true><<<grid, 256, 0, st>>>(a, tw_log2));
     } else if (tpix == 256) {
-      if (sc) conv3x3_patch_kernel<2, true, 256, 2, true><<<grid, 512, 0, st>>>(a, tw_log2);
-      else conv3x3_patch_kernel<2, false, 256, 2, true><<<grid, 512, 0, st>>>(a, tw_log2);
+      if (sc) LIMBS12(limbs, conv3x3_patch_kernel<L, true, 256, 2, true><<<grid, 512, 0, st>>>(a, tw_log2));
+      else LIMBS12(limbs, conv3x3_patch_kernel<L, false, 256, 2, true><<<grid, 512, 0, st>>>(a, tw_log2));
     } else {
-      if (sc) conv3x3_patch_kernel<2, true, 128, 2, true><<<grid, 256, 0, st>>>(a, tw_log2);
-      else conv3x3_patch_kernel<2, false, 128, 2, true><<<grid, 256, 0, st>>>(a, tw_log2);
+      if (sc) LIMBS12(limbs, conv3x3_patch_kernel<L, true, 128, 2, true><<<grid, 256, 0, st>>>(a, tw_log2));
+      else LIMBS12(limbs, conv3x3_patch_kernel<L, false, 128, 2, true><<<grid, 256, 0, st>>>(a, tw_log2));
     }
   } else if (narrow && tpix == 256) {
-    if (sc) conv3x3_patch_kernel<2, true, 256, 1><<<grid, 512, 0, st>>>(a, tw_log2);
-    else conv3x3_patch_kernel<2, false, 256, 1><<<grid, 512, 0, st>>>(a, tw_log2);
+    if (sc) LIMBS12(limbs, conv3x3_patch_kernel<L, true, 256, 1><<<grid, 512, 0, st>>>(a, tw_log2));
+    else LIMBS12(limbs, conv3x3_patch_kernel<L, false, 256, 1><<<grid, 512, 0, st>>>(a, tw_log2));
   } else if (narrow) {
-    if (sc) conv3x3_patch_kernel<2, true, 128, 1><<<grid, 256, 0, st>>>(a, tw_log2);
-    else conv3x3_patch_kernel<2, false, 128, 1><<<grid, 256, 0, st>>>(a, tw_log2);
-  } else if (limbs == 2 && tpix == 256) {
-    if (sc) conv3x3_patch_kernel<2, true, 256><<<grid, 512, 0, st>>>(a, tw_log2);
-    else conv3x3_patch_kernel<2, false, 256><<<grid, 512, 0, st>>>(a, tw_log2);
-  } else if (limbs == 2) {
-    if (sc) conv3x3_patch_kernel<2, true, 128><<<grid, 256, 0, st>>>(a, tw_log2);
-    else conv3x3_patch_kernel<2, false, 128><<<grid, 256, 0, st>>>(a, tw_log2);
+    if (sc) LIMBS12(limbs, conv3x3_patch_kernel<L, true, 128, 1><<<grid, 256, 0, st>>>(a, tw_log2));
+    else LIMBS12(limbs, conv3x3_patch_kernel<L, false, 128, 1><<<grid, 256, 0, st>>>(a, tw_log2));
+  } else if (limbs <= 2 && tpix == 256) {
+    if (sc) LIMBS12(limbs, conv3x3_patch_kernel<L, true, 256><<<grid, 512, 0, st>>>(a, tw_log2));
+    else LIMBS12(limbs, conv3x3_patch_kernel<L, false, 256><<<grid, 512, 0, st>>>(a, tw_log2));
+  } else if (limbs <= 2) {
+    if (sc) LIMBS12(limbs, conv3x3_patch_kernel<L, true, 128><<<grid, 256, 0, st>>>(a, tw_log2));
+    else LIMBS12(limbs, conv3x3_patch_kernel<L, false, 128><<<grid, 256, 0, st>>>(a, tw_log2));
   } else {
     if (sc) conv3x3_patch_kernel<3, true, 128><<<grid, 256, 0, st>>>(a, tw_log2);
     else conv3x3_patch_kernel<3, false, 128><<<grid, 256, 0, st>>>(a, tw_log2);
@@ -2054,7 +2067,7 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   int tiles_y, edge;
   int tq = 128;
   long long tp = tiles_for(tq, tiles_y, edge);
-  if (limbs != 2 || tp * a.tiles_co * a.groups < 2 * gg::kNumCu) {
+  if (limbs > 2 || tp * a.tiles_co * a.groups < 2 * gg::kNumCu) {
     tq = 64;
     tp = tiles_for(tq, tiles_y, edge);
   }
@@ -2077,12 +2090,12 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   }
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
-  if (limbs == 2 && tq == 128) {
-    if (sc) convT3x3s2_patch_kernel<2, true, 128><<<grid, 512, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
-    else convT3x3s2_patch_kernel<2, false, 128><<<grid, 512, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
-  } else if (limbs == 2) {
-    if (sc) convT3x3s2_patch_kernel<2, true, 64><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
-    else convT3x3s2_patch_kernel<2, false, 64><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
+  if (limbs <= 2 && tq == 128) {
+    if (sc) LIMBS12(limbs, convT3x3s2_patch_kernel<L, true, 128><<<grid, 512, 0, st>>>(a, tw_log2, tiles_y, edge, pad));
+    else LIMBS12(limbs, convT3x3s2_patch_kernel<L, false, 128><<<grid, 512, 0, st>>>(a, tw_log2, tiles_y, edge, pad));
+  } else if (limbs <= 2) {
+    if (sc) LIMBS12(limbs, convT3x3s2_patch_kernel<L, true, 64><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad));
+    else LIMBS12(limbs, convT3x3s2_patch_kernel<L, false, 64><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad));
   } else {
     if (sc) convT3x3s2_patch_kernel<3, true, 64><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
     else convT3x3s2_patch_kernel<3, false, 64><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
@@ -2096,7 +2109,7 @@ template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {
   if (a.mask_ref) {
     int tw_log2;
-    if (!(limbs == 2 && KS == 3 && mode == 0 && stride == 1 && pad == 1)) return kNotFused;
+    if (!((limbs == 1 || limbs == 2) && KS == 3 && mode == 0 && stride == 1 && pad == 1)) return kNotFused;
     const long long tiles256 = (long long)a.batch * a.oh * a.ow / 256 * ((a.cout_g + 127) / 128) * a.groups;
     if (tiles256 >= 2 * gg::kNumCu && patch_geometry(a, 256, tw_log2)) return launch_conv_patch(a, limbs, tw_log2, 256, st);
     if (patch_geometry(a, 128, tw_log2)) return launch_conv_patch(a, limbs, tw_log2, 128, st);
@@ -2109,7 +2122,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     int tw_log2;
     // 256-pixel tiles when they still fill the chip (>= 2 blocks per CU), else 128-pixel tiles
     const long long tiles256 = (long long)a.batch * a.oh * a.ow / 256 * ((a.cout_g + 127) / 128) * a.groups;
-    if (limbs == 2 && tiles256 >= 2 * gg::kNumCu && patch_geometry(a, 256, tw_log2))
+    if (limbs <= 2 && tiles256 >= 2 * gg::kNumCu && patch_geometry(a, 256, tw_log2))
       return launch_conv_patch(a, limbs, tw_log2, 256, st);
     if (patch_geometry(a, 128, tw_log2, limbs)) return launch_conv_patch(a, limbs, tw_log2, 128, st);
   }
@@ -2214,7 +2227,7 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   if (mode == 1 && stride != 2)
     return gg::fail(-2, "conv2d: transposed mode is implemented for stride 2 (stride 1 = mode 0 with flipped taps)");
   if (limbs) {
-    if (limbs != 2 && limbs != 3) return gg::fail(-2, "conv2d_split: limbs must be 2 or 3");
+    if (limbs < 1 || limbs > 3) return gg::fail(-2, "conv2d_split: limbs must be 1, 2 or 3");
     if (cin_g % BKS != 0) return gg::fail(-2, "conv2d_split: cin per group must be a multiple of %d", BKS);
     if (in_scale && (reinterpret_cast<uintptr_t>(in_scale) & 15)) return gg::fail(-2, "conv2d_split: in_scale must be 16-byte aligned");
     if (reinterpret_cast<uintptr_t>(wsplit) & 15) return gg::fail(-2, "conv2d_split: weights must be 16-byte aligned");
@@ -2281,7 +2294,7 @@ extern "C" int gg_conv3x3_masked_dgrad_f32(float* y, const float* x, const float
                                            const float* in_scale, const float* out_scale, int batch, int cin,
                                            int cout, int h, int w, void* stream) {
   if (!mask_ref) return gg::fail(-2, "conv3x3_masked_dgrad: mask_ref missing");
-  if (limbs != 2) return kNotFused;
+  if (limbs != 1 && limbs != 2) return kNotFused;
   MaskArgs mask;
   mask.ref = mask_ref; mask.alpha = alpha; mask.gain = gain;
   return conv2d_entry(y, x, nullptr, wsplit, limb_stride, limbs, in_scale, out_scale, nullptr, batch, 1, cin, cout, h,
@@ -2332,7 +2345,7 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
   };
   if (batch <= 0 || a.oh <= 0 || a.ow <= 0) return zero_dw();
   if (limbs) {
-    if (limbs != 2 && limbs != 3) return gg::fail(-2, "conv2d_wgrad_split: limbs must be 2 or 3");
+    if (limbs < 1 || limbs > 3) return gg::fail(-2, "conv2d_wgrad_split: limbs must be 1, 2 or 3");
     if ((a.oh * a.ow) % BKS != 0 || a.ow % 4 != 0 || (reinterpret_cast<uintptr_t>(dy) & 15))
       return gg::fail(-2, "conv2d_wgrad_split: needs OH*OW %% 32 == 0, OW %% 4 == 0 and 16-byte aligned dy");
   }
@@ -2387,19 +2400,19 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
     if (workspace && workspace_bytes >= need && splits <= 65535 && (long long)a.tiles_co * a.tiles_j < (1LL << 31)) {
       dim3 grid((unsigned)(a.tiles_co * a.tiles_j), (unsigned)splits, (unsigned)groups);
       if (strip16) {
-        if (limbs == 2) {
-          if (narrow) conv3x3_wgrad_rows_kernel<2, 64, 64, false, 16><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
-          else conv3x3_wgrad_rows_kernel<2, 128, 32, false, 16><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
+        if (limbs <= 2) {
+          if (narrow) LIMBS12(limbs, conv3x3_wgrad_rows_kernel<L, 64, 64, false, 16><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws));
+          else LIMBS12(limbs, conv3x3_wgrad_rows_kernel<L, 128, 32, false, 16><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws));
         } else {
           if (narrow) conv3x3_wgrad_rows_kernel<3, 64, 64, false, 16><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
           else conv3x3_wgrad_rows_kernel<3, 128, 32, false, 16><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
         }
       } else if (a.mask_ref) {   // limbs == 2 (checked by the entry point)
-        if (narrow) conv3x3_wgrad_rows_kernel<2, 64, 64, true><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
-        else conv3x3_wgrad_rows_kernel<2, 128, 32, true><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
-      } else if (limbs == 2) {
-        if (narrow) conv3x3_wgrad_rows_kernel<2, 64, 64><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
-        else conv3x3_wgrad_rows_kernel<2, 128, 32><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
+        if (narrow) LIMBS12(limbs, conv3x3_wgrad_rows_kernel<L, 64, 64, true><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws));
+        else LIMBS12(limbs, conv3x3_wgrad_rows_kernel<L, 128, 32, true><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws));
+      } else if (limbs <= 2) {
+        if (narrow) LIMBS12(limbs, conv3x3_wgrad_rows_kernel<L, 64, 64><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws));
+        else LIMBS12(limbs, conv3x3_wgrad_rows_kernel<L, 128, 32><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws));
       } else {
         if (narrow) conv3x3_wgrad_rows_kernel<3, 64, 64><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
         else conv3x3_wgrad_rows_kernel<3, 128, 32><<<grid, 256, 0, st>>>(a, segs, (int)rblocks, rows_per_block, (int)upb, workspace, dbws);
@@ -2435,9 +2448,9 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
   splits = (a.ktot + kps - 1) / kps;
   a.k_per_split = kps;
   dim3 grid((unsigned)(a.tiles_co * a.tiles_j), (unsigned)splits, (unsigned)groups);
-  if (limbs == 2) {
-    if (ksize == 3) conv_wgrad_split_kernel<3, 2><<<grid, 256, 0, st>>>(a);
-    else conv_wgrad_split_kernel<1, 2><<<grid, 256, 0, st>>>(a);
+  if (limbs == 1 || limbs == 2) {
+    if (ksize == 3) LIMBS12(limbs, conv_wgrad_split_kernel<3, L><<<grid, 256, 0, st>>>(a));
+    else LIMBS12(limbs, conv_wgrad_split_kernel<1, L><<<grid, 256, 0, st>>>(a));
   } else if (limbs == 3) {
     if (ksize == 3) conv_wgrad_split_kernel<3, 3><<<grid, 256, 0, st>>>(a);
     else conv_wgrad_split_kernel<1, 3><<<grid, 256, 0, st>>>(a);
@@ -2481,7 +2494,7 @@ extern "C" int gg_conv3x3_masked_wgrad_f32(float* dw, float* dbias, const float*
                                            int cout, int h, int w, float scale, int limbs, int accumulate,
                                            float* workspace, long long workspace_bytes, void* stream) {
   if (!mask_ref) return gg::fail(-2, "conv3x3_masked_wgrad: mask_ref missing");
-  if (limbs != 2 || (reinterpret_cast<uintptr_t>(mask_ref) & 15)) return kNotFused;
+  if ((limbs != 1 && limbs != 2) || (reinterpret_cast<uintptr_t>(mask_ref) & 15)) return kNotFused;
   return wgrad_entry(dw, x, dy, batch, 1, cin, cout, h, w, 3, 1, 1, scale, limbs, stream, accumulate != 0, workspace,
                      workspace_bytes, mask_ref, alpha, gain, dbias);
 }

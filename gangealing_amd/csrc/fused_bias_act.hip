@@ -198,3 +198,30 @@ extern "C" int gg_fused_lrelu_bwd_f64(double* grad_in, double* grad_bias, const 
                                       double alpha, double scale, int n, int c, long long hw, void* stream) {
   return fused_lrelu_bwd_impl<double>(grad_in, grad_bias, grad_out, out, alpha, scale, n, c, hw, stream);
 }
+
+// (a + b) * scale in one pass: the residual merge of ResBlock, (out + skip) / sqrt(2) (networks.py:392-393).
+namespace {
+__global__ __launch_bounds__(256) void add_scale_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                        const float* __restrict__ b, float scale, long long n4,
+                                                        long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    float4 r;
+    r.x = (x.x + y.x) * scale; r.y = (x.y + y.y) * scale; r.z = (x.z + y.z) * scale; r.w = (x.w + y.w) * scale;
+    reinterpret_cast<float4*>(out)[i] = r;
+  }
+  for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = (a[i] + b[i]) * scale;
+}
+}  // namespace
+
+extern "C" int gg_add_scale_f32(float* out, const float* a, const float* b, float scale, long long n, void* stream) {
+  if (n <= 0) return 0;
+  if (!out || !a || !b) return gg::fail(-2, "add_scale: null pointer");
+  const bool vec = aligned16(out) && aligned16(a) && aligned16(b);
+  const long long n4 = vec ? n / 4 : 0;
+  add_scale_kernel<<<gg::stream_grid(vec ? n4 + 1 : n, 256), 256, 0, gg::as_stream(stream)>>>(out, a, b, scale, n4, n);
+  return gg::launch_status("add_scale");
+}
+

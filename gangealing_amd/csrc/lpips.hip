@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void lpips_tail_fwd_kernel(float* __restrict__
 __global__ __launch_bounds__(256) void lpips_tail_bwd_kernel(float* __restrict__ df, const float* __restrict__ f,
                                                              const float* __restrict__ lin,
                                                              const float* __restrict__ gout, int n, int c,
-                                                             long long hw, float eps, float inv_hw) {
+                                                             long long hw, float eps, float inv_hw, int accumulate) {
   __shared__ float red[CG][5][PIX];
   const int s = blockIdx.y, px = threadIdx.x & (PIX - 1), grp = threadIdx.x >> 6;
   const float* f0 = f + (size_t)s * c * hw;
@@ -96,8 +96,14 @@ __global__ __launch_bounds__(256) void lpips_tail_bwd_kernel(float* __restrict__
       for (int k = grp; k < c; k += CG) {
         const float u0 = f0[(size_t)k * hw + p] * a0, u1 = f1[(size_t)k * hw + p] * a1;
         const float q = g2 * (lin ? lin[k] : 1.f) * (u0 - u1);
-        d0[(size_t)k * hw + p] = a0 * q - u0 * r0;
-        d1[(size_t)k * hw + p] = -a1 * q - u1 * r1;
+        const float e0 = a0 * q - u0 * r0, e1 = -a1 * q - u1 * r1;
+        if (accumulate) {        // df already holds the gradient that reached this feature map from the next stage
+          d0[(size_t)k * hw + p] += e0;
+          d1[(size_t)k * hw + p] += e1;
+        } else {
+          d0[(size_t)k * hw + p] = e0;
+          d1[(size_t)k * hw + p] = e1;
+        }
       }
   }
 }
@@ -122,11 +128,11 @@ extern "C" int gg_lpips_tail_fwd_f32(float* out, const float* feats, const float
 }
 
 extern "C" int gg_lpips_tail_bwd_f32(float* dfeats, const float* feats, const float* lin, const float* grad_out, int n,
-                                     int c, long long hw, float eps, void* stream) {
+                                     int c, long long hw, float eps, int accumulate, void* stream) {
   if (n <= 0) return 0;
   if (!dfeats || !feats || !grad_out || c <= 0 || hw <= 0 || n > 65535)
     return gg::fail(-2, "lpips_tail_bwd: bad arguments");
   lpips_tail_bwd_kernel<<<tail_grid(n, hw), 256, 0, gg::as_stream(stream)>>>(dfeats, feats, lin, grad_out, n, c, hw, eps,
-                                                                            1.f / (float)hw);
+                                                                            1.f / (float)hw, accumulate);
   return gg::launch_status("lpips_tail_bwd");
 }

@@ -138,6 +138,109 @@ extern "C" int gg_torgb_dgrad_add_f32(float* g, const float* grad_rgb, const flo
   return gg::launch_status("torgb_dgrad_add");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Style bank: the modulation vectors of MANY layers in two launches (all styles, then all demodulations) instead of
+// two launches per layer.  The generator is frozen, so the job table (weights, sizes, output offsets) is built once;
+// per call only the latent base pointer and the output buffer change.
+//   phase 0 job: out[n, r] = sum_k latent[n, slot, k] * m[r, k] * scale + bias[r] * bias_scale        (EqualLinear)
+//   phase 1 job: out[n, r] = rsqrt(sum_k in[n, k]^2 * m[r, k] + eps),  in = a phase-0 output         (demodulation)
+struct StyleJob {
+  const float* m;          // (rows, kdim) weight / squared-weight table
+  const float* bias;       // (rows) or null
+  long long out_off;       // float offset of this job's (n, rows) output inside `out_base`
+  long long in_off;        // phase 0: latent slot index; phase 1: float offset of the (n, kdim) input inside `out_base`
+  int kdim, rows;
+  float scale, bias_scale, eps;
+  int pad;
+};
+static_assert(sizeof(StyleJob) == 56, "StyleJob layout is mirrored by numpy in op/conv_mfma.py");
+
+template <bool DEMOD>
+__global__ __launch_bounds__(256) void style_bank_kernel(float* __restrict__ out_base, const float* __restrict__ latent,
+                                                         long long lat_sample_stride, int slot_stride,
+                                                         const StyleJob* __restrict__ jobs, int n_total) {
+  __shared__ float sin[LDS_FLOATS];
+  const StyleJob job = jobs[blockIdx.z];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wid;
+  if (blockIdx.x * 4 >= job.rows) return;                  // whole block beyond this job's rows
+  const int kdim = job.kdim;
+  const int nb = min(LDS_FLOATS / kdim, n_total);
+  const float* in = DEMOD ? out_base + job.in_off : latent + job.in_off * slot_stride;
+  const long long in_stride = DEMOD ? kdim : lat_sample_stride;
+  const float* row = job.m + (size_t)(r < job.rows ? r : 0) * kdim;
+  float wreg[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = lane + 64 * j;
+    wreg[j] = k < kdim ? row[k] : 0.f;
+  }
+  const float bb = (!DEMOD && job.bias && r < job.rows) ? job.bias[r] * job.bias_scale : 0.f;
+  float* out = out_base + job.out_off;
+  for (int n0 = 0; n0 < n_total; n0 += nb) {
+    const int ncount = min(nb, n_total - n0);
+    const int total = ncount * kdim;
+    __syncthreads();
+    for (int base = 0; base < total; base += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * 256 + threadIdx.x;
+        const int n = i / kdim, k = i - n * kdim;
+        v[u] = i < total ? in[(size_t)(n0 + n) * in_stride + k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * 256 + threadIdx.x;
+        if (i < total) sin[i] = DEMOD ? v[u] * v[u] : v[u];
+      }
+    }
+    __syncthreads();
+    if (r < job.rows)
+      for (int nb4 = 0; nb4 < ncount; nb4 += 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* x = sin + (nb4 + u < ncount ? nb4 + u : nb4) * kdim;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = lane + 64 * j;
+            acc[u] += (k < kdim ? x[k] : 0.f) * wreg[j];
+          }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[u] += __shfl_down(acc[u], off, 64);
+        if (lane == 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (nb4 + u < ncount) {
+              const float v = acc[u] * job.scale + bb;
+              out[(size_t)(n0 + nb4 + u) * job.rows + r] = DEMOD ? rsqrtf(v + job.eps) : v;
+            }
+        }
+      }
+  }
+}
+
+extern "C" int gg_style_bank_f32(float* out_base, const float* latent, long long lat_sample_stride, int slot_stride,
+                                 const void* style_jobs, int n_style_jobs, int max_style_rows, const void* demod_jobs,
+                                 int n_demod_jobs, int max_demod_rows, int n, void* stream) {
+  if (n <= 0 || n_style_jobs <= 0) return 0;
+  if (!out_base || !latent || !style_jobs || (n_demod_jobs > 0 && !demod_jobs))
+    return gg::fail(-2, "style_bank: null pointer");
+  if (n_style_jobs > 65535 || n_demod_jobs > 65535) return gg::fail(-2, "style_bank: too many jobs");
+  hipStream_t st = gg::as_stream(stream);
+  style_bank_kernel<false><<<dim3((unsigned)((max_style_rows + 3) / 4), 1, (unsigned)n_style_jobs), 256, 0, st>>>(
+      out_base, latent, lat_sample_stride, slot_stride, static_cast<const StyleJob*>(style_jobs), n);
+  int rc = gg::launch_status("style_bank (styles)");
+  if (rc || n_demod_jobs <= 0) return rc;
+  style_bank_kernel<true><<<dim3((unsigned)((max_demod_rows + 3) / 4), 1, (unsigned)n_demod_jobs), 256, 0, st>>>(
+      out_base, latent, lat_sample_stride, slot_stride, static_cast<const StyleJob*>(demod_jobs), n);
+  return gg::launch_status("style_bank (demodulation)");
+}
+
 extern "C" int gg_style_demod_f32(float* style, float* demod, const float* latent, long long lat_stride,
                                   const float* w, const float* b, const float* wsq, int n, int style_dim, int cin,
                                   int cout, float w_scale, float b_scale, float eps, void* stream) {

@@ -321,7 +321,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void upfirdn2d_direct(
     T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ kernel,
     long long total, int in_h, int in_w, int out_h, int out_w, int kh, int kw,
-    int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_y0) {
+    int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_y0, const T* __restrict__ addend = nullptr) {
   __shared__ T sk[MAX_LDS_TAPS];
   const bool lds_taps = kh * kw <= MAX_LDS_TAPS;
   if (lds_taps) {
@@ -352,6 +352,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_direct(
         acc += src[(size_t)iy * in_w + ix] * kv;
       }
     }
+    if (addend) acc += addend[o];
     out[o] = acc;
   }
 }
@@ -386,6 +387,25 @@ extern "C" int gg_upfirdn2d_f32(float* out, const float* in, const float* kernel
   return upfirdn2d_impl<float>(out, in, kernel, major, in_h, in_w, kernel_h, kernel_w, up_x, up_y, down_x, down_y,
                                pad_x0, pad_x1, pad_y0, pad_y1, stream);
 }
+// upfirdn2d(in) + addend in one pass: the ToRGB skip connection `rgb + Upsample(skip)` (networks.py:369-371) without
+// the separate element-wise add.  addend has the shape of the output.
+extern "C" int gg_upfirdn2d_add_f32(float* out, const float* in, const float* kernel, const float* addend, int major,
+                                    int in_h, int in_w, int kernel_h, int kernel_w, int up_x, int up_y, int down_x,
+                                    int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+  if (up_x < 1 || up_y < 1 || down_x < 1 || down_y < 1 || kernel_h < 1 || kernel_w < 1 || major < 0 || in_h < 0 ||
+      in_w < 0)
+    return gg::fail(-2, "upfirdn2d_add: bad arguments");
+  const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kernel_h + down_y) / down_y;
+  const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w + down_x) / down_x;
+  if (out_h <= 0 || out_w <= 0 || major == 0) return 0;
+  if (!out || !in || !kernel || !addend) return gg::fail(-2, "upfirdn2d_add: null pointer");
+  const long long total = (long long)major * out_h * out_w;
+  upfirdn2d_direct<float><<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(
+      out, in, kernel, total, in_h, in_w, out_h, out_w, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0,
+      addend);
+  return gg::launch_status("upfirdn2d_add");
+}
+
 extern "C" int gg_blur4_fused_f32(float* out, const float* in, const float* kernel, int n, int c, int in_h, int in_w,
                                   int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise,
                                   const float* noise_weight, const float* act_bias, const float* ref, float alpha,

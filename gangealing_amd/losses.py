@@ -97,7 +97,7 @@ class _LpipsTail(torch.autograd.Function):
         n2, c, h, w = feats.shape
         dfeats = torch.empty_like(feats)
         _lib.call('gg_lpips_tail_bwd_f32', dfeats, feats, lin if lin.numel() else None, grad_out.contiguous().float(),
-                  n2 // 2, c, h * w, ctx.eps)
+                  n2 // 2, c, h * w, ctx.eps, 0)
         return dfeats, None, None
 
 
@@ -105,6 +105,43 @@ def lpips_tail(feats, lin=None, eps=1e-10):
     if lin is not None:
         lin = lin.reshape(-1).contiguous().float()
     return _LpipsTail.apply(feats, lin, eps)
+
+
+class _LpipsTap(torch.autograd.Function):
+    """A feature tap of the trunk as ONE autograd node: returns (the features, passed on to the next stage, and this
+    tap's distance).  In the backward the tail's gradient is ADDED by the tail kernel into the gradient that came
+    back from the next stage, instead of being written to a second full-size tensor that autograd then adds."""
+
+    @staticmethod
+    def forward(ctx, feats, lin, eps):
+        feats = feats.contiguous()
+        n2, c, h, w = feats.shape
+        out = torch.empty(n2 // 2, dtype=torch.float32, device=feats.device)
+        _lib.call('gg_lpips_tail_fwd_f32', out, feats, lin, n2 // 2, c, h * w, eps)
+        ctx.save_for_backward(feats, lin if lin is not None else feats.new_empty(0))
+        ctx.eps = eps
+        return feats, out
+
+    @staticmethod
+    def backward(ctx, g_feats, g_out):
+        feats, lin = ctx.saved_tensors
+        n2, c, h, w = feats.shape
+        if g_out is None:
+            return g_feats, None, None
+        if g_feats is None:
+            df, acc = torch.empty_like(feats), 0
+        else:
+            df, acc = g_feats.contiguous(), 1              # produced for this node only: updated in place
+        _lib.call('gg_lpips_tail_bwd_f32', df, feats, lin if lin.numel() else None, g_out.contiguous().float(),
+                  n2 // 2, c, h * w, ctx.eps, acc)
+        return df, None, None
+
+
+def lpips_tap(feats, lin=None, eps=1e-10):
+    """-> (features for the next stage, per-sample distance of this tap)."""
+    if lin is not None:
+        lin = lin.reshape(-1).contiguous().float()
+    return _LpipsTap.apply(feats, lin, eps)
 
 
 VGG16_CFG = [(64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512)]
@@ -149,7 +186,11 @@ class vgg16(nn.Module):
                 if isinstance(m, nn.Conv2d):
                     fan_in = m.in_channels * 9
                     m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * (2.0 / fan_in) ** 0.5)
-                    m.bias.zero_()
+                    # a small positive bias keeps some channels active at every pixel: with all-zero biases a random
+                    # trunk produces pixels whose feature vector is (almost) exactly zero, where the perceptual
+                    # distance's x / (|x| + 1e-10) has gradients of order 1e10 .. 1e20 (lpips.py:26-28) - enough to
+                    # overflow Adam's second moment in float32 within a few dozen iterations of a synthetic run
+                    m.bias.fill_(0.1)
         if pretrained_weights is not None:
             self.load_features_state_dict(torch.load(pretrained_weights, map_location='cpu'), strict=True)
         elif pretrained:
@@ -178,7 +219,9 @@ class vgg16(nn.Module):
         self.weights_loaded = True
         return result
 
-    def forward(self, x):
+    def forward(self, x, tap=None):
+        """tap: optional callable (slice index, features) -> (features, value); when given the trunk returns the list
+        of values instead of the list of feature maps (LPIPS' fused per-tap distance)."""
         feats = []
         for si in range(5):
             for mod in getattr(self, f'slice{si + 1}'):
@@ -190,7 +233,11 @@ class vgg16(nn.Module):
                 elif isinstance(mod, nn.MaxPool2d):
                     x = F.max_pool2d(x, 2, 2)
                 # nn.ReLU: applied in the convolution above
-            feats.append(x)
+            if tap is not None:
+                x, val = tap(si, x)
+                feats.append(val)
+            else:
+                feats.append(x)
         return feats
 
 
@@ -260,14 +307,21 @@ class LPIPS(nn.Module):
         x = torch.cat([in0, in1], 0)                      # one batched pass for both images
         if self.version == '0.1':
             x = self.scaling_layer(x)
-        feats = self.net(x)
-        res = []
+        def lin_of(kk):
+            if not self.lpips:
+                return None
+            if self.training and any(isinstance(m, nn.Dropout) for m in self.lins[kk].model):
+                raise NotImplementedError('LPIPS lin layers with active dropout (training mode) are not fused')
+            return self.lins[kk].model[-1].weight
+
+        if x.dtype == torch.float32 and not ({'lpips_tail', 'lpips_tap'} & conv_mfma.DISABLED):
+            res = [v.view(n, 1, 1, 1) for v in self.net(x, tap=lambda kk, f: lpips_tap(f, lin_of(kk)))]
+            feats = []
+        else:
+            feats = self.net(x)
+            res = []
         for kk, f in enumerate(feats):
-            lin = None
-            if self.lpips:
-                if self.training and any(isinstance(m, nn.Dropout) for m in self.lins[kk].model):
-                    raise NotImplementedError('LPIPS lin layers with active dropout (training mode) are not fused')
-                lin = self.lins[kk].model[-1].weight
+            lin = lin_of(kk)
             if f.dtype == torch.float32 and 'lpips_tail' not in conv_mfma.DISABLED:
                 res.append(lpips_tail(f, lin).view(n, 1, 1, 1))
                 continue

@@ -34,9 +34,12 @@ PROFILER = None
 #   'bf16x3' / 'bf16x6'  bf16 matrix pipe with 2 / 3 bf16 limbs per fp32 operand (3 / 6 MFMAs per tile step,
 #            fp32 accumulation): ~2^-16 / ~2^-23 relative error per product.  Layers whose input-channel
 #            count is not a multiple of 32 (3-channel stems) or with <= 32 outputs stay on the fp32 kernel.
+#   'bf16'   one bf16 limb per operand (one MFMA per tile step, fp32 accumulation, fp32 activations in HBM): plain
+#            bf16 matrix arithmetic, ~2^-9 relative error per product - the arithmetic BASELINE.json's benchmark
+#            configuration names ("bf16").  Not a parity mode: activations agree with the reference to ~1e-2.
 import os as _os
 PRECISION = _os.environ.get('GANGEALING_CONV_PRECISION', 'fp32')
-_LIMBS = {'fp32': 0, 'bf16x3': 2, 'bf16x6': 3}
+_LIMBS = {'fp32': 0, 'bf16': 1, 'bf16x3': 2, 'bf16x6': 3}
 
 
 def set_precision(mode):
@@ -140,6 +143,15 @@ def repack_trainable():
         ent[1] = ent[0].weight._version
 
 
+def mark_trainable_packs_current():
+    """After a captured graph replayed the optimizer + re-pack launches: the registered packs hold the current
+    parameter values again; record the parameters' (host-bumped) version counters."""
+    reg = TRAINABLE_PACKS
+    if reg is not None:
+        for ent in reg.entries.values():
+            ent[1] = ent[0].weight._version
+
+
 def packed(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0):
     """PackedWeight for `weight`; weights that do not require grad (frozen VGG / generator) keep their
     packs across steps, keyed by storage + version so an in-place update invalidates them."""
@@ -194,7 +206,7 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
                 # + the 256-pixel-tile rule): the generator's style-scaled 3x3 stride-1 layers that fill the chip
                 tiles256 = (batch * oh * ow + 255) // 256 * ((cout_g + 127) // 128) * groups
                 pow2 = ow >= 16 and (ow & (ow - 1)) == 0
-                if (limbs == 2 and stride == 1 and pad == 1 and in_scale is not None and pow2 and tiles256 >= 512
+                if (limbs in (1, 2) and stride == 1 and pad == 1 and in_scale is not None and pow2 and tiles256 >= 512
                         and oh % (256 // min(ow, 64)) == 0):
                     prof = PROFILER
                 # bf16x6: the same layers run conv3x3_patch_kernel<3, true, 128>
@@ -509,7 +521,8 @@ class _ModulatedConv(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate, demod_pre=None):
+    def forward(ctx, x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate, demod_pre=None, bias=None):
+        """bias: (Cout,) frozen per-channel bias added in the convolution's epilogue (ToRGB's bias, networks.py:366)."""
         x = x.contiguous()
         style = style.contiguous()
         n, cin, h, w = x.shape
@@ -518,9 +531,9 @@ class _ModulatedConv(Function):
         if demodulate:
             demod = demod_pre if demod_pre is not None else torch.rsqrt((style * style) @ wsq.t() + 1e-8)
         if upsample:
-            y = conv_forward(x, wmat_fwd, n, 1, cin, cout, k, 2, 0, 1, in_scale=style, out_scale=demod)
+            y = conv_forward(x, wmat_fwd, n, 1, cin, cout, k, 2, 0, 1, in_scale=style, out_scale=demod, bias=bias)
         else:
-            y = conv_forward(x, wmat_fwd, n, 1, cin, cout, k, 1, k // 2, 0, in_scale=style, out_scale=demod)
+            y = conv_forward(x, wmat_fwd, n, 1, cin, cout, k, 1, k // 2, 0, in_scale=style, out_scale=demod, bias=bias)
         ctx.save_for_backward(x, style, demod if demod is not None else style.new_empty(0), y, wsq)
         ctx.wmat_bwd = wmat_bwd
         ctx.conf = (k, upsample, demodulate)
@@ -557,19 +570,20 @@ class _ModulatedConv(Function):
                 dx = dxt * style.view(n, cin, 1, 1) if ctx.needs_input_grad[0] else None
             else:
                 dx = dxt
-        return dx, dstyle, None, None, None, None, None, None, None
+        return dx, dstyle, None, None, None, None, None, None, None, None
 
 
 def masked_dgrad(dy, y_act, alpha, gain, wmat_bwd, n, cin, cout, h, w, in_scale=None, out_scale=None):
     """Data gradient of a 3x3 conv + leaky-ReLU layer with the activation's backward applied while the gradient is
     gathered (gg_conv3x3_masked_dgrad_f32): no separate masked-gradient tensor.  `cin` = reduction channels (the
     layer's output channels), `cout` = the layer's input channels.  None when the shape is not served."""
-    if _LIMBS[PRECISION] != 2 or 'mask_dgrad' in DISABLED or not isinstance(wmat_bwd, PackedWeight) or \
+    limbs = _LIMBS[PRECISION]
+    if limbs not in (1, 2) or 'mask_dgrad' in DISABLED or not isinstance(wmat_bwd, PackedWeight) or \
             not wmat_bwd.split_ok():
         return None
-    wbuf, stride_l = wmat_bwd.split(2)
+    wbuf, stride_l = wmat_bwd.split(limbs)
     dx = torch.empty((n, cout, h, w), dtype=torch.float32, device=dy.device)
-    rc = _lib.call('gg_conv3x3_masked_dgrad_f32', dx, dy, y_act, alpha, gain, wbuf, stride_l, 2, in_scale, out_scale,
+    rc = _lib.call('gg_conv3x3_masked_dgrad_f32', dx, dy, y_act, alpha, gain, wbuf, stride_l, limbs, in_scale, out_scale,
                    n, cin, cout, h, w, allow=(_lib.NOT_SERVED,))
     return dx if rc == 0 else None
 
@@ -623,7 +637,7 @@ class _StyledConvToRGB(Function):
 
     @staticmethod
     def forward(ctx, x, style, wmat_fwd, wmat_bwd, wsq, demodulate, noise, noise_weight, act_bias, alpha, gain,
-                demod_pre, rgb_style, rgb_wmat, rgb_weight, rgb_scale):
+                demod_pre, rgb_style, rgb_wmat, rgb_weight, rgb_scale, rgb_bias=None):
         x = x.contiguous()
         style = style.contiguous()
         n, cin, h, w = x.shape
@@ -634,7 +648,7 @@ class _StyledConvToRGB(Function):
         y = conv_forward(x, wmat_fwd, n, 1, cin, cout, 3, 1, 1, 0, in_scale=style, out_scale=demod,
                          act=(noise.contiguous(), noise_weight.contiguous(), act_bias.contiguous(), alpha, gain))
         rgb_style = rgb_style.contiguous()
-        rgb = conv_forward(y, rgb_wmat, n, 1, cout, 3, 1, 1, 0, 0, in_scale=rgb_style)
+        rgb = conv_forward(y, rgb_wmat, n, 1, cout, 3, 1, 1, 0, 0, in_scale=rgb_style, bias=rgb_bias)
         ctx.save_for_backward(style, demod if demod is not None else style.new_empty(0), y, rgb_style, rgb_weight)
         ctx.wmat_bwd = wmat_bwd
         ctx.conf = (demodulate, alpha, gain, cin, rgb_scale)
@@ -645,7 +659,7 @@ class _StyledConvToRGB(Function):
         style, demod, y, rgb_style, rgb_weight = ctx.saved_tensors
         demodulate, alpha, gain, cin, rgb_scale = ctx.conf
         if not ctx.needs_input_grad[0]:
-            return (None,) * 16
+            return (None,) * 17
         n, cout, h, w = y.shape
         if gy is None:
             g = torch.zeros_like(y)
@@ -659,14 +673,14 @@ class _StyledConvToRGB(Function):
             _lib.call('gg_fused_lrelu_bwd_f32', gm, None, g, y, alpha, gain, n, cout, h * w)
             dx = conv_forward(gm, ctx.wmat_bwd, n, 1, cout, cin, 3, 1, 1, 0, in_scale=demod if demodulate else None,
                               out_scale=style)
-        return (dx,) + (None,) * 15
+        return (dx,) + (None,) * 16
 
 
 def styled_conv_torgb(x, style, wmat_fwd, wmat_bwd, wsq, demodulate, act, demod, rgb_style, rgb_wmat, rgb_weight,
-                      rgb_scale):
+                      rgb_scale, rgb_bias=None):
     noise, noise_weight, act_bias, alpha, gain = act
     return _StyledConvToRGB.apply(x, style, wmat_fwd, wmat_bwd, wsq, demodulate, noise, noise_weight, act_bias, alpha,
-                                  gain, demod, rgb_style, rgb_wmat, rgb_weight, float(rgb_scale))
+                                  gain, demod, rgb_style, rgb_wmat, rgb_weight, float(rgb_scale), rgb_bias)
 
 
 def style_demod(latent, weight, bias, w_scale, b_scale, wsq=None, eps=1e-8):
@@ -688,7 +702,8 @@ def style_demod(latent, weight, bias, w_scale, b_scale, wsq=None, eps=1e-8):
     return style, demod
 
 
-def modulated_conv2d(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample=False, demodulate=True, act=None, demod=None):
+def modulated_conv2d(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample=False, demodulate=True, act=None, demod=None,
+                     bias=None):
     """act = (noise, noise_weight, act_bias, alpha, gain) fuses the StyledConv tail (3x3, no upsampling, and no
     gradient wanted for style / noise weight / bias).  demod: precomputed demodulation (style_demod)."""
     if act is not None:
@@ -697,4 +712,94 @@ def modulated_conv2d(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample=False, demod
             raise NotImplementedError('modulated_conv2d: fused activation not applicable to this layer')
         return _ModulatedConvAct.apply(x, style, wmat_fwd, wmat_bwd, wsq, demodulate, noise, noise_weight, act_bias,
                                        alpha, gain, demod)
-    return _ModulatedConv.apply(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate, demod)
+    if bias is not None and bias.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError('modulated_conv2d: the epilogue bias is for frozen layers')
+    return _ModulatedConv.apply(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate, demod, bias)
+
+
+class _AddScale(Function):
+    """(a + b) * scale in one pass (ResBlock's residual merge, networks.py:392-393); both inputs receive g * scale."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        _lib.call('gg_add_scale_f32', out, a, b, scale, a.numel())
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = g * ctx.scale
+        return gs, gs, None
+
+
+def add_scale(a, b, scale):
+    if a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32 or 'add_scale' in DISABLED:
+        return (a + b) * scale
+    return _AddScale.apply(a, b, float(scale))
+
+
+class StyleBank:
+    """Job tables for gg_style_bank_f32: the modulation (+ demodulation) vectors of a list of frozen layers in two
+    launches.  entries: [(slot, mod_weight (cin, D), mod_bias (cin,) or None, w_scale, b_scale, wsq (cout, cin) or None,
+    eps)].  `run(latent)` -> [(style (N, cin), demod (N, cout) or None)] as views of one freshly allocated buffer."""
+
+    def __init__(self, entries, device):
+        import numpy as np
+        dt = np.dtype([('m', '<u8'), ('bias', '<u8'), ('out_off', '<i8'), ('in_off', '<i8'), ('kdim', '<i4'),
+                       ('rows', '<i4'), ('scale', '<f4'), ('bias_scale', '<f4'), ('eps', '<f4'), ('pad', '<i4')])
+        assert dt.itemsize == 56
+        self.keep = entries                      # keeps the weight tensors (and their addresses) alive
+        self.layout = []                         # per entry: (style offset, cin, demod offset or None, cout)
+        style_rows, demod_rows = [], []
+        off = 0                                  # offsets per sample; multiplied by N at run time (jobs are per N)
+        for slot, w, b, w_scale, b_scale, wsq, eps in entries:
+            cin, dim = w.shape
+            if dim > 512 or cin > 512:
+                raise ValueError('StyleBank: reduction lengths up to 512')
+            s_off = off
+            off += cin
+            d_off = None
+            if wsq is not None:
+                d_off = off
+                off += wsq.shape[0]
+            self.layout.append((s_off, cin, d_off, None if wsq is None else wsq.shape[0]))
+            style_rows.append((w.data_ptr(), 0 if b is None else b.data_ptr(), s_off, slot, dim, cin, w_scale, b_scale,
+                               0.0, 0))
+            if wsq is not None:
+                demod_rows.append((wsq.data_ptr(), 0, d_off, s_off, cin, wsq.shape[0], 1.0, 0.0, eps, 0))
+        self.per_sample = off
+        self.dt, self.device = dt, device
+        self.style_rows, self.demod_rows = style_rows, demod_rows
+        self.max_style = max(r[5] for r in style_rows)
+        self.max_demod = max((r[5] for r in demod_rows), default=0)
+        self.tables = {}                         # batch -> (style jobs, demod jobs) device tensors
+
+    def _tables(self, n):
+        import numpy as np
+        t = self.tables.get(n)
+        if t is None:
+            def build(rows, in_is_offset):
+                if not rows:
+                    return None
+                arr = np.array([(m, b, o * n, (i * n if in_is_offset else i), k, r, sc, bs, eps, pad)
+                                for (m, b, o, i, k, r, sc, bs, eps, pad) in rows], dtype=self.dt)
+                return torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).to(self.device)
+            t = self.tables[n] = (build(self.style_rows, False), build(self.demod_rows, True))
+        return t
+
+    def run(self, latent):
+        """latent: (N, n_latent, D) contiguous float32."""
+        n, n_latent, dim = latent.shape
+        sj, dj = self._tables(n)
+        out = torch.empty(self.per_sample * n, dtype=torch.float32, device=latent.device)
+        _lib.call('gg_style_bank_f32', out, latent, n_latent * dim, dim, sj, len(self.style_rows), self.max_style, dj,
+                  len(self.demod_rows), self.max_demod, n)
+        res = []
+        for s_off, cin, d_off, cout in self.layout:
+            style = out[s_off * n:(s_off + cin) * n].view(n, cin)
+            demod = None if d_off is None else out[d_off * n:(d_off + cout) * n].view(n, cout)
+            res.append((style, demod))
+        return res
+

@@ -73,6 +73,44 @@ class UpFirDn2d(Function):
         return grad_input, None, None, None, None
 
 
+class UpFirDn2dAdd(Function):
+    """upfirdn2d(input) + addend in one kernel (gg_upfirdn2d_add_f32): ToRGB's `out + self.upsample(skip)`
+    (networks.py:369-371).  The addend's gradient is the incoming gradient itself."""
+
+    @staticmethod
+    def forward(ctx, input, kernel, up, down, pad, addend):
+        px0, px1, py0, py1 = pad
+        kh, kw = kernel.shape
+        n, c, in_h, in_w = input.shape
+        out_h, out_w = _out_size(in_h, in_w, kh, kw, up, up, down, down, px0, px1, py0, py1)
+        if tuple(addend.shape) != (n, c, out_h, out_w):
+            raise ValueError(f'upfirdn2d_add: addend {tuple(addend.shape)} vs output {(n, c, out_h, out_w)}')
+        ctx.save_for_backward(kernel)
+        ctx.conf = (up, down)
+        ctx.g_pad = (kw - px0 - 1, in_w * up - out_w * down + px0 - up + 1,
+                     kh - py0 - 1, in_h * up - out_h * down + py0 - up + 1)
+        out = torch.empty_like(addend, memory_format=torch.contiguous_format)
+        _lib.call('gg_upfirdn2d_add_f32', out, input.contiguous(), kernel.to(input.dtype).contiguous(),
+                  addend.contiguous(), n * c, in_h, in_w, kh, kw, up, up, down, down, px0, px1, py0, py1)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (kernel,) = ctx.saved_tensors
+        up, down = ctx.conf
+        grad_input = None
+        if ctx.needs_input_grad[0]:
+            grad_input = UpFirDn2d.apply(grad_output, _flipped(kernel), (down, down), (up, up), ctx.g_pad)
+        return grad_input, None, None, None, None, (grad_output if ctx.needs_input_grad[5] else None)
+
+
+def upfirdn2d_add(input, kernel, addend, up=1, down=1, pad=(0, 0)):
+    """upfirdn2d(input, kernel, up, down, pad) + addend (float32)."""
+    if input.dtype != torch.float32 or addend.dtype != torch.float32:
+        return upfirdn2d(input, kernel, up, down, pad) + addend
+    return UpFirDn2dAdd.apply(input, kernel, up, down, (pad[0], pad[1], pad[0], pad[1]), addend)
+
+
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     if input.device.type != 'cuda':
         raise _lib.HipLibraryError('upfirdn2d: HIP tensors only (the CPU restatement is oracle/np_ops.upfirdn2d)')

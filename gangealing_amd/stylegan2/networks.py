@@ -23,7 +23,7 @@ from torch.nn import functional as F
 
 from ..op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from ..op.fused_act import noise_bias_leaky_relu
-from ..op.upfirdn2d import blur_noise_act, blur_noise_act_ok
+from ..op.upfirdn2d import blur_noise_act, blur_noise_act_ok, upfirdn2d_add
 from ..op import conv_mfma
 
 
@@ -195,11 +195,22 @@ class ModulatedConv2d(nn.Module):
                                          wsq if self.demodulate else None, self.eps)
         return mod(style), None
 
-    def forward(self, input, style, act=None):
+    def bank_entry(self, slot):
+        """This layer's row of a conv_mfma.StyleBank (modulation + demodulation from W+ slot `slot`)."""
+        _, _, wsq = self._weights()
+        mod = self.modulation
+        return (slot, mod.weight.detach(), None if mod.bias is None else mod.bias.detach(), mod.scale, mod.lr_mul,
+                wsq if self.demodulate else None, self.eps)
+
+    def forward(self, input, style, act=None, pre=None, bias=None):
         """act = (noise, noise_weight, bias, negative_slope, scale): fuse StyledConv's NoiseInjection +
-        FusedLeakyReLU into the convolution (callers check `can_fuse_act` first)."""
+        FusedLeakyReLU into the convolution (callers check `can_fuse_act` first).  pre = (style vector, demodulation)
+        already computed for this layer (Generator's style bank); bias: frozen per-channel bias for the epilogue."""
         wmat_fwd, wmat_bwd, wsq = self._weights()
-        style, demod = self.modulate(input, style, wsq)
+        if pre is not None:
+            style, demod = pre
+        else:
+            style, demod = self.modulate(input, style, wsq)
         if self.upsample and act is not None:
             # up-sampling layer: the activation follows the blur, so it rides in the blur kernel instead
             out = conv_mfma.modulated_conv2d(input, style, wmat_fwd, wmat_bwd, wsq, self.kernel_size,
@@ -207,7 +218,8 @@ class ModulatedConv2d(nn.Module):
             noise, noise_weight, bias, negative_slope, scale = act
             return blur_noise_act(out, self.blur.kernel, self.blur.pad, noise, noise_weight, bias, negative_slope, scale)
         out = conv_mfma.modulated_conv2d(input, style, wmat_fwd, wmat_bwd, wsq, self.kernel_size,
-                                         upsample=self.upsample, demodulate=self.demodulate, act=act, demod=demod)
+                                         upsample=self.upsample, demodulate=self.demodulate, act=act, demod=demod,
+                                         bias=bias)
         if self.upsample:
             out = self.blur(out)
         return out
@@ -262,7 +274,7 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None):
+    def forward(self, input, style, noise=None, pre=None):
         if self.conv.can_fuse_act(input, style, self.noise.weight, self.activate.bias):
             n, _, h, w = input.shape
             if self.conv.upsample:
@@ -272,8 +284,8 @@ class StyledConv(nn.Module):
             elif noise.shape[0] != n:
                 noise = noise.expand(n, -1, -1, -1)
             return self.conv(input, style, act=(noise.type(input.dtype), self.noise.weight, self.activate.bias,
-                                                self.activate.negative_slope, self.activate.scale))
-        out = self.conv(input, style)
+                                                self.activate.negative_slope, self.activate.scale), pre=pre)
+        out = self.conv(input, style, pre=pre)
         n, _, h, w = out.shape
         if out.dtype == torch.float32 and (h * w) % 4 == 0:
             # NoiseInjection + FusedLeakyReLU in one pass over the activation (csrc/fused_bias_act.hip)
@@ -287,7 +299,7 @@ class StyledConv(nn.Module):
         return self.activate(out)
 
 
-def styled_conv_with_rgb(styled, to_rgb, input, style, rgb_latent, noise=None):
+def styled_conv_with_rgb(styled, to_rgb, input, style, rgb_latent, noise=None, pre=None, pre_rgb=None):
     """StyledConv (no up-sampling) + the ToRGB convolution of the same resolution as ONE autograd node
     (conv_mfma._StyledConvToRGB); returns (activation, raw rgb) or None when the pair cannot be fused (a style that
     needs a gradient, trainable generator weights, shapes off the fused path)."""
@@ -304,14 +316,14 @@ def styled_conv_with_rgb(styled, to_rgb, input, style, rgb_latent, noise=None):
     elif noise.shape[0] != n:
         noise = noise.expand(n, -1, -1, -1)
     wmat_fwd, wmat_bwd, wsq = conv._weights()
-    s_c, demod = conv.modulate(input, style, wsq)
+    s_c, demod = pre if pre is not None else conv.modulate(input, style, wsq)
     rgb_fwd, _, _ = rgb_conv._weights()
-    s_rgb, _ = rgb_conv.modulate(input, rgb_latent, None)
+    s_rgb = pre_rgb[0] if pre_rgb is not None else rgb_conv.modulate(input, rgb_latent, None)[0]
     act = (noise.type(input.dtype), styled.noise.weight, styled.activate.bias, styled.activate.negative_slope,
            styled.activate.scale)
     w_rgb = rgb_conv.weight.detach().reshape(3, rgb_conv.in_channel).contiguous()
     return conv_mfma.styled_conv_torgb(input, s_c, wmat_fwd, wmat_bwd, wsq, conv.demodulate, act, demod, s_rgb, rgb_fwd,
-                                       w_rgb, rgb_conv.scale)
+                                       w_rgb, rgb_conv.scale, to_rgb.epilogue_bias())
 
 
 class ToRGB(nn.Module):
@@ -322,14 +334,27 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False, normalize=normalize)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
-    def forward(self, input, style, skip=None):
-        return self.finish(self.conv(input, style), skip)
+    def epilogue_bias(self):
+        """The bias as a (3,) vector for the 1x1 convolution's epilogue, or None when it needs a gradient (then
+        finish() adds it as the reference does) or the fusion is switched off."""
+        if 'torgb_bias' in conv_mfma.DISABLED or (self.bias.requires_grad and torch.is_grad_enabled()):
+            return None
+        return self.bias.detach().reshape(-1)
 
-    def finish(self, rgb, skip=None):
-        """bias + up-sampled skip connection around the raw modulated 1x1 convolution output."""
-        out = rgb + self.bias.type(rgb.dtype)
+    def forward(self, input, style, skip=None, pre=None):
+        bias = self.epilogue_bias() if input.dtype == torch.float32 else None
+        return self.finish(self.conv(input, style, pre=pre, bias=bias), skip, bias_done=bias is not None)
+
+    def finish(self, rgb, skip=None, bias_done=False):
+        """bias + up-sampled skip connection around the raw modulated 1x1 convolution output (networks.py:366-371);
+        the bias rides in the convolution's epilogue and the skip addition in the up-sampling kernel where possible."""
+        out = rgb if bias_done else rgb + self.bias.type(rgb.dtype)
         if skip is not None:
-            out = out.float() + self.upsample(skip)
+            up = self.upsample
+            if out.dtype == torch.float32 and skip.dtype == torch.float32 and 'torgb_bias' not in conv_mfma.DISABLED:
+                out = upfirdn2d_add(skip, up.kernel, out, up=up.factor, down=1, pad=up.pad)
+            else:
+                out = out.float() + up(skip)
         return out
 
 
@@ -372,7 +397,7 @@ class ResBlock(nn.Module):
 
     def forward(self, input):
         out = self.conv2(self.conv1(input))
-        return (out + self.skip(input)) / math.sqrt(2)
+        return conv_mfma.add_scale(out, self.skip(input), 1.0 / math.sqrt(2))
 
 
 CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
@@ -439,8 +464,11 @@ class Generator(nn.Module):
             if mapping_only:
                 return styles
         if noise is None:
-            noise = [None] * self.num_layers if randomize_noise else \
-                [getattr(self.noises, f'noise_{i}') for i in range(self.num_layers)]
+            if randomize_noise and 'noise_bank' not in conv_mfma.DISABLED:
+                noise = self._noise_bank(styles[0].shape[0], styles[0].device, styles[0].dtype)
+            else:
+                noise = [None] * self.num_layers if randomize_noise else \
+                    [getattr(self.noises, f'noise_{i}') for i in range(self.num_layers)]
         if truncation < 1:
             styles = [truncation_latent + truncation * (styles[0] - truncation_latent), styles[0]]
         if len(styles) < 2 or inject_index == self.n_latent:
@@ -454,20 +482,70 @@ class Generator(nn.Module):
             lat = [latent[:, j] if j < grad_latents else latent[:, j].detach() for j in range(self.n_latent)]
         else:
             lat = [latent[:, j] for j in range(self.n_latent)]
-        out = self.conv1(self.input(latent), lat[0], noise=noise[0])
-        skip = self.to_rgb1(out, lat[1])
+        first_free = 0
+        if latent.requires_grad and torch.is_grad_enabled():
+            first_free = self.n_latent if grad_latents is None else grad_latents
+        pre = self._styles(latent, first_free)          # layer -> (style, demodulation) for W+ slots >= first_free
+        out = self.conv1(self.input(latent), lat[0], noise=noise[0], pre=pre.get(self.conv1.conv))
+        skip = self.to_rgb1(out, lat[1], pre=pre.get(self.to_rgb1.conv))
         i = 1
         for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2],
                                                        self.to_rgbs):
-            out = conv_up(out, lat[i], noise=n_up)
+            out = conv_up(out, lat[i], noise=n_up, pre=pre.get(conv_up.conv))
             last = to_rgb is self.to_rgbs[-1]
             # every resolution but the last: the activation feeds ToRGB AND the next up-sampling layer -> one node
-            pair = None if last else styled_conv_with_rgb(conv, to_rgb, out, lat[i + 1], lat[i + 2], noise=n_conv)
+            pair = None if last else styled_conv_with_rgb(conv, to_rgb, out, lat[i + 1], lat[i + 2], noise=n_conv,
+                                                          pre=pre.get(conv.conv), pre_rgb=pre.get(to_rgb.conv))
             if pair is not None:
                 out, rgb = pair
-                skip = to_rgb.finish(rgb, skip)
+                skip = to_rgb.finish(rgb, skip, bias_done=to_rgb.epilogue_bias() is not None)
             else:
-                out = conv(out, lat[i + 1], noise=n_conv)
-                skip = to_rgb(out, lat[i + 2], skip)
+                out = conv(out, lat[i + 1], noise=n_conv, pre=pre.get(conv.conv))
+                skip = to_rgb(out, lat[i + 2], skip, pre=pre.get(to_rgb.conv))
             i += 2
         return (skip, latent) if return_latents else (skip, None)
+
+    def _layer_slots(self):
+        """[(ModulatedConv2d, W+ slot)] in execution order (networks.py:560-583)."""
+        order = [(self.conv1.conv, 0), (self.to_rgb1.conv, 1)]
+        i = 1
+        for conv_up, conv, to_rgb in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
+            order += [(conv_up.conv, i), (conv.conv, i + 1), (to_rgb.conv, i + 2)]
+            i += 2
+        return order
+
+    def _styles(self, latent, first_free):
+        """Modulation + demodulation vectors of every layer whose W+ slot needs no gradient (slot >= first_free), in
+        two launches (conv_mfma.StyleBank) instead of two per layer.  {} when the bank does not apply."""
+        if ('style_bank' in conv_mfma.DISABLED or 'style_demod' in conv_mfma.DISABLED or latent.dtype != torch.float32
+                or not latent.is_cuda or latent.dim() != 3 or first_free >= self.n_latent):
+            return {}
+        layers = [(m, slot) for m, slot in self._layer_slots() if slot >= first_free]
+        frozen = all(not (m.modulation.weight.requires_grad or m.weight.requires_grad or
+                          (m.modulation.bias is not None and m.modulation.bias.requires_grad)) for m, _ in layers)
+        if not layers or (torch.is_grad_enabled() and not frozen) or any(m.modulation.activation for m, _ in layers):
+            return {}
+        key = (latent.device,) + tuple((m.weight._version, m.modulation.weight._version, m.weight.data_ptr())
+                                       for m, _ in layers)
+        banks = self.__dict__.setdefault('_banks', {})           # one bank per first_free (pass 1: 0, pass 2: inject)
+        cache = banks.get(first_free)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                bank = conv_mfma.StyleBank([m.bank_entry(slot) for m, slot in layers], latent.device)
+            cache = banks[first_free] = (key, bank)
+        lat = latent.detach()
+        if not lat.is_contiguous():
+            lat = lat.contiguous()
+        vecs = cache[1].run(lat)
+        return {m: v for (m, _), v in zip(layers, vecs)}
+
+    def _noise_bank(self, batch, device, dtype):
+        """Fresh N(0,1) noise images for all layers from ONE generator launch (the reference draws one tensor per
+        layer, networks.py:294)."""
+        sizes = [2 ** ((i + 5) // 2) for i in range(self.num_layers)]
+        flat = torch.empty(batch * sum(r * r for r in sizes), device=device, dtype=dtype).normal_()
+        out, off = [], 0
+        for r in sizes:
+            out.append(flat[off:off + batch * r * r].view(batch, 1, r, r))
+            off += batch * r * r
+        return out

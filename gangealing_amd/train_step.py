@@ -125,13 +125,24 @@ class FlatArena:
         return groups[0]['lr']
 
 
-def adam_ema_step(arena, lr, ema_arena=None, ema_decay=0.0, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+def adam_hyper(lr, step, betas=(0.9, 0.999), grad_scale=1.0):
+    """The step-dependent scalars of the update: [lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale]."""
+    return [float(lr), 1.0 - betas[0] ** step, math.sqrt(1.0 - betas[1] ** step), float(grad_scale)]
+
+
+def adam_ema_step(arena, lr, ema_arena=None, ema_decay=0.0, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, hyper=None):
     """Adam over `arena` and (optionally) the EMA update of `ema_arena` (a FlatArena of the same layout) in one
-    streaming kernel."""
+    streaming kernel.  hyper: device tensor holding adam_hyper(...) - the launch then carries no step-dependent
+    argument and can be replayed from a captured graph (`lr` / `grad_scale` are ignored)."""
     arena.step_count += 1
-    _lib.call('gg_adam_ema_f32', arena.param, arena.exp_avg, arena.exp_avg_sq,
-              None if ema_arena is None else ema_arena.param, arena.grad, arena.numel,
-              lr, betas[0], betas[1], eps, arena.step_count, ema_decay, grad_scale)
+    if hyper is not None:
+        _lib.call('gg_adam_ema_dev_f32', arena.param, arena.exp_avg, arena.exp_avg_sq,
+                  None if ema_arena is None else ema_arena.param, arena.grad, arena.numel, hyper, betas[0], betas[1],
+                  eps, ema_decay)
+    else:
+        _lib.call('gg_adam_ema_f32', arena.param, arena.exp_avg, arena.exp_avg_sq,
+                  None if ema_arena is None else ema_arena.param, arena.grad, arena.numel,
+                  lr, betas[0], betas[1], eps, arena.step_count, ema_decay, grad_scale)
     # the kernel wrote through raw pointers: bump the version counters of the parameters themselves, so that
     # anything cached against the old values (weight packs, scaled EqualLinear weights) is recognised as stale
     arena.touch()
@@ -155,7 +166,8 @@ class GangealingTrainer:
                  stn_channel_multiplier=0.5, inject=5, ndirs=1, padding_mode='reflection', tv_weight=1000.0,
                  flow_identity_weight=1.0, stn_lr=1e-3, ll_lr=1e-2, sample_from_full_res=False, freeze_ll=False,
                  loss_fn='vgg_ssl', seed=0, perturb_heads=0.0, pipeline_update=None, anneal_psi=150000,
-                 anneal_fn='cosine', period=37500, decay=0.9, tm=2):
+                 anneal_fn='cosine', period=37500, decay=0.9, tm=2, perceptual_weights=None, use_graph=False,
+                 graph_warmup=3):
         self.device = device
         self._pending = None
         self.batch = batch
@@ -189,7 +201,7 @@ class GangealingTrainer:
         self.t_ema.requires_grad_(False)
         self.ll = DirectionInterpolator(None, ndirs, inject, self.generator.n_latent, num_heads,
                                         dim_latent=dim_latent).to(device)
-        self.loss_fn = get_perceptual_loss(loss_fn, device)
+        self.loss_fn = get_perceptual_loss(loss_fn, device, weights=perceptual_weights)
         self.resize_fake2stn = BilinearDownsample(gen_size // flow_size, 3).to(device) if gen_size > flow_size \
             else nn.Sequential()
         conv_mfma.enable_pack_registry()     # trainable conv weights: packs rebuilt once per step (repack_trainable)
@@ -205,6 +217,20 @@ class GangealingTrainer:
         # is a collective to hide
         self.pipeline_update = (world > 1) if pipeline_update is None else bool(pipeline_update)
         self.stn.register_forward_pre_hook(lambda module, inputs: self.flush())
+        # whole-iteration hipGraph (single process): after `graph_warmup` eager iterations the step - zeroing the
+        # gradient arenas, loss forward, backward, both optimizers, EMA, weight re-pack: ~900 launches - is captured
+        # once and replayed; psi and the optimizers' step-dependent scalars live in device memory and are refreshed
+        # by the host before every replay
+        self.use_graph = bool(use_graph)
+        if self.use_graph and world > 1:
+            raise NotImplementedError('use_graph: single-process only (the multi-GPU path keeps the pipelined eager step)')
+        self._graph = None
+        self._graph_calls = 0
+        self._graph_warmup = max(int(graph_warmup), 1)
+        self._psi_dev = torch.zeros((), dtype=torch.float32, device=device)
+        self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=device)        # [stn x4, ll x4]
+        self._cap_stream = None
+        self._hyper_ring = None
         # psi annealing + learning-rate schedules (train.py:206-207, 92-97, 129-132)
         self.anneal_psi, self.period = anneal_psi, period
         self.anneal_fn = get_psi_annealing_fn(anneal_fn)
@@ -279,6 +305,9 @@ class GangealingTrainer:
         right before the STN is next used (a forward pre-hook) - i.e. behind the next iteration's two generator
         passes, which do not read the STN.  Parameter values seen by every forward are exactly those of the
         un-pipelined order; call `flush()` before reading parameters from outside (checkpoints, evaluation)."""
+        if self.use_graph:
+            return self._graph_step(psi, self.stn_lr if stn_lr is None else stn_lr,
+                                    self.ll_lr if ll_lr is None else ll_lr)
         if self._pending is None:
             self.stn_arena.zero_grad()
         self.ll_arena.zero_grad()
@@ -300,6 +329,72 @@ class GangealingTrainer:
         else:
             self._apply_stn_update(scale, stn_lr)
         return parts
+
+    # ---- hipGraph path ------------------------------------------------------------------------------------------
+    def _graph_body(self):
+        """Everything of one iteration that runs on the GPU, with no step-dependent host scalar in any launch."""
+        self.stn_arena.grad.zero_()
+        self.ll_arena.grad.zero_()
+        total, parts = self.loss(self._psi_dev)
+        with conv_mfma.grad_slots():
+            total.backward()
+        if not self.freeze_ll:
+            adam_ema_step(self.ll_arena, 0.0, hyper=self._hyper_dev[4:8])
+        adam_ema_step(self.stn_arena, 0.0, self.ema_arena, self.ema_decay, hyper=self._hyper_dev[0:4])
+        conv_mfma.repack_trainable()
+        return parts
+
+    def _graph_step(self, psi, stn_lr, ll_lr):
+        # Everything of the graph path - the eager warm-up iterations, the capture, the per-iteration scalar uploads and
+        # the replays - runs on ONE dedicated stream; the caller's stream waits for it at the end of every call.
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream()
+        self._cap_stream.wait_stream(cur)
+        with torch.cuda.stream(self._cap_stream):
+            parts = self._graph_step_on_stream(psi, stn_lr, ll_lr)
+        cur.wait_stream(self._cap_stream)
+        return parts
+
+    def _graph_step_on_stream(self, psi, stn_lr, ll_lr):
+        # the scalars this iteration's launches read from device memory
+        vals = adam_hyper(stn_lr, self.stn_arena.step_count + 1) + adam_hyper(ll_lr, self.ll_arena.step_count + 1)
+        # pinned staging ring: the copy is asynchronous (no host sync per iteration); a slot is rewritten 16 iterations
+        # later, after its event shows the copy has been consumed
+        if self._hyper_ring is None:
+            self._hyper_ring = [[torch.zeros(9, dtype=torch.float32).pin_memory(), None] for _ in range(16)]
+        slot = self._hyper_ring[self._graph_calls % 16]
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0][:8] = torch.tensor(vals, dtype=torch.float32)
+        slot[0][8] = float(psi)
+        self._hyper_dev.copy_(slot[0][:8], non_blocking=True)
+        self._psi_dev.copy_(slot[0][8], non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        self._graph_calls += 1
+        if self._graph is None and self._graph_calls <= self._graph_warmup:
+            # eager iterations: every cache, workspace and library handle the capture must not create exists afterwards
+            self.stn_arena.zero_grad()           # (re-points .grad at the arenas)
+            self.ll_arena.zero_grad()
+            return self._graph_body()
+        if self._graph is None:
+            self._cap_stream.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            steps = (self.stn_arena.step_count, self.ll_arena.step_count)
+            with torch.cuda.graph(self._graph, stream=self._cap_stream):
+                self._graph_parts = self._graph_body()
+            self.stn_arena.step_count, self.ll_arena.step_count = steps       # the capture executed nothing
+        self._graph.replay()
+        # host-side bookkeeping of what the replay did on the device
+        self.stn_arena.step_count += 1
+        self.stn_arena.touch()
+        self.ema_arena.touch()
+        if not self.freeze_ll:
+            self.ll_arena.step_count += 1
+            self.ll_arena.touch()
+        conv_mfma.mark_trainable_packs_current()
+        return self._graph_parts
 
     def _apply_stn_update(self, scale, lr):
         adam_ema_step(self.stn_arena, lr, self.ema_arena, self.ema_decay, grad_scale=scale)

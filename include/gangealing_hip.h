@@ -78,6 +78,14 @@ int gg_upfirdn2d_f64(double* out, const double* in, const double* kernel,
                      int major, int in_h, int in_w, int kernel_h, int kernel_w,
                      int up_x, int up_y, int down_x, int down_y,
                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+/* upfirdn2d(in) + addend (addend shaped like the output) in one pass: ToRGB's `out + self.upsample(skip)`
+ * (networks.py:369-371) without the separate element-wise add. */
+int gg_upfirdn2d_add_f32(float* out, const float* in, const float* kernel, const float* addend, int major, int in_h,
+                         int in_w, int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                         int pad_x1, int pad_y0, int pad_y1, void* stream);
+/* out = (a + b) * scale over n floats: ResBlock's residual merge (out + skip) / sqrt(2) (networks.py:392-393). */
+int gg_add_scale_f32(float* out, const float* a, const float* b, float scale, long long n, void* stream);
+
 /* 4x4 FIR blur (up = down = 1; upfirdn2d.py:147-158 with a 4x4 kernel) with the neighbouring element-wise
  * stage of the generator's up-sampling StyledConv fused in (networks.py:268-298, 344-350):
  *   noise != NULL: out = lrelu(blur(in) + noise_weight[0] * noise[n,0] + act_bias[c], alpha) * gain   (forward)
@@ -303,6 +311,15 @@ int gg_conv3x3_masked_wgrad_f32(float* dw, float* dbias, const float* x, const f
 int gg_style_demod_f32(float* style, float* demod, const float* latent, long long lat_stride, const float* w,
                        const float* b, const float* wsq, int n, int style_dim, int cin, int cout, float w_scale,
                        float b_scale, float eps, void* stream);
+/* The modulation vectors of many frozen layers in two launches (networks.py:214-216,244-249 for every layer of a
+ * generator pass).  style_jobs / demod_jobs: device arrays of 56-byte records {const float* m; const float* bias;
+ * int64 out_off; int64 in_off; int32 kdim, rows; float scale, bias_scale, eps; int32 pad}: outputs go to
+ * out_base + out_off as (n, rows); a style job reads latent + in_off * slot_stride (sample stride
+ * lat_sample_stride), a demodulation job reads the style at out_base + in_off.  kdim <= 512. */
+int gg_style_bank_f32(float* out_base, const float* latent, long long lat_sample_stride, int slot_stride,
+                      const void* style_jobs, int n_style_jobs, int max_style_rows, const void* demod_jobs,
+                      int n_demod_jobs, int max_demod_rows, int n, void* stream);
+
 /* Perceptual-loss tail of one feature tap (reference models/losses/lpips.py:26-28, 190-199):
  * feats (2n, c, hw): samples [0,n) belong to image 0, [n,2n) to image 1.  With u = f / (sqrt(sum_c f^2) + eps):
  *   out[s] = mean_pixels sum_c lin[c] * (u0 - u1)^2     (lin NULL = all ones: the lpips=False / vgg_ssl branch)
@@ -310,7 +327,7 @@ int gg_style_demod_f32(float* style, float* demod, const float* latent, long lon
 int gg_lpips_tail_fwd_f32(float* out, const float* feats, const float* lin, int n, int c, long long hw, float eps,
                           void* stream);
 int gg_lpips_tail_bwd_f32(float* dfeats, const float* feats, const float* lin, const float* grad_out, int n, int c,
-                          long long hw, float eps, void* stream);
+                          long long hw, float eps, int accumulate, void* stream);
 /* Data gradient of a modulated 1x1 ToRGB convolution (networks.py:352-372, no demodulation) ADDED into an existing
  * gradient:  g[n,c,p] += sum_{k<3} w[k,c] * wscale * style[n,c] * grad_rgb[n,k,p].
  * g (n,c,hw) accumulates, grad_rgb (n,3,hw), w (3,c) = the ToRGB weight, style (n,c) its modulation; hw % 4 == 0,
@@ -329,6 +346,13 @@ int gg_plane_dot_f32(float* out, const float* a, const float* b, int planes, lon
 int gg_adam_ema_f32(float* param, float* exp_avg, float* exp_avg_sq, float* ema, const float* grad,
                     long long numel, float lr, float beta1, float beta2, float eps, int step,
                     float ema_decay, float grad_scale, void* stream);
+/* The same update with the step-dependent scalars in DEVICE memory: hyper = {lr, 1 - beta1^t, sqrt(1 - beta2^t),
+ * grad_scale}.  Lets a captured hipGraph of the whole training step be replayed while the host only refreshes four
+ * floats per step (learning-rate schedule of train.py:129-132, Adam's bias corrections). */
+int gg_adam_ema_dev_f32(float* param, float* exp_avg, float* exp_avg_sq, float* ema, const float* grad,
+                        long long numel, const float* hyper, float beta1, float beta2, float eps, float ema_decay,
+                        void* stream);
+
 
 #ifdef __cplusplus
 }

@@ -429,30 +429,9 @@ def gen_train_step():
                                        scale_rules=[list(r) for r in rules], grad_norms=gnorm))])
 
 
-def gen_splat_selfcheck():
-    """splat2d has no runnable reference here (no CPU path: functional.py:54-55; the CUDA source
-    does not build against torch>=1.11: splat_gpu.c:7).  The fixture stores inputs and the numpy
-    restatement's output so that the GPU test has a committed, hash-stable target; parity for
-    this op is pinned only to the restated source lines ("parity unpinned" - DESIGN.md)."""
-    from oracle import np_ops
-    cases = []
-    for ci, (n, c, h, w, p, sig, soft) in enumerate([
-        (2, 3, 16, 20, 17, 1.3, False), (1, 1, 12, 12, 1, 0.3, True), (2, 2, 24, 24, 200, 3.0, False),
-        (1, 3, 8, 8, 40, 1.2, True),
-    ]):
-        rs = np.random.RandomState(100 + ci)
-        coords = (rs.rand(n, p, 2) * [w + 4, h + 4] - 2).astype(np.float32)   # some out of bounds
-        coords[:, 0] = [0.0, 0.0]                                               # on the border
-        if p > 2:
-            coords[:, 1] = coords[:, 2]                                         # duplicates
-        values = rs.randn(n, p, c).astype(np.float32)
-        sigma = np.full((n,), sig, dtype=np.float32)
-        inp = np.zeros((n, c, h, w), dtype=np.float32) if ci != 3 else rs.randn(n, c, h, w).astype(np.float32)
-        out = np_ops.splat2d(inp, coords, values, sigma, soft)
-        cases.append(dict(input=inp, coords=coords, values=values, sigma=sigma, out=out,
-                          meta=dict(soft_normalize=soft, source='oracle-restatement')))
-    save('splat2d', cases)
-
+# splat2d: tests/golden/splat2d.npz is written by oracle/make_golden_splat.py ON A GPU BOX from the reference's own
+# kernel (oracle/_ref/libsplat_ref.so = utils/splat2d_cuda/src/splat_gpu_impl.cu compiled unmodified by oracle/Makefile);
+# this script never touches it.
 
 
 # ---------------------------------------------------------------------------------------------
@@ -645,7 +624,7 @@ if __name__ == '__main__':
     only = sys.argv[1:]
     gens = dict(upfirdn2d=gen_upfirdn2d, fused_act=gen_fused_act, mipmap_warp=gen_mipmap_warp, heads=gen_heads,
                 misc=gen_misc, modconv=gen_modconv, generator=gen_generator, stn=gen_stn,
-                train_step=gen_train_step, splat=gen_splat_selfcheck, cluster_classifier=gen_cluster_classifier,
+                train_step=gen_train_step, cluster_classifier=gen_cluster_classifier,
                 point_transfer=gen_point_transfer, warp_indices=gen_warp_indices, annealing=gen_annealing)
     for name, fn in gens.items():
         if only and name not in only:

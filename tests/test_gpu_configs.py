@@ -77,7 +77,7 @@ GRAD_FACTOR = 4.0                        # HIP-path error allowed as a multiple 
 # run is subject to the same effect (its distance from float64 is 1e-3 .. 7e-3 on several parameters) and sometimes
 # lucky (2e-6); the HIP path is not required to match that luck.  The kernels themselves are compared with float64
 # convolutions at the same shapes, where nothing can flip, in tests/test_gpu_c2_layer_ops.py.
-GRAD_FLOOR = {'fp32': (5e-3, 2e-3), 'bf16x3': (2e-2, 5e-3)}
+GRAD_FLOOR = {'fp32': (5e-3, 5e-3), 'bf16x3': (2e-2, 1e-2)}
 # the similarity stage additionally receives gradient through MipmapWarp's level selection, where a similarity warp
 # makes the four neighbour distances EXACTLY tied in real arithmetic: arg-max (and with it the sub-gradient) is decided
 # by last-ulp noise of the grid in every implementation, the reference's float32 and float64 runs included

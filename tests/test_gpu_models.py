@@ -512,3 +512,46 @@ def test_trainer_schedule_and_checkpoint_round_trip(cuda):
     assert abs(float(pa['p']) - float(pb['p'])) <= 2e-2 * abs(float(pa['p']))
     da, db = (a.stn_arena.param - before).double(), (b.stn_arena.param - before).double()
     assert float((da * db).sum() / (da.norm() * db.norm())) > 0.7 and 0.7 < float(da.norm() / db.norm()) < 1.4
+
+
+def test_graph_replay_trainer(cuda):
+    """use_graph: the whole iteration captured in a hipGraph after the eager warm-up iterations.  Replays must train
+    (finite losses, parameters move, EMA follows), the device-resident scalars must be live (a zero learning rate
+    freezes the parameters, psi reaches the latent mix) and the host-side step counters / version counters must track
+    what the replays did."""
+    from gangealing_amd.train_step import GangealingTrainer
+    kw = dict(gen_size=64, flow_size=64, batch=2, transform=('similarity', 'flow'), inject=3, ndirs=2,
+              perturb_heads=0.02, seed=13)
+    tr = GangealingTrainer(cuda, use_graph=True, graph_warmup=2, **kw)
+    p0 = tr.stn_arena.param.clone()
+    losses = []
+    for i in range(6):
+        parts = tr.step(psi=0.5)
+        losses.append(float(parts['p']))
+        assert (tr._graph is None) == (i < 2)
+    assert all(np.isfinite(losses)) and tr.stn_arena.step_count == 6 and tr.ll_arena.step_count == 6
+    p6 = tr.stn_arena.param.clone()
+    assert float((p6 - p0).abs().max()) > 1e-3
+    v = [p._version for p in tr.stn.parameters()][:3]
+    # zero learning rate: the replay reads lr from device memory -> parameters stay, moments still update
+    m_before = tr.stn_arena.exp_avg.clone()
+    tr.step(psi=0.5, stn_lr=0.0, ll_lr=0.0)
+    assert torch.equal(tr.stn_arena.param, p6) and not torch.equal(tr.stn_arena.exp_avg, m_before)
+    assert [p._version for p in tr.stn.parameters()][:3] != v
+    # psi is read from device memory too: psi = 1 makes the target the unaligned sample's own latent, psi = 0 the
+    # mean latent - different losses from the same replayed graph and the same random stream
+    torch.manual_seed(1)
+    a = float(tr.step(psi=1.0, stn_lr=0.0, ll_lr=0.0)['p'])
+    torch.manual_seed(1)
+    b = float(tr.step(psi=0.0, stn_lr=0.0, ll_lr=0.0)['p'])
+    torch.manual_seed(1)
+    a2 = float(tr.step(psi=1.0, stn_lr=0.0, ll_lr=0.0)['p'])
+    assert abs(a - a2) <= 2e-2 * abs(a) and abs(a - b) > 5e-2 * abs(a), (a, b, a2)
+    # the EMA network (evaluated eagerly, outside the graph) sees the replayed updates
+    x = torch.randn(2, 3, 64, 64, device=cuda) * 0.3
+    with torch.no_grad():
+        e1 = tr.t_ema(x, padding_mode='border')
+    tr.step(psi=0.5)
+    with torch.no_grad():
+        e2 = tr.t_ema(x, padding_mode='border')
+    assert float((e1 - e2).abs().max()) > 0

@@ -395,3 +395,113 @@ def test_torgb_dgrad_add_matches_autograd(cuda):
     _lib.call('gg_torgb_dgrad_add_f32', g, grad_rgb.float().to(cuda), weight.float().to(cuda), style.float().to(cuda),
               scale, n, c, h * w)
     np.testing.assert_allclose(g.cpu().numpy(), (running.double() + ref).numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- round 2: launch-tail fusions
+
+def test_upfirdn2d_add_matches_separate_ops(cuda):
+    """ToRGB's `rgb + Upsample(skip)` in one kernel: values and both gradients equal the two-op form."""
+    from gangealing_amd.op.upfirdn2d import upfirdn2d, upfirdn2d_add
+    g = torch.Generator().manual_seed(1)
+    k = torch.tensor(np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0 * 4, dtype=torch.float32, device=cuda)
+    for (n, c, h) in [(2, 3, 8), (3, 3, 64), (1, 5, 17)]:
+        skip = torch.randn(n, c, h, h, generator=g).to(cuda).requires_grad_(True)
+        rgb = torch.randn(n, c, 2 * h, 2 * h, generator=g).to(cuda).requires_grad_(True)
+        gout = torch.randn(n, c, 2 * h, 2 * h, generator=g).to(cuda)
+        a = upfirdn2d_add(skip, k, rgb, up=2, down=1, pad=(2, 1))
+        ga = torch.autograd.grad(a, (skip, rgb), gout)
+        b = upfirdn2d(skip, k, up=2, down=1, pad=(2, 1)) + rgb
+        gb = torch.autograd.grad(b, (skip, rgb), gout)
+        torch.testing.assert_close(a, b, atol=1e-6, rtol=1e-6)
+        torch.testing.assert_close(ga[0], gb[0], atol=1e-6, rtol=1e-6)
+        torch.testing.assert_close(ga[1], gb[1], atol=0, rtol=0)
+
+
+def test_add_scale_matches_torch(cuda):
+    from gangealing_amd.op.conv_mfma import add_scale
+    g = torch.Generator().manual_seed(2)
+    for shape in [(2, 7, 5, 3), (4, 64, 32, 32), (1, 1, 1, 1)]:
+        a = torch.randn(*shape, generator=g).to(cuda).requires_grad_(True)
+        b = torch.randn(*shape, generator=g).to(cuda).requires_grad_(True)
+        y = add_scale(a, b, 2 ** -0.5)
+        ga, gb = torch.autograd.grad(y, (a, b), torch.ones_like(y))
+        torch.testing.assert_close(y, (a + b) * 2 ** -0.5, atol=1e-6, rtol=1e-6)
+        torch.testing.assert_close(ga, torch.full_like(a, 2 ** -0.5))
+        torch.testing.assert_close(gb, torch.full_like(b, 2 ** -0.5))
+
+
+def test_style_bank_matches_per_layer_modulation(cuda):
+    """All modulation / demodulation vectors of a generator pass from two launches == the per-layer computation
+    (networks.py:214-216,244-249), for the whole W+ and for the slots behind the learned ones."""
+    from gangealing_amd.stylegan2 import Generator
+    torch.manual_seed(3)
+    g = Generator(64, 512, 8).to(cuda).eval().requires_grad_(False)
+    latent = torch.randn(5, g.n_latent, 512, device=cuda)
+    for first in (0, 3):
+        pre = g._styles(latent, first)
+        layers = [(m, s) for m, s in g._layer_slots() if s >= first]
+        assert len(pre) == len(layers) > 0
+        for m, slot in layers:
+            style, demod = pre[m]
+            ref_style = torch.nn.functional.linear(latent[:, slot].double(), m.modulation.weight.double() * m.modulation.scale,
+                                                   m.modulation.bias.double() * m.modulation.lr_mul)
+            np.testing.assert_allclose(style.cpu().numpy(), ref_style.cpu().numpy(), rtol=2e-5, atol=2e-5)
+            if m.demodulate:
+                w = m.weight[0].double() * m.scale
+                ref_demod = torch.rsqrt(ref_style.pow(2) @ w.pow(2).sum(dim=(2, 3)).t() + 1e-8)
+                np.testing.assert_allclose(demod.cpu().numpy(), ref_demod.cpu().numpy(), rtol=3e-5, atol=1e-7)
+            else:
+                assert demod is None
+    # a latent that needs gradients everywhere leaves nothing to the bank
+    assert g._styles(latent.clone().requires_grad_(True), g.n_latent) == {}
+
+
+def test_generator_fusions_do_not_change_the_image(cuda):
+    """Style bank, noise bank (explicit noise given here), ToRGB bias / skip fusion on vs off: same image, same
+    latent gradient."""
+    from gangealing_amd.op import conv_mfma
+    from gangealing_amd.stylegan2 import Generator
+    torch.manual_seed(4)
+    g = Generator(64, 512, 8).to(cuda).eval().requires_grad_(False)
+    with torch.no_grad():
+        for p in g.parameters():
+            if p.dim() == 4 and p.shape[1] == 3:       # ToRGB biases (1, 3, 1, 1) are zero-initialised
+                p.normal_(0, 0.3)
+    noise = [torch.randn(3, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), device=cuda) for i in range(g.num_layers)]
+    w = torch.randn(3, g.n_latent, 512, device=cuda)
+
+    def run(disabled):
+        old = conv_mfma.DISABLED
+        conv_mfma.DISABLED = frozenset(disabled)
+        try:
+            lat = w.clone().requires_grad_(True)
+            img, _ = g([lat], input_is_latent=True, noise=noise, grad_latents=4)
+            (gl,) = torch.autograd.grad(img.square().mean(), lat)
+            return img.detach(), gl
+        finally:
+            conv_mfma.DISABLED = old
+    img_on, g_on = run(())
+    img_off, g_off = run(('style_bank', 'torgb_bias', 'noise_bank'))
+    torch.testing.assert_close(img_on, img_off, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(g_on, g_off, atol=1e-6 + 1e-4 * float(g_off.abs().max()), rtol=0)
+    assert float(g_on[:, 4:].abs().max()) == 0.0 and float(g_on[:, :4].abs().max()) > 0
+
+
+def test_lpips_tap_accumulates_into_the_downstream_gradient(cuda):
+    """The tap node (features passed on + distance) gives the same value and the same feature gradient as the
+    separate tail with autograd's addition."""
+    from gangealing_amd.losses import lpips_tail, lpips_tap
+    g = torch.Generator().manual_seed(5)
+    f = torch.relu(torch.randn(6, 64, 16, 16, generator=g) + 0.2).to(cuda)
+    lin = torch.rand(64, generator=g).to(cuda)
+    wnext = torch.randn(6, 64, 16, 16, generator=g).to(cuda)
+    gv = torch.randn(3, generator=g).to(cuda)
+    for use_lin in (None, lin):
+        fa = f.clone().requires_grad_(True)
+        passed, val = lpips_tap(fa * 1.0, use_lin)
+        (ga,) = torch.autograd.grad([(passed * wnext).sum(), val], fa, [torch.ones((), device=cuda), gv])
+        fb = f.clone().requires_grad_(True)
+        fb1 = fb * 1.0
+        (gb,) = torch.autograd.grad([(fb1 * wnext).sum(), lpips_tail(fb1, use_lin)], fb, [torch.ones((), device=cuda), gv])
+        torch.testing.assert_close(val, lpips_tail(f, use_lin), atol=1e-6, rtol=1e-5)
+        torch.testing.assert_close(ga, gb, atol=1e-5, rtol=1e-5)

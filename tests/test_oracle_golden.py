@@ -101,9 +101,12 @@ def test_modulated_conv(case):
 
 
 @pytest.mark.parametrize('case', load_golden('splat2d'))
-def test_splat2d_selfcheck(case):
+def test_splat2d_restatement_matches_reference_kernel(case):
+    """oracle/np_ops.splat2d (restated from splat_gpu_impl.cu:53-95, splat_gpu.c:14-41) against outputs of the
+    reference's own kernel run on an MI355X (oracle/make_golden_splat.py)."""
+    assert case['meta']['source'] == 'reference-kernel'
     out = O.splat2d(case['input'], case['coords'], case['values'], case['sigma'], case['meta']['soft_normalize'])
-    close(out, case['out'], 1e-6)
+    close(out, case['out'], 2e-6, 1e-5)          # the kernel sums with float atomics in arbitrary order
     assert np.isfinite(out).all()
 
 
