@@ -47,34 +47,68 @@ MFMA_PRODUCTS = {'fp32': 1, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}
 def pmc_traffic(precision, workload, batch):
     """HBM bytes per launch of the dominant kernel, measured offline with rocprofv3 --pmc on this same command
     (scripts/final_measure.sh) and committed under profiles/; None for configurations that were not profiled."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-    except (OSError, ValueError):
-        return None
-    if (rec.get('precision'), rec.get('workload'), rec.get('batch')) != (precision, workload, batch):
-        return None
-    return rec.get('hbm_bytes_per_launch')
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        try:
+            with open(os.path.join(here, 'profiles', name)) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if (rec.get('precision'), rec.get('workload'), rec.get('batch')) == (precision, workload, batch):
+            return rec.get('hbm_bytes_per_launch')
+    return None
 
 
 DTYPE = {'fp32': 'f32', 'bf16': 'bf16 (convolution operands rounded to bf16, fp32 accumulate, fp32 activations)', 'bf16x3': 'bf16x3 (fp32 operands split into 2 bf16 limbs, fp32 accumulate)',
          'bf16x6': 'bf16x6 (fp32 operands split into 3 bf16 limbs, fp32 accumulate)'}
 
 
-def cpu_baseline(budget_s=20.0):
-    """The oracle's torch-CPU restatement of the reference's CPU op fallback (kind "port"), config C1
-    (gen 64, similarity-only STN at 64, batch 4), full loss forward + backward + Adam + EMA, MSE stand-in
-    for the VGG loss (torchvision is absent), on the host cores of this box.  Bounded sample: whole
-    steps until ~budget_s seconds have elapsed (at least 1)."""
+def _reference_step_fn(wl):
+    """The REFERENCE's own training-loss step on its pure-PyTorch CPU op fallback (upfirdn2d_native, CPU
+    fused_leaky_relu, F.conv2d / grid_sample), imported from /root/reference through the stub loader of
+    oracle/make_golden.py.  Only possible where the reference checkout exists (the authoring container); None on
+    the GPU box."""
+    ref = os.environ.get('GANGEALING_REFERENCE', '/root/reference')
+    if not os.path.isdir(os.path.join(ref, 'models')):
+        return None
+    try:
+        from oracle.make_golden import import_reference
+        import_reference()
+        from models.stylegan2.networks import Generator
+        from models.spatial_transformers.spatial_transformer import get_stn
+        from models.latent_learner import DirectionInterpolator
+        from models.losses.loss import gangealing_loss
+        from models import accumulate
+    except Exception:                          # noqa: BLE001 - any import problem: fall back to the port
+        return None
+    gen = Generator(wl['gen_size'], 512, 8).eval().requires_grad_(False)
+    stn = get_stn(list(wl['transform']), flow_size=wl['flow_size'], supersize=wl['gen_size'], channel_multiplier=0.5,
+                  num_heads=1)
+    ema = get_stn(list(wl['transform']), flow_size=wl['flow_size'], supersize=wl['gen_size'], channel_multiplier=0.5,
+                  num_heads=1)
+    ll = DirectionInterpolator(None, wl['ndirs'], wl['inject'], gen.n_latent)
+    t_optim = torch.optim.Adam(stn.parameters(), lr=1e-3)
+    ll_optim = torch.optim.Adam(ll.parameters(), lr=1e-2)
+    mse = lambda x, y: ((x - y) ** 2).mean(dim=(1, 2, 3))         # torchvision (LPIPS trunk) is not installed
+
+    def step():
+        loss, _ = gangealing_loss(gen, stn, ll, mse, torch.nn.Sequential(), 0.5, wl['batch'], 512, False, 'cpu',
+                                  padding_mode=wl['padding_mode'])
+        stn.zero_grad()
+        ll.zero_grad()
+        loss.backward()
+        t_optim.step()
+        ll_optim.step()
+        accumulate(ema, stn, 0.5 ** (32 / 10000))
+    return step
+
+
+def _port_step_fn(wl):
+    """oracle/torch_ref.py: the torch-CPU restatement of the same step (what travels to the GPU box)."""
     from oracle import torch_ref as R
     from oracle.det_weights import det_state_dict
     from gangealing_amd.stylegan2 import Generator
     from gangealing_amd.spatial_transformers.spatial_transformer import get_stn
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
-    wl = WORKLOADS['c1']
     g_sd = det_state_dict(Generator(wl['gen_size'], 512, 8))
     stn = get_stn(list(wl['transform']), flow_size=wl['flow_size'], supersize=wl['gen_size'], channel_multiplier=0.5)
     stn_sd = {k: v.clone().requires_grad_(True) for k, v in
@@ -85,8 +119,8 @@ def cpu_baseline(budget_s=20.0):
     opt = torch.optim.Adam(params, lr=1e-3)
     ema = [p.detach().clone() for p in stn_sd.values()]
     decay = 0.5 ** (32 / 10000)
-    steps, t0 = 0, time.perf_counter()
-    while True:
+
+    def step():
         z = torch.randn(wl['batch'], 512)
         total, _ = R.train_loss(g_sd, stn_sd, ll_sd, z, wl['gen_size'], wl['flow_size'], 0.5, wl['inject'],
                                 wl['padding_mode'], wl['transform'], R.mse_loss_fn, 0.0, 0.0)
@@ -96,13 +130,88 @@ def cpu_baseline(budget_s=20.0):
         with torch.no_grad():
             for e, p in zip(ema, stn_sd.values()):
                 e.mul_(decay).add_(p, alpha=1 - decay)
+    return step
+
+
+def cpu_baseline(budget_s=20.0):
+    """Config C1 (gen 64, similarity-only STN at 64, batch 4: BASELINE.json configs[0]) as full train steps - loss
+    forward, backward, Adam x2, EMA - on this box's host cores, MSE stand-in for the VGG loss.  kind "reference" when
+    the reference checkout is importable (its own code runs), else "port" (oracle/torch_ref.py).  The thread count is
+    chosen by a 3-point sweep (one step each) and reported; the sample is whole steps until ~budget_s seconds."""
+    wl = WORKLOADS['c1']
+    step = _reference_step_fn(wl)
+    kind = 'reference' if step is not None else 'port'
+    if step is None:
+        step = _port_step_fn(wl)
+    cores = os.cpu_count() or 1
+    sweep = {}
+    for threads in sorted({min(cores, t) for t in (8, 16, 32)}):
+        torch.set_num_threads(threads)
+        step()                                     # warm (allocator, thread pool)
+        t0 = time.perf_counter()
+        step()
+        sweep[threads] = time.perf_counter() - t0
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        step()
         steps += 1
         dt = time.perf_counter() - t0
         if dt >= budget_s or steps >= 50:
             break
-    return dict(value=round(steps * wl['batch'] / dt, 3), unit='images/sec', cores=threads, kind='port',
+    src = 'the reference\'s own modules (imported from the reference checkout)' if kind == 'reference' \
+        else 'oracle/torch_ref.py (reference checkout absent on this box)'
+    return dict(value=round(steps * wl['batch'] / dt, 3), unit='images/sec', cores=threads, kind=kind,
                 sample=f'{steps} full train steps of config C1 (gen 64, similarity STN@64, batch {wl["batch"]}, '
-                       f'MSE stand-in loss) in {dt:.1f} s via oracle/torch_ref.py on {threads} of {cores} host cores')
+                       f'MSE stand-in loss) in {dt:.1f} s via {src}; {threads} of {cores} host cores, chosen by a '
+                       f'one-step sweep: ' + ', '.join(f'{t} threads {v:.2f} s' for t, v in sorted(sweep.items())))
+
+
+SYNTHETIC_LR = 1e-4      # the work per step does not depend on the learning rate; with randomly initialised G / VGG the
+                         # reference's 1e-3 sends the random STN to extreme zooms within a few iterations (gradient spikes of
+                         # 1e4 .. 1e10 in the similarity head), 1e-4 keeps it near its perturbed initial warp
+
+
+def measure(device, wl, precision, graph, steps, warmup, world, gdist, profile=True):
+    """Warm-up, then time exactly `steps` iterations between barrier + synchronize pairs.  -> dict."""
+    from gangealing_amd.op import conv_mfma
+    from gangealing_amd.train_step import GangealingTrainer
+    conv_mfma.set_precision(precision)
+    trainer = GangealingTrainer(device, perturb_heads=0.02, seed=0, use_graph=graph and world == 1,
+                                stn_lr=SYNTHETIC_LR, ll_lr=SYNTHETIC_LR, **wl)
+
+    def barrier():
+        torch.cuda.synchronize()
+        gdist.synchronize()
+        torch.cuda.synchronize()
+
+    graphed = trainer.use_graph
+    for _ in range(max(warmup, trainer._graph_warmup + 1 if graphed else 0)):
+        trainer.step(psi=0.5)
+    trainer.flush()
+    barrier()
+    prof = conv_mfma.LaunchProfiler()
+    if profile and not graphed:
+        conv_mfma.PROFILER = prof        # HIP events around the dominant kernel's launches inside the timed region
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        parts = trainer.step(psi=0.5)
+    trainer.flush()                      # a deferred (pipelined) optimizer step belongs to the timed region
+    barrier()
+    elapsed = time.perf_counter() - t0
+    conv_mfma.PROFILER = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(parts['p'])
+    assert loss == loss and abs(loss) != float('inf'), 'non-finite loss'
+    res = dict(elapsed=elapsed, loss=loss, graphed=graphed, prof=prof.summary() if (profile and not graphed) else None,
+               images=world * wl['batch'] * steps)
+    del trainer
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -116,8 +225,10 @@ def main():
                     choices=['fp32', 'bf16', 'bf16x3', 'bf16x6'],
                     help='arithmetic of the implicit-GEMM convolutions (fp32 = exact fp32 MFMA parity mode)')
     ap.add_argument('--graph', action='store_true',
-                    help='capture the whole iteration in a hipGraph and replay it (single GPU); the roofline entry is then '
-                         'timed on eager iterations run right after the timed region')
+                    help='time hipGraph replays of the whole iteration instead of eager launches (single GPU; no '
+                         'roofline entry: HIP events cannot be recorded inside a replayed graph)')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the additional single-GPU measurements (hipGraph replay, plain-bf16 arithmetic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
@@ -125,9 +236,6 @@ def main():
     from gangealing_amd import _lib
     _lib.load()                      # fail loudly when the HIP library is missing
     from gangealing_amd import distributed as gdist
-    from gangealing_amd.op import conv_mfma
-    from gangealing_amd.train_step import GangealingTrainer
-    conv_mfma.set_precision(args.precision)
 
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -145,52 +253,14 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl['batch'] = args.batch
-    trainer = GangealingTrainer(device, perturb_heads=0.02, seed=0, use_graph=args.graph and world == 1, **wl)
-
-    def barrier():
-        torch.cuda.synchronize()
-        gdist.synchronize()
-        torch.cuda.synchronize()
-
-    graphed = trainer.use_graph
-    for _ in range(max(args.warmup, trainer._graph_warmup + 1 if graphed else 0)):
-        trainer.step(psi=0.5)
-    trainer.flush()
-    barrier()
-    prof = conv_mfma.LaunchProfiler()
-    if not graphed:
-        conv_mfma.PROFILER = prof        # HIP events around the dominant kernel's launches inside the timed region
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        parts = trainer.step(psi=0.5)
-    trainer.flush()                      # a deferred (pipelined) optimizer step belongs to the timed region
-    barrier()
-    elapsed = time.perf_counter() - t0
-    conv_mfma.PROFILER = None
-    if graphed:
-        # events cannot be recorded inside a replayed graph: time the same launches on eager iterations of the same
-        # trainer right after the timed region (same kernels, same shapes, same data distribution)
-        loss_parts = {k: (v.clone() if v is not None else None) for k, v in parts.items()}
-        trainer.use_graph = False
-        conv_mfma.PROFILER = prof
-        for _ in range(3):
-            trainer.step(psi=0.5)
-        torch.cuda.synchronize()
-        conv_mfma.PROFILER = None
-        parts = loss_parts
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(parts['p']).all(), 'non-finite loss'
+    main_run = measure(device, wl, args.precision, args.graph, args.steps, args.warmup, world, gdist)
 
     if rank == 0:
-        psum = prof.summary()
-        images = world * wl['batch'] * args.steps
-        achieved = psum['total_flops'] / (psum['total_ms'] * 1e-3) / 1e12 if psum['total_ms'] > 0 else 0.0
+        psum = main_run['prof']
+        elapsed = main_run['elapsed']
         out = {
             'metric': 'train-step images/sec, LSUN-Cats 256^2 STN+StyleGAN2',
-            'value': round(images / elapsed, 3),
+            'value': round(main_run['images'] / elapsed, 3),
             'unit': 'images/sec',
             'n_gpus': world,
             'steps': args.steps,
@@ -203,28 +273,48 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: gen {wl["gen_size"]}^2, STN {"+".join(wl["transform"])} @ '
                                    f'{wl["flow_size"]}^2, per-GPU batch {wl["batch"]}, VGG16-topology perceptual loss '
-                                   f'(random weights), random-init frozen G, psi 0.5',
+                                   f'(random weights), random-init frozen G, psi 0.5, learning rates {SYNTHETIC_LR}',
                        'global_batch': world * wl['batch'], 'parallelism': f'dp{world}',
-                       'launch': 'hipGraph replay of the whole iteration' if graphed else 'eager launches',
-                       'loss': float(parts['p'])},
-            'roofline': {
-                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS[args.precision],
-                'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_PEAK_TFLOPS[args.precision], 4),
+                       'launch': 'hipGraph replay of the whole iteration' if main_run['graphed'] else 'eager launches',
+                       'loss': main_run['loss']},
+        }
+        if psum is not None:
+            achieved = psum['total_flops'] / (psum['total_ms'] * 1e-3) / 1e12 if psum['total_ms'] > 0 else 0.0
+            peak = MFMA_PEAK_TFLOPS[args.precision]
+            out['roofline'] = {
+                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
+                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                 'traffic': pmc_traffic(args.precision, args.workload, wl['batch']),
                 'kernel': KERNEL_NAME[args.precision],
                 'mfma_products_per_flop': MFMA_PRODUCTS[args.precision],
-                'mfma_issue_frac': round(achieved * MFMA_PRODUCTS[args.precision] / MFMA_PEAK_TFLOPS[args.precision], 4),
-                'note': 'achieved = algorithmic conv FLOPs (2*N*Cin*Cout*9*OH*OW per launch) / HIP-event time; '
-                        'peak = dense MFMA peak of the instruction used; mfma_issue_frac = share of that peak the '
-                        'matrix pipe actually executes (split precision issues 3 or 6 MFMA products per algorithmic '
-                        'product); traffic = HBM bytes per launch from the committed rocprofv3 PMC passes '
-                        '(profiles/r01_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), null when '
-                        'the run is not the profiled configuration',
+                'mfma_issue_frac': round(achieved * MFMA_PRODUCTS[args.precision] / peak, 4),
+                'note': 'achieved = algorithmic conv FLOPs (2*N*Cin*Cout*9*OH*OW per launch) / HIP-event time over '
+                        'the timed region; peak = dense MFMA peak of the instruction used; mfma_issue_frac = share of '
+                        'that peak the matrix pipe actually executes (split precision issues 3 or 6 MFMA products '
+                        'per algorithmic product); traffic = HBM bytes per launch from the committed rocprofv3 PMC '
+                        'passes (profiles/*pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), null '
+                        'when the run is not the profiled configuration',
                 'launches': psum['launches'],
                 'avg_launch_ms': round(psum['total_ms'] / max(psum['launches'], 1), 4),
                 'avg_launch_gflop': round(psum['total_flops'] / max(psum['launches'], 1) / 1e9, 3),
-            },
-        }
+            }
+    if world == 1 and rank == 0 and not args.no_extras and not args.graph:
+        # further measurements of the same workload in the same process (each with its own trainer); `value` above
+        # stays the eager, parity-preserving run whose dominant kernel was timed with HIP events
+        extras = {}
+        for name, prec, graph in (('hipgraph_replay', args.precision, True), ('bf16_eager', 'bf16', False),
+                                  ('bf16_hipgraph_replay', 'bf16', True)):
+            if name.startswith('bf16') and args.precision == 'bf16':
+                continue
+            try:
+                r = measure(device, wl, prec, graph, args.steps, args.warmup, world, gdist, profile=False)
+                extras[name] = {'value': round(r['images'] / r['elapsed'], 3),
+                                'ms_per_step': round(1e3 * r['elapsed'] / args.steps, 3), 'dtype': DTYPE[prec],
+                                'launch': 'hipGraph replay' if r['graphed'] else 'eager'}
+            except Exception as e:             # noqa: BLE001 - an extra must never take the headline line down
+                extras[name] = {'error': str(e)[:200]}
+        out['extras'] = extras
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_budget)
         print(json.dumps(out), flush=True)

@@ -20,17 +20,52 @@ def flow_identity_loss(delta_flow):
     return flow_losses(delta_flow)[1]
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device)
+    if s is None:
+        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 def sample_gan_supervised_pairs(generator, ll, resize_fake2stn, psi, batch, dim_latent, freeze_ll, device, z=None):
-    """(unaligned G(w), aligned target G(mix(w, c))) - loss.py:21-29.  G pass #1 needs no graph."""
+    """(unaligned G(w), aligned target G(mix(w, c))) - loss.py:21-29.  G pass #1 needs no graph.
+
+    The two synthesis passes are independent once w is known, so pass #1 can be issued on a second HIP stream and
+    overlap pass #2: the low-resolution layers (too few tiles to fill 256 CUs) and the HBM-bound blur / activation
+    kernels of one pass run beside the matrix-pipe-bound convolutions of the other.  The caller's stream waits for
+    the side stream before anything reads `unaligned_in`."""
     if z is None:
         z = torch.randn(batch, dim_latent, device=device)
-    with torch.no_grad():
-        unaligned_in, w_noise = generator([z], noise=None, return_latents=True)
+    # measured (MI355X, C2): +3.5 % at per-GPU batch 5, +0.6 % at batch 16 - while every kernel's own duration
+    # roughly doubles under the contention, which would blur the per-kernel roofline measurement.  Hence: automatic for
+    # small batches (the reference recipes use 5 per GPU), opt-in (GG_ENABLE=two_streams) otherwise.
+    overlap = (isinstance(generator, torch.nn.Module) and z.is_cuda and hasattr(generator, 'get_latent') and
+               'two_streams' not in conv_mfma.DISABLED and (batch <= 8 or 'two_streams' in conv_mfma.ENABLED))
+    if not overlap:
+        with torch.no_grad():
+            unaligned_in, w_noise = generator([z], noise=None, return_latents=True)
+        side = None
+    else:
+        with torch.no_grad():
+            w = generator.get_latent(z)                                    # mapping network (both passes need w)
+            w_noise = w.unsqueeze(1).repeat(1, generator.n_latent, 1)      # as Generator.forward builds it (:548-549)
+        cur = torch.cuda.current_stream()
+        side = _side_stream(z.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            unaligned_in, _ = generator([w_noise], input_is_latent=True, noise=None)
+        w_noise.record_stream(side)
     with torch.set_grad_enabled(not freeze_ll):
         w_aligned = ll([w_noise[:, 0, :]], psi=psi)
         aligned_target, _ = generator(w_aligned, input_is_latent=True, noise=None,
                                       grad_latents=getattr(ll, 'inject_index', None))
         aligned_target = resize_fake2stn(aligned_target)
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
+        unaligned_in.record_stream(torch.cuda.current_stream())
     return unaligned_in, aligned_target
 
 

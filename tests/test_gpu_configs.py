@@ -96,7 +96,7 @@ def grad_errors(ours, ref32, ref64):
             float(np.abs(d_r).max()) / mx)
 
 
-def check_grads(test, mode, grads, case, select=lambda name: True, factor=GRAD_FACTOR):
+def check_grads(test, mode, grads, case, select=lambda name: True, factor=GRAD_FACTOR, floor_scale=1.0):
     """Gradient parity with a float64 evaluation of the REFERENCE as ground truth (fixture keys grad64_*).
 
     Metric: relative L2 error of each parameter's gradient (over the stored strided sample) and relative error of its
@@ -112,7 +112,7 @@ def check_grads(test, mode, grads, case, select=lambda name: True, factor=GRAD_F
     meta = case['meta']
     names = [k for k in meta['grad_norms'] if select(k)]
     assert set(norms) >= set(names)
-    n_floor, l2_floor = GRAD_FLOOR[mode][1], GRAD_FLOOR[mode][0]
+    n_floor, l2_floor = GRAD_FLOOR[mode][1] * floor_scale, GRAD_FLOOR[mode][0] * floor_scale
     rows, failures = [], []
     for name in names:
         key = name.replace('.', '_')
@@ -209,7 +209,8 @@ def test_c2_stn_batch16(ci, mode, cuda):
     # where a similarity warp makes the four neighbour distances exactly tied in real arithmetic
     named = {k: g for (k, _), g in zip(params, grads)}
     check_grads(test + '/flow-stage', mode, named, c, select=lambda k: k.startswith('stns.1.'))
-    check_grads(test + '/similarity-stage', mode, named, c, select=lambda k: k.startswith('stns.0.'), factor=SIM_FACTOR)
+    check_grads(test + '/similarity-stage', mode, named, c, select=lambda k: k.startswith('stns.0.'), factor=SIM_FACTOR,
+                floor_scale=3.0)
 
 
 @pytest.mark.parametrize('name', ['c2', 'c4', 'c5'])
@@ -229,7 +230,8 @@ def test_config_loss_step(name, mode, cuda):
     grads = res['grads']
     assert set(grads) == set(c['meta']['grad_norms'])
     check_grads(test + '/flow-stage', mode, grads, c, select=lambda k: k.startswith('stns.1.'))
-    check_grads(test + '/similarity-stage', mode, grads, c, select=lambda k: k.startswith('stns.0.'), factor=SIM_FACTOR)
+    check_grads(test + '/similarity-stage', mode, grads, c, select=lambda k: k.startswith('stns.0.'), factor=SIM_FACTOR,
+                floor_scale=3.0)
     check_grads(test + '/latent-learner', mode, grads, c, select=lambda k: k == 'll.coefficients')
 
 
