@@ -531,8 +531,10 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   // 3-limb rows are 240 bytes per pixel: 32-wide tiles ((4+2) x (32+2) patch pixels) keep the block under 80 KB of
   // LDS, i.e. two blocks per CU instead of one
   constexpr int PATCH_MAX = LIMBS == 3 ? 6 * 34 : patch_pixels(TPIX);
-  // one LDS arena: [limb][patch rows] then [limb][weight rows]; reused as the epilogue staging buffer
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LIMBS * (PATCH_MAX + TCO) * ROWB];
+  // one LDS arena: [limb][patch rows] then [limb][weight rows]; reused as the epilogue staging buffer (32 x 64
+  // floats per wave - with a single limb that is the larger of the two uses)
+  constexpr int MAIN_BYTES = LIMBS * (PATCH_MAX + TCO) * ROWB, STAGE_BYTES = (NT / 64) * 32 * 64 * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES];
   unsigned char (*sP)[PATCH_MAX * ROWB] = reinterpret_cast<unsigned char (*)[PATCH_MAX * ROWB]>(smem);
   unsigned char (*sW)[TCO * ROWB] = reinterpret_cast<unsigned char (*)[TCO * ROWB]>(smem + LIMBS * PATCH_MAX * ROWB);
 
@@ -831,7 +833,8 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   // weight slabs staged per barrier interval: the 8-wave variant (alone on its CU) takes a whole row of taps
   // (ky fixed, kx = 0..2) so that each interval carries 36 instead of 12 MFMAs per wave
   constexpr int TPI = (TQ == 128) ? 3 : 1;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LIMBS * (PATCH_MAX + TPI * TCO) * ROWB];
+  constexpr int MAIN_BYTES = LIMBS * (PATCH_MAX + TPI * TCO) * ROWB, STAGE_BYTES = (NT / 64) * 8 * 128 * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES];
   unsigned char (*sP)[PATCH_MAX * ROWB] = reinterpret_cast<unsigned char (*)[PATCH_MAX * ROWB]>(smem);
   unsigned char (*sW)[TCO * ROWB] = reinterpret_cast<unsigned char (*)[TCO * ROWB]>(smem + LIMBS * PATCH_MAX * ROWB);
 

@@ -89,38 +89,67 @@ class SpatialTransformer(SingleStnPointOps, nn.Module):
     def forward(self, input_img, output_resolution=None, iters=1, return_warp=False, return_flow=False,
                 return_intermediates=False, return_out_of_bounds=False, intermediate_output_resolution=None,
                 stop_grad=False, alpha=None, padding_mode='border', input_img_for_sampling=None, image_bounds=None,
-                warp_policy='cartesian', unfold=False, base_warp=None, pack=False):
-        if return_out_of_bounds or return_intermediates:
-            raise NotImplementedError('inference-application options are out of scope for the training path')
-        if iters != 1:
-            assert not self.is_flow, 'iterating is only defined for similarity STNs'
-            out, src = input_img, (input_img if input_img_for_sampling is None else input_img_for_sampling)
-            mid = self.stn_in_size if intermediate_output_resolution is None else intermediate_output_resolution
-            m = base_warp
-            for it in range(iters):
-                last = it == iters - 1
-                out, grid, m, _ = self._single(out, output_resolution if last else mid, m, src, stop_grad,
-                                               alpha if last else None, padding_mode, warp_policy, unfold and last)
-        else:
-            out, grid, m, _ = self._single(input_img, output_resolution, base_warp, input_img_for_sampling, stop_grad,
-                                           alpha, padding_mode, warp_policy, unfold)
-        if pack:
-            return [out, grid, m, None]
-        ret = [out] + ([grid] if return_warp else []) + ([m] if return_flow else [])
+                warp_policy='cartesian', unfold=False, base_warp=None):
+        """spatial_transformer.py:471-521: iters == 1 -> single_forward, else iterated_forward."""
+        common = dict(output_resolution=output_resolution, return_warp=return_warp, return_flow=return_flow,
+                      stop_grad=stop_grad, alpha=alpha, padding_mode=padding_mode,
+                      input_img_for_sampling=input_img_for_sampling, return_out_of_bounds=return_out_of_bounds,
+                      image_bounds=image_bounds, warp_policy=warp_policy, unfold=unfold, base_warp=base_warp)
+        if iters == 1:
+            return self.single_forward(input_img, **common)
+        return self.iterated_forward(input_img, iters=iters, return_intermediates=return_intermediates,
+                                     intermediate_output_resolution=intermediate_output_resolution, **common)
+
+    def iterated_forward(self, input_img, output_resolution=None, iters=1, return_warp=False, return_flow=False,
+                         return_intermediates=False, intermediate_output_resolution=None, stop_grad=False, alpha=None,
+                         padding_mode='border', input_img_for_sampling=None, return_out_of_bounds=False,
+                         image_bounds=None, warp_policy='cartesian', unfold=False, base_warp=None):
+        """Apply a similarity STN to its own output `iters` times, composing the warps; pixels are always sampled
+        from the original source (spatial_transformer.py:523-567)."""
+        assert not self.is_flow, 'iterated_forward is currently only supported for similarity STNs'
+        out = input_img
+        source = input_img if input_img_for_sampling is None else input_img_for_sampling
+        mid = self.stn_in_size if intermediate_output_resolution is None else intermediate_output_resolution
+        m = base_warp
+        outs, transforms = [], []
+        grid = out_of_bounds = None
+        for it in range(iters):
+            last = it == iters - 1
+            out, grid, m, oob = self.single_forward(
+                out, output_resolution=output_resolution if last else mid, return_warp=True, return_flow=True,
+                return_out_of_bounds=return_out_of_bounds and last, base_warp=m, input_img_for_sampling=source,
+                stop_grad=stop_grad, alpha=alpha if last else None, padding_mode=padding_mode,
+                image_bounds=image_bounds, warp_policy=warp_policy, unfold=unfold and last, pack=True)
+            if return_out_of_bounds and last:
+                out_of_bounds = oob
+            outs.append(out)
+            transforms.append(m)
+        if return_intermediates:
+            return outs, transforms
+        ret = [out] + ([grid] if return_warp else []) + ([m] if return_flow else []) + \
+            ([out_of_bounds] if return_out_of_bounds else [])
         return ret[0] if len(ret) == 1 else ret
 
-    single_forward = forward
-
-    def _single(self, input_img, output_resolution, base_warp, input_img_for_sampling, stop_grad, alpha,
-                padding_mode, warp_policy, unfold):
+    def single_forward(self, input_img, output_resolution=None, return_warp=False, return_flow=False,
+                       return_out_of_bounds=False, base_warp=None, input_img_for_sampling=None, stop_grad=False,
+                       alpha=None, padding_mode='border', image_bounds=None, warp_policy='cartesian', unfold=False,
+                       pack=False):
+        """spatial_transformer.py:569-615.  pack=True returns everything the warp head returned."""
         regression_input = self.input_downsample(input_img) if input_img.size(-1) > self.stn_in_size else input_img
         source = input_img if input_img_for_sampling is None else input_img_for_sampling
         feats = self.final_conv(self.convs(regression_input))
         if not self.is_flow:
             feats = self.final_linear(feats.view(feats.shape[0], -1))
         res = output_resolution if output_resolution is not None else self.stn_in_size
-        return self.warp_head(source, feats, output_resolution=res, base_warp=base_warp, stop_grad=stop_grad,
-                              alpha=alpha, padding_mode=padding_mode, warp_policy=warp_policy, unfold=unfold)
+        out, grid, m, oob = self.warp_head(source, feats, output_resolution=res, base_warp=base_warp,
+                                           stop_grad=stop_grad, alpha=alpha, padding_mode=padding_mode,
+                                           return_out_of_bounds=return_out_of_bounds, image_bounds=image_bounds,
+                                           warp_policy=warp_policy, unfold=unfold)
+        if pack:
+            return [out, grid, m, oob]
+        ret = [out] + ([grid] if return_warp else []) + ([m] if return_flow else []) + \
+            ([oob] if return_out_of_bounds else [])
+        return ret[0] if len(ret) == 1 else ret
 
 
 class ComposedSTN(ComposedStnPointOps, nn.Module):

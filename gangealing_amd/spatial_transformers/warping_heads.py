@@ -33,6 +33,29 @@ def _resolve_policy(warp_policy, img, num_heads):
     return 'assign_only', logits.max(dim=1).indices % num_heads
 
 
+def check_if_warp_exceeds_image_boundaries(grid, image_bounds, img_size, split_size, threshold=0.025):
+    """(N,) bool: did more than `threshold` of the output pixels sample beyond the image (or beyond the un-padded
+    content described by `image_bounds` (N, 2) = (height, width) of the raw image)?  warping_heads.py:280-310; used by
+    the data pre-processing application only."""
+    if image_bounds is None:
+        boundary_y = img_size[-2]
+        boundary_x = img_size[-1]
+    else:
+        image_bounds = image_bounds.repeat_interleave(split_size, dim=0)
+        landscape = image_bounds[:, 0] < image_bounds[:, 1]
+        boundary_y = torch.where(landscape, img_size[-2] * image_bounds[:, 0] / image_bounds[:, 1],
+                                 torch.tensor(img_size[-2], dtype=torch.float, device=grid.device)).round()
+        boundary_x = torch.where(landscape, torch.tensor(img_size[-1], dtype=torch.float, device=grid.device),
+                                 img_size[-1] * image_bounds[:, 1] / image_bounds[:, 0]).round()
+    grid_x, grid_y = grid[..., 0], grid[..., 1]
+    bx, by = (boundary_x - 1) / img_size[-1], (boundary_y - 1) / img_size[-2]
+    if isinstance(bx, torch.Tensor):
+        bx, by = bx.view(-1, 1), by.view(-1, 1)
+    oob_x = grid_x.flatten(1).abs().gt(bx).float().mean(dim=1).gt(threshold)
+    oob_y = grid_y.flatten(1).abs().gt(by).float().mean(dim=1).gt(threshold)
+    return torch.logical_or(oob_y, oob_x)
+
+
 class SimilarityHead(nn.Module):
     """Rotation, uniform scale and translation (4 parameters per head)."""
 
@@ -61,8 +84,6 @@ class SimilarityHead(nn.Module):
     def forward(self, img, features, output_resolution=None, alpha=None, base_warp=None, stop_grad=False,
                 padding_mode='border', return_out_of_bounds=False, image_bounds=None, warp_policy='cartesian',
                 unfold=False):
-        if return_out_of_bounds:
-            raise NotImplementedError('return_out_of_bounds is used by the data pre-processing app only')
         n = features.size(0)
         params = self.linear(features)
         policy, assignments = _resolve_policy(warp_policy, img, self.num_heads)
@@ -88,11 +109,14 @@ class SimilarityHead(nn.Module):
         img = img.repeat_interleave(split, dim=0) if split > 1 else img
         grid = affine_grid(matrix, (n * split, img.size(1), res_h, res))
         out = self.warper(img, grid, padding_mode=padding_mode)
+        oob = None
+        if return_out_of_bounds:
+            oob = check_if_warp_exceeds_image_boundaries(grid, image_bounds, (n * split, img.size(1), res_h, res), split)
         if unfold:
             out = out.reshape(n, -1, out.size(1), out.size(2), out.size(3))
             matrix = matrix.reshape(n, -1, 2, 3)
             grid = grid.reshape(n, -1, res_h, res, 2)
-        return out, grid, matrix, None
+        return out, grid, matrix, oob
 
 
 class FlowHead(nn.Module):
@@ -123,8 +147,6 @@ class FlowHead(nn.Module):
     def forward(self, img, features, output_resolution=None, alpha=None, base_warp=None, stop_grad=False,
                 padding_mode='border', return_out_of_bounds=False, image_bounds=None, warp_policy='cartesian',
                 unfold=False):
-        if return_out_of_bounds:
-            raise NotImplementedError('return_out_of_bounds is used by the data pre-processing app only')
         ds, k = self.flow_downsample, self.num_heads
         low = self.flow_out(features)                          # (N, K*2, h, w)
         mask = self.mask_out(features)                         # (N, K*9*ds*ds, h, w)
@@ -150,11 +172,16 @@ class FlowHead(nn.Module):
             flow = flow.detach() + 0 * flow
         img = img.repeat_interleave(split, dim=0) if split > 1 else img
         out = self.warper(img, flow, padding_mode=padding_mode)
+        oob = None
+        if return_out_of_bounds:
+            size = (img.size(0), flow.size(1), flow.size(2)) if output_resolution is None else \
+                (img.size(0), img.size(1), output_resolution, output_resolution)
+            oob = check_if_warp_exceeds_image_boundaries(flow, image_bounds, size, split)
         if unfold:
             out = out.reshape(out.size(0) // k, k, out.size(1), out.size(2), out.size(3))
             flow = flow.reshape(flow.size(0) // k, k, out.size(3), out.size(4), 2)
             delta_flow = delta_flow.reshape(delta_flow.size(0) // k, k, ds * h, ds * w, 2)
-        return out, flow, delta_flow, None
+        return out, flow, delta_flow, oob
 
 
 def apply_affine(matrix, grid):

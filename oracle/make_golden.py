@@ -434,6 +434,42 @@ def gen_train_step():
 # this script never touches it.
 
 
+def gen_stn_inference():
+    """Inference options of the STN (spatial_transformer.py:471-567, warping_heads.py:129-131,257-260,280-310):
+    iterated similarity warps with intermediates, output_resolution, out-of-bounds detection with and without
+    image_bounds, for a single STN and the composed one."""
+    from models.spatial_transformers.spatial_transformer import get_stn
+    rules = (('warp_head.linear', 0.004), ('flow_out.2', 0.05), ('mask_out', 0.5))
+    cases = []
+    for ci, transforms in enumerate((['similarity'], ['similarity', 'flow'])):
+        stn = get_stn(transforms, flow_size=64, supersize=128, channel_multiplier=0.5, num_heads=1)
+        torch.nn.Module.load_state_dict(stn, det_state_dict(stn, rules), strict=False)
+        stn.eval()
+        x = rnd(f'inf.x{ci}', (3, 3, 128, 128), 0.5)
+        bounds = torch.tensor([[96.0, 128.0], [128.0, 80.0], [128.0, 128.0]])
+        with torch.no_grad():
+            if len(transforms) == 1:
+                out3, grid3, m3, oob3 = stn(x, iters=3, return_warp=True, return_flow=True, return_out_of_bounds=True,
+                                            output_resolution=96, padding_mode='border')
+                out1, oob1 = stn(x, return_out_of_bounds=True, padding_mode='reflection')
+                # image_bounds: the reference compares (N, H*W) with an (N,) threshold vector
+                # (warping_heads.py:306-307), which only broadcasts for one image at a time - as the pre-processing
+                # application calls it
+                oob_b = torch.cat([stn(x[i:i + 1], return_out_of_bounds=True, padding_mode='border',
+                                       image_bounds=bounds[i:i + 1])[1] for i in range(3)])
+                outs, mats = stn(x, iters=3, return_intermediates=True, padding_mode='border')
+                case = dict(x=x, bounds=bounds, out3=out3, grid3=grid3, m3=m3, oob3=oob3, out1=out1, oob1=oob1,
+                            oob_b=oob_b, inter_out=torch.stack(outs), inter_m=torch.stack(mats))
+            else:       # the composed STN iterates its similarity stage; it has no out-of-bounds output (:117)
+                out3, grid3, d3 = stn(x, iters=3, return_warp=True, return_flow=True, output_resolution=96,
+                                      padding_mode='border')
+                imgs, warps = stn(x, iters=2, return_intermediates=True, padding_mode='reflection')
+                case = dict(x=x, out3=out3, grid3=grid3, m3=d3, inter_out=torch.stack(imgs), inter_m=torch.stack(warps))
+            case['meta'] = dict(transforms=transforms, scale_rules=[list(r) for r in rules])
+        cases.append(case)
+    save('stn_inference', cases)
+
+
 # ---------------------------------------------------------------------------------------------
 # integer by-products of the anti-aliased sampling ("bit-exact warp grid indices")
 
@@ -625,7 +661,7 @@ if __name__ == '__main__':
     gens = dict(upfirdn2d=gen_upfirdn2d, fused_act=gen_fused_act, mipmap_warp=gen_mipmap_warp, heads=gen_heads,
                 misc=gen_misc, modconv=gen_modconv, generator=gen_generator, stn=gen_stn,
                 train_step=gen_train_step, cluster_classifier=gen_cluster_classifier,
-                point_transfer=gen_point_transfer, warp_indices=gen_warp_indices, annealing=gen_annealing)
+                point_transfer=gen_point_transfer, warp_indices=gen_warp_indices, annealing=gen_annealing, stn_inference=gen_stn_inference)
     for name, fn in gens.items():
         if only and name not in only:
             continue

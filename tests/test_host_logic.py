@@ -246,3 +246,19 @@ def test_lpips_module_layout_matches_reference_and_loads_torchvision_features():
         get_perceptual_loss('vgg_ssl', 'cpu', weights='/nonexistent/simclr.pt')
     with pytest.raises(FileNotFoundError):
         get_perceptual_loss('vgg_ssl', 'cpu', weights='/nonexistent/simclr.pt', allow_random=False)
+
+
+def test_torch_library_ops_are_registered_with_fake_kernels():
+    """torch.ops.gangealing.*: schemas exist and shape inference works without a GPU (fake tensors)."""
+    import gangealing_amd.op.library  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name in ('upfirdn2d', 'fused_leaky_relu', 'splat2d', 'mipmap_warp'):
+        assert hasattr(torch.ops.gangealing, name)
+    with FakeTensorMode():
+        x = torch.empty(2, 3, 8, 8, device='cuda')
+        k = torch.empty(4, 4, device='cuda')
+        assert torch.ops.gangealing.upfirdn2d(x, k, 2, 1, 2, 1).shape == (2, 3, 16, 16)
+        assert torch.ops.gangealing.upfirdn2d(x, k, 1, 2, 1, 1).shape == (2, 3, 4, 4)
+        assert torch.ops.gangealing.fused_leaky_relu(x, torch.empty(3, device='cuda'), 0.2, 2 ** 0.5).shape == x.shape
+        out, levels = torch.ops.gangealing.mipmap_warp(x, torch.empty(2, 5, 6, 2, device='cuda'), 2.5, 0.0, 'border', True)
+        assert out.shape == (2, 3, 5, 6) and levels.shape == (2, 5, 6)
