@@ -53,6 +53,23 @@ def reference_splat2d(input, coordinates, values, sigma, soft_normalize=False):
     return output / (alpha + 1e-8)
 
 
+def reference_splat_points(images, points, sigma, opacity, colors, alpha_channel=None):
+    """splat_points (utils/vis_tools/helpers.py:134-194) with explicit colours and alpha compositing, on the reference
+    kernel: the lines around its two splat2d calls (:181-186) restated."""
+    n = images.size(0)
+    if points.dim() == 4:
+        points = points.reshape(points.size(0), points.size(1) * points.size(2), 2)
+    if alpha_channel is None:
+        alpha_channel = torch.ones(n, points.size(1), 1, device=images.device)
+    if isinstance(sigma, (float, int)):
+        sigma = torch.tensor(sigma, device=images.device, dtype=torch.float).view(1).repeat(n)
+    blank_img = torch.zeros_like(images)
+    blank_mask = torch.zeros(n, 1, images.size(2), images.size(3), device=images.device)
+    obj = reference_splat2d(blank_img, points, colors, sigma, False)
+    mask = reference_splat2d(blank_mask, points, alpha_channel, sigma, True) * opacity
+    return mask * obj + (1 - mask) * images
+
+
 def make_cases():
     specs = []
     ci = 0

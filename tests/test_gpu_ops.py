@@ -534,3 +534,29 @@ def test_torch_library_ops_run_the_hip_kernels(cuda):
     img = torch.zeros(2, 3, 9, 9, device=cuda)
     torch.testing.assert_close(torch.ops.gangealing.splat2d(img, coords, vals, sigma, False),
                                splat2d(img, coords, vals, sigma, False), atol=1e-6, rtol=1e-5)
+
+
+def test_splat_points_overlay_against_reference_kernel(cuda):
+    """helpers.splat_points (mixed-reality / propagation overlay: two splats + alpha composite) against the same
+    lines evaluated on the compiled reference kernel (when it travelled to this box) and against the restatement."""
+    from gangealing_amd.splat2d_cuda.overlay import splat_points
+    from oracle import make_golden_splat as ref
+    from oracle import np_ops
+    g = torch.Generator().manual_seed(12)
+    n, p, h, w = 2, 300, 48, 64
+    images = (torch.rand(n, 3, h, w, generator=g) * 2 - 1).to(cuda)
+    points = (torch.rand(n, 2, p // 2, 2, generator=g) * torch.tensor([w + 6.0, h + 6.0]) - 3.0).to(cuda)
+    colors = (torch.rand(n, p, 3, generator=g) * 2 - 1).to(cuda)
+    alpha = torch.rand(n, p, 1, generator=g).to(cuda)
+    out = splat_points(images, points, 1.4, 0.8, colors=colors, alpha_channel=alpha)
+    assert out.shape == images.shape
+    pts = points.reshape(n, p, 2).cpu().numpy()
+    sig = np.full((n,), 1.4, np.float32)
+    obj = np_ops.splat2d(np.zeros((n, 3, h, w), np.float32), pts, colors.cpu().numpy(), sig, False)
+    mask = np_ops.splat2d(np.zeros((n, 1, h, w), np.float32), pts, alpha.cpu().numpy(), sig, True) * 0.8
+    np.testing.assert_allclose(out.cpu().numpy(), mask * obj + (1 - mask) * images.cpu().numpy(), atol=2e-5, rtol=1e-4)
+    if ref.reference_available():
+        want = ref.reference_splat_points(images, points, 1.4, 0.8, colors, alpha)
+        assert float((out - want).abs().max()) <= 5e-5
+    with pytest.raises(NotImplementedError):
+        splat_points(images, points, 1.4, 0.8)                       # colour-scale lookup is not part of the package
