@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libgangealing_hip.so')
+# GANGEALING_HIP_LIB selects another build of the same library (kernel A/B measurements); the ABI check still applies.
+LIB_PATH = os.environ.get('GANGEALING_HIP_LIB') or os.path.join(_HERE, 'lib', 'libgangealing_hip.so')
 ABI_VERSION = 1
 NOT_SERVED = -1000            # GG_NOT_SERVED of the header
 

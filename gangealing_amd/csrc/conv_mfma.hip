@@ -311,6 +311,21 @@ __device__ __forceinline__ U4 buffer_load_u4(__amdgpu_buffer_rsrc_t r, unsigned 
 }
 __device__ __forceinline__ float buffer_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voffset, int soffset) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voffset, soffset, 0));
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// stores need dword alignment only; an offset beyond num_records makes the store vanish
+__device__ __forceinline__ void buffer_store_f32x4(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voffset, int soffset) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, v), r, (int)voffset, soffset, 0);
+}
+__device__ __forceinline__ void buffer_store_f32(float v, __amdgpu_buffer_rsrc_t r, unsigned voffset, int soffset) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voffset, soffset, 0);
+}
+// orders one wave's LDS writes before its own later LDS reads (and vice versa) when the lanes exchange data through a
+// region no other wave touches: DS operations of a wave execute in order, so only the compiler has to be held back
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }   // a native vector: a struct here is kept in scratch by the compiler
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
@@ -525,15 +540,19 @@ constexpr int patch_pixels(int tpix) { return (tpix / 64 + 2) * 66; }    // (TH+
 
 // MI = 32-row co sub-tiles per wave: 2 -> 128-channel tiles; 1 -> 64-channel tiles (layers with cout <= 64 would
 // otherwise spend half of their MFMAs on zero rows)
-template <int LIMBS, bool IN_SCALE, int TPIX, int MI = 2, bool MASK = false>
+// TPI = tap slabs staged per barrier interval.  With two or three limbs a tap already carries 24 / 48 MFMAs per wave
+// between its two barriers; with ONE limb (plain bf16) it carries 8, and the barrier pair costs about as much as the
+// MFMAs - so the single-limb instantiations stage a whole row of taps (ky fixed, kx = 0..2) per interval.
+template <int LIMBS, bool IN_SCALE, int TPIX, int MI = 2, bool MASK = false, int TPI = (LIMBS == 1 ? 3 : 1)>
 __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvArgs a, int tw_log2) {
   constexpr int TCO = MI * 64, NJ = 2, NT = TPIX * 2, PWAVES = TPIX / 64;
+  static_assert(9 % TPI == 0, "TPI must divide the 9 taps");
   // 3-limb rows are 240 bytes per pixel: 32-wide tiles ((4+2) x (32+2) patch pixels) keep the block under 80 KB of
   // LDS, i.e. two blocks per CU instead of one
   constexpr int PATCH_MAX = LIMBS == 3 ? 6 * 34 : patch_pixels(TPIX);
   // one LDS arena: [limb][patch rows] then [limb][weight rows]; reused as the epilogue staging buffer (32 x 64
   // floats per wave - with a single limb that is the larger of the two uses)
-  constexpr int MAIN_BYTES = LIMBS * (PATCH_MAX + TCO) * ROWB, STAGE_BYTES = (NT / 64) * 32 * 64 * 4;
+  constexpr int MAIN_BYTES = LIMBS * (PATCH_MAX + TPI * TCO) * ROWB, STAGE_BYTES = (NT / 64) * 32 * 64 * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES];
   unsigned char (*sP)[PATCH_MAX * ROWB] = reinterpret_cast<unsigned char (*)[PATCH_MAX * ROWB]>(smem);
   unsigned char (*sW)[TCO * ROWB] = reinterpret_cast<unsigned char (*)[TCO * ROWB]>(smem + LIMBS * PATCH_MAX * ROWB);
@@ -600,7 +619,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
 
   float xa[BKS], xl = 0.f;
   float xm[MASK ? BKS : 1], xml = 0.f;           // saved activation output at the same positions (MASK)
-  U4 wv[LIMBS][EPT / 8];
+  U4 wv[TPI][LIMBS][EPT / 8];
 
   auto load_patch = [&](int chunk) {
     const int cbase = __builtin_amdgcn_readfirstlane(chunk * BKS * hw * 4);
@@ -654,24 +673,30 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       }
     }
   };
-  auto load_w = [&](int chunk, int t) {
+  // interval i of a chunk covers taps [i * TPI, i * TPI + TPI)
+  auto load_w = [&](int chunk, int interval) {
     if (!w_thr) return;
-    const int soff = __builtin_amdgcn_readfirstlane((t * a.cin_g + chunk * BKS) * 2);
 #pragma unroll
-    for (int l = 0; l < LIMBS; ++l) {
+    for (int u = 0; u < TPI; ++u) {
+      const int soff = __builtin_amdgcn_readfirstlane(((interval * TPI + u) * a.cin_g + chunk * BKS) * 2);
 #pragma unroll
-      for (int q = 0; q < EPT / 8; ++q)
-        wv[l][q] = buffer_load_u4(wr, wvoff, soff + l * wlimb + q * 16);
+      for (int l = 0; l < LIMBS; ++l) {
+#pragma unroll
+        for (int q = 0; q < EPT / 8; ++q)
+          wv[u][l][q] = buffer_load_u4(wr, wvoff, soff + l * wlimb + q * 16);
+      }
     }
   };
   auto store_w = [&]() {
     if (!w_thr) return;
 #pragma unroll
-    for (int l = 0; l < LIMBS; ++l) {
-      U4* wd = reinterpret_cast<U4*>(&sW[l][wrow * ROWB + wpart * EPT * 2]);
+    for (int u = 0; u < TPI; ++u)
 #pragma unroll
-      for (int q = 0; q < EPT / 8; ++q) wd[q] = wv[l][q];
-    }
+      for (int l = 0; l < LIMBS; ++l) {
+        U4* wd = reinterpret_cast<U4*>(&sW[u * LIMBS + l][wrow * ROWB + wpart * EPT * 2]);
+#pragma unroll
+        for (int q = 0; q < EPT / 8; ++q) wd[q] = wv[u][l][q];
+      }
   };
 
   f32x16 acc[MI][NJ];
@@ -699,37 +724,42 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       __syncthreads();                         // previous chunk's readers are done with sP
       store_patch(chunk);
       if (chunk + 1 < chunk1) load_patch(chunk + 1);
-      for (int t = 0; t < 9; ++t) {
+      for (int iv = 0; iv < 9 / TPI; ++iv) {
         store_w();
         __syncthreads();
-        // prefetch the next weight slab (next tap, or tap 0 of the next chunk)
-        if (t + 1 < 9) load_w(chunk, t + 1);
+        // prefetch the next weight slabs (next interval, or interval 0 of the next chunk)
+        if (iv + 1 < 9 / TPI) load_w(chunk, iv + 1);
         else if (chunk + 1 < chunk1) load_w(chunk + 1, 0);
-        const int ky = t / 3, kx = t - ky * 3;
-        const int tapoff = (ky * PW + kx) * ROWB;
 #pragma unroll
-        for (int ks = 0; ks < BKS / 16; ++ks) {
-          bf16x8 fa[LIMBS][MI], fb[LIMBS][NJ];
+        for (int u = 0; u < TPI; ++u) {
+          const int t = iv * TPI + u;
+          const int ky = t / 3, kx = t - ky * 3;
+          const int tapoff = (ky * PW + kx) * ROWB;
 #pragma unroll
-          for (int l = 0; l < LIMBS; ++l) {
+          for (int ks = 0; ks < BKS / 16; ++ks) {
+            bf16x8 fa[LIMBS][MI], fb[LIMBS][NJ];
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-              fa[l][i] = *reinterpret_cast<const bf16x8*>(&sW[l][((wco * MI + i) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-              fb[l][j] = *reinterpret_cast<const bf16x8*>(&sP[l][pbase[j] + tapoff + ks * 32 + kh * 16]);
-          }
-#pragma unroll
-          for (int sum = LIMBS - 1; sum >= 0; --sum)
-#pragma unroll
-            for (int la = 0; la <= sum; ++la) {
-              const int lb = sum - la;
+            for (int l = 0; l < LIMBS; ++l) {
 #pragma unroll
               for (int i = 0; i < MI; ++i)
+                fa[l][i] = *reinterpret_cast<const bf16x8*>(
+                    &sW[u * LIMBS + l][((wco * MI + i) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la][i], fb[lb][j], acc[i][j], 0, 0, 0);
+              for (int j = 0; j < NJ; ++j)
+                fb[l][j] = *reinterpret_cast<const bf16x8*>(&sP[l][pbase[j] + tapoff + ks * 32 + kh * 16]);
             }
+#pragma unroll
+            for (int sum = LIMBS - 1; sum >= 0; --sum)
+#pragma unroll
+              for (int la = 0; la <= sum; ++la) {
+                const int lb = sum - la;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                  for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la][i], fb[lb][j], acc[i][j], 0, 0, 0);
+              }
+          }
         }
         __syncthreads();                       // sW may be overwritten
       }
@@ -781,7 +811,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
         }
         stage[row * 64 + j * 32 + (lane & 31)] = v;
       }
-    __syncthreads();
+    wave_lds_sync();                // the staging rows are this wave's own
     const float anw = (a.act && a.act_noise) ? a.act_noise_w[0] : 0.f;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -805,7 +835,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
         *reinterpret_cast<float4*>(a.y + (size_t)(ochan0 + co) * hw + (size_t)oy * a.w + ox) = v4;
       }
     }
-    __syncthreads();
+    wave_lds_sync();                // the staging rows are this wave's own
   }
 }
 
@@ -1033,6 +1063,19 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
     }
   }
 
+#ifdef GG_EXP_NO_EPILOGUE        // measurement build: main loop only
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[c][j][r];
+    if (t == 1234.5678f) a.y[0] = t;
+    return;
+  }
+#endif
   const bool atomic = a.splitk > 1;
   const int ohw = a.oh * a.ow;
   const int ochan0 = (pn * a.groups + g) * a.cout_g;
@@ -1060,9 +1103,15 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
     }
     return;
   }
-  // interleave the classes through LDS: per pass 8 channels x (2*64) outputs of one output-row parity
-  __syncthreads();
+  // Interleave the classes through LDS: per pass 8 channels x (2*64) outputs of one output-row parity.  Each wave
+  // owns its staging rows, so passes are ordered by wave-level fences only (no block barriers: waves drift apart and
+  // one wave's stores overlap another's LDS traffic).  The two column classes of a q position are adjacent in the
+  // output row: one 8-byte LDS write per lane, 16-byte reads, and 16-byte buffer stores (dword-aligned: the rows of
+  // the (2W+1)-wide output start at odd offsets) - 4x fewer store instructions than the per-dword form.
+  __syncthreads();                                          // sP / sW are dead from here on
   float* stage = reinterpret_cast<float*>(smem) + wid * (8 * 128);
+  const __amdgpu_buffer_rsrc_t yr = uniform_rsrc(a.y + (size_t)ochan0 * ohw, a.cout_g * ohw * 4);
+  const bool vec = tw_log2 > 0;                             // edge tiles (one q column): scalar stores
 #pragma unroll
   for (int py = 0; py < 2; ++py) {
 #pragma unroll
@@ -1078,23 +1127,46 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
           if (bia) bi = bia[co];
         }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int px = 0; px < 2; ++px)
-            stage[lrow * 128 + (j * 32 + l31) * 2 + px] = acc[py * 2 + px][j][r] * sc + bi;
+        for (int j = 0; j < NJ; ++j) {
+          float2 v2;
+          v2.x = acc[py * 2 + 0][j][r] * sc + bi;
+          v2.y = acc[py * 2 + 1][j][r] * sc + bi;
+          *reinterpret_cast<float2*>(stage + lrow * 128 + (j * 32 + l31) * 2) = v2;
+        }
       }
-      __syncthreads();
+      wave_lds_sync();
+      if (vec) {
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int idx = it * 64 + lane;
-        const int lrow = idx >> 7, s = idx & 127;
-        const int p = wpix * 64 + (s >> 1);
-        const int oy = 2 * (y0 + (p >> tw_log2)) + py - pad, ox = 2 * (x0 + (p & (TW - 1))) + (s & 1) - pad;
-        const int co = co0 + wco * 32 + lrow + 8 * q4;
-        if (co < a.cout_g && (unsigned)oy < (unsigned)a.oh && (unsigned)ox < (unsigned)a.ow)
-          a.y[(size_t)(ochan0 + co) * ohw + (size_t)oy * a.ow + ox] = stage[lrow * 128 + s];
+        for (int it = 0; it < 4; ++it) {
+          const int idx = it * 64 + lane;
+          const int lrow = idx >> 5, s = (idx & 31) * 4;
+          const f32x4 v4 = *reinterpret_cast<const f32x4*>(stage + lrow * 128 + s);
+          const int p = wpix * 64 + (s >> 1);
+          const int oy = 2 * (y0 + (p >> tw_log2)) + py - pad, ox = 2 * (x0 + (p & (TW - 1))) - pad;
+          const int co = co0 + wco * 32 + lrow + 8 * q4;
+          const bool rowok = co < a.cout_g && (unsigned)oy < (unsigned)a.oh;
+          const unsigned off = (unsigned)(co * ohw + oy * a.ow + ox) * 4u;
+          if (rowok && ox >= 0 && ox + 3 < a.ow) {
+            buffer_store_f32x4(v4, yr, off, 0);
+          } else if (rowok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              buffer_store_f32(v4[e], yr, (unsigned)(ox + e) < (unsigned)a.ow ? off + 4u * e : kOobOffset, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int idx = it * 64 + lane;
+          const int lrow = idx >> 7, s = idx & 127;
+          const int p = wpix * 64 + (s >> 1);
+          const int oy = 2 * (y0 + (p >> tw_log2)) + py - pad, ox = 2 * (x0 + (p & (TW - 1))) + (s & 1) - pad;
+          const int co = co0 + wco * 32 + lrow + 8 * q4;
+          if (co < a.cout_g && (unsigned)oy < (unsigned)a.oh && (unsigned)ox < (unsigned)a.ow)
+            a.y[(size_t)(ochan0 + co) * ohw + (size_t)oy * a.ow + ox] = stage[lrow * 128 + s];
+        }
       }
-      __syncthreads();
+      wave_lds_sync();
     }
   }
 }
@@ -1980,6 +2052,25 @@ int post_activation(const ConvArgs& a, hipStream_t st) {
                                a.groups * a.cout_g, (long long)a.oh * a.ow, st);
 }
 
+// split-K threshold of the patch kernels: a launch with fewer blocks than this is split along Cin until it has about
+// that many.  (GG_SPLIT_PATCH / GG_SPLIT_CONVT: measurement overrides.)
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+static int split_at_patch() {
+  static const int v = env_int("GG_SPLIT_PATCH", 2 * gg::kNumCu);
+  return v;
+}
+// The transposed kernel's split-K epilogue is four classes of scattered atomics onto a zero-filled output, so it only
+// pays when most of the chip would otherwise idle.  Measured per generator pass at batch 16 (512 -> 512 channels):
+// 16^2 -> 33^2 (384 blocks) 0.308 ms split in two vs 0.143 unsplit; 8^2 -> 17^2 (192 blocks) 0.154 vs 0.124;
+// 4^2 -> 9^2 (128 blocks) 0.093 split vs 0.121 unsplit.
+static int split_at_convt() {
+  static const int v = env_int("GG_SPLIT_CONVT", 3 * gg::kNumCu / 4);
+  return v;
+}
+
 // 3x3 / stride 1 / pad 1 with a power-of-two width >= 16 whose 128-pixel tiles fit the image
 bool patch_geometry(const ConvArgs& a, int tpix, int& tw_log2, int limbs = 2) {
   const int w = a.w, h = a.h;
@@ -2004,8 +2095,8 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
   a.nslabs = a.cin_g / BKS;
   const long long blocks = tp * a.tiles_co * a.groups;
   int splitk = 1;
-  if (blocks < 2 * gg::kNumCu) {
-    splitk = (int)((2 * gg::kNumCu + blocks - 1) / blocks);
+  if (blocks < split_at_patch()) {
+    splitk = (int)((split_at_patch() + blocks - 1) / blocks);
     if (splitk > a.nslabs) splitk = a.nslabs;
     if (splitk < 1) splitk = 1;
   }
@@ -2070,7 +2161,8 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   int tiles_y, edge;
   int tq = 128;
   long long tp = tiles_for(tq, tiles_y, edge);
-  if (limbs > 2 || tp * a.tiles_co * a.groups < 2 * gg::kNumCu) {
+  static const bool force64 = getenv("GG_CONVT_TQ64") != nullptr;     // measurement switch
+  if (force64 || limbs > 2 || tp * a.tiles_co * a.groups < 2 * gg::kNumCu) {
     tq = 64;
     tp = tiles_for(tq, tiles_y, edge);
   }
@@ -2079,8 +2171,8 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   a.nslabs = a.cin_g / BKS;
   const long long blocks = tp * a.tiles_co * a.groups;
   int splitk = 1;
-  if (blocks < 2 * gg::kNumCu) {
-    splitk = (int)((2 * gg::kNumCu + blocks - 1) / blocks);
+  if (blocks < split_at_convt()) {
+    splitk = (int)((gg::kNumCu + blocks - 1) / blocks);
     if (splitk > a.nslabs) splitk = a.nslabs;
     if (splitk < 1) splitk = 1;
   }
@@ -2119,7 +2211,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     return kNotFused;
   }
   if (!a.act && limbs && KS == 3 && mode == 1 && pad <= 1 && a.w >= 4 && (a.w & (a.w - 1)) == 0 &&
-      (long long)a.cin_g * a.h * a.w * 4 < (1LL << 31))
+      (long long)a.cin_g * a.h * a.w * 4 < (1LL << 31) && (long long)a.cout_g * a.oh * a.ow * 4 < (1LL << 31))
     return launch_convT_patch(a, limbs, pad, st);
   if (limbs && KS == 3 && mode == 0 && stride == 1 && pad == 1) {
     int tw_log2;
