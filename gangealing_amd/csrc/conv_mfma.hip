@@ -547,12 +547,16 @@ template <int LIMBS, bool IN_SCALE, int TPIX, int MI = 2, bool MASK = false, int
 __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvArgs a, int tw_log2) {
   constexpr int TCO = MI * 64, NJ = 2, NT = TPIX * 2, PWAVES = TPIX / 64;
   static_assert(9 % TPI == 0, "TPI must divide the 9 taps");
+  // PIPE: the 8-wave tile (alone on its CU) double-buffers the weight slab and software-pipelines the tap loop - see
+  // the main loop.  The 4-wave tiles keep one slab: two of their blocks share a CU and fill each other's stalls.
+  constexpr bool PIPE = (TPIX == 256 && TPI == 1);
+  constexpr int WBUF = PIPE ? 2 : 1;
   // 3-limb rows are 240 bytes per pixel: 32-wide tiles ((4+2) x (32+2) patch pixels) keep the block under 80 KB of
   // LDS, i.e. two blocks per CU instead of one
   constexpr int PATCH_MAX = LIMBS == 3 ? 6 * 34 : patch_pixels(TPIX);
   // one LDS arena: [limb][patch rows] then [limb][weight rows]; reused as the epilogue staging buffer (32 x 64
   // floats per wave - with a single limb that is the larger of the two uses)
-  constexpr int MAIN_BYTES = LIMBS * (PATCH_MAX + TPI * TCO) * ROWB, STAGE_BYTES = (NT / 64) * 32 * 64 * 4;
+  constexpr int MAIN_BYTES = LIMBS * (PATCH_MAX + WBUF * TPI * TCO) * ROWB, STAGE_BYTES = (NT / 64) * 32 * 64 * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES];
   unsigned char (*sP)[PATCH_MAX * ROWB] = reinterpret_cast<unsigned char (*)[PATCH_MAX * ROWB]>(smem);
   unsigned char (*sW)[TCO * ROWB] = reinterpret_cast<unsigned char (*)[TCO * ROWB]>(smem + LIMBS * PATCH_MAX * ROWB);
@@ -687,13 +691,13 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       }
     }
   };
-  auto store_w = [&]() {
+  auto store_w = [&](int buf) {
     if (!w_thr) return;
 #pragma unroll
     for (int u = 0; u < TPI; ++u)
 #pragma unroll
       for (int l = 0; l < LIMBS; ++l) {
-        U4* wd = reinterpret_cast<U4*>(&sW[u * LIMBS + l][wrow * ROWB + wpart * EPT * 2]);
+        U4* wd = reinterpret_cast<U4*>(&sW[(buf * TPI + u) * LIMBS + l][wrow * ROWB + wpart * EPT * 2]);
 #pragma unroll
         for (int q = 0; q < EPT / 8; ++q) wd[q] = wv[u][l][q];
       }
@@ -720,12 +724,85 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   if (chunk0 < chunk1) {
     load_patch(chunk0);
     load_w(chunk0, 0);
+    if constexpr (PIPE) {
+      // Software-pipelined tap loop (BKS = 32: two k-steps per tap).  Tap t reads weight buffer t & 1 while slab t + 1
+      // is written to the other one, so ONE barrier per tap both publishes slab t + 1 and retires buffer t & 1; the
+      // fragments of a tap's first k-step are fetched right after the previous tap's barrier and those of its second
+      // k-step before its own, so every LDS fetch has 12 MFMAs (per wave; 24 per SIMD) in front of the instruction
+      // that needs it.  With one slab and two barriers per tap the first MFMAs after each barrier waited for the
+      // LDS round trip with nothing queued on the matrix pipe: SQ_WAIT_ANY was 32 % of the wave cycles and the pipe
+      // 61 % busy inside the main loop.
+      typedef bf16x8 FragA[LIMBS][MI];
+      typedef bf16x8 FragB[LIMBS][NJ];
+      FragA fa0, fa1;
+      FragB fb0, fb1;
+      auto read_frag = [&](FragA& fa, FragB& fb, int buf, int tapoff, int ks) {
+#pragma unroll
+        for (int l = 0; l < LIMBS; ++l) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+            fa[l][i] = *reinterpret_cast<const bf16x8*>(
+                &sW[buf * LIMBS + l][((wco * MI + i) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            fb[l][j] = *reinterpret_cast<const bf16x8*>(&sP[l][pbase[j] + tapoff + ks * 32 + kh * 16]);
+        }
+      };
+      auto mma = [&](const FragA& fa, const FragB& fb) {
+#pragma unroll
+        for (int sum = LIMBS - 1; sum >= 0; --sum)
+#pragma unroll
+          for (int la = 0; la <= sum; ++la) {
+            const int lb = sum - la;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la][i], fb[lb][j], acc[i][j], 0, 0, 0);
+          }
+      };
+      for (int chunk = chunk0; chunk < chunk1; ++chunk) {
+        // here: every wave is past the barrier that followed its last LDS fetch of the previous chunk (or at kernel
+        // start); registers hold this chunk's patch and its tap-0 slab
+        store_patch(chunk);
+        store_w(0);
+        load_w(chunk, 1);
+        if (chunk + 1 < chunk1) load_patch(chunk + 1);
+        __syncthreads();
+        read_frag(fa0, fb0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int buf = t & 1;
+          const int ky = t / 3, kx = t - ky * 3;
+          const int tapoff = (ky * PW + kx) * ROWB;
+          if (t < 8) {
+            store_w(buf ^ 1);                                    // slab t + 1
+            if (t + 2 < 9) load_w(chunk, t + 2);
+            else if (chunk + 1 < chunk1) load_w(chunk + 1, 0);
+          }
+          read_frag(fa1, fb1, buf, tapoff, 1);
+          // (the scheduler otherwise sinks each fetch down to its first use to shorten the live ranges, which puts
+          // the LDS round trip back in front of the MFMAs)
+          __builtin_amdgcn_sched_barrier(0);
+          mma(fa0, fb0);
+          __builtin_amdgcn_sched_barrier(0);
+          __syncthreads();
+          if (t < 8) {
+            const int t1 = t + 1, ky1 = t1 / 3, kx1 = t1 - ky1 * 3;
+            read_frag(fa0, fb0, buf ^ 1, (ky1 * PW + kx1) * ROWB, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mma(fa1, fb1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
       __syncthreads();                         // previous chunk's readers are done with sP
       store_patch(chunk);
       if (chunk + 1 < chunk1) load_patch(chunk + 1);
       for (int iv = 0; iv < 9 / TPI; ++iv) {
-        store_w();
+        store_w(0);
         __syncthreads();
         // prefetch the next weight slabs (next interval, or interval 0 of the next chunk)
         if (iv + 1 < 9 / TPI) load_w(chunk, iv + 1);
@@ -764,8 +841,22 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
         __syncthreads();                       // sW may be overwritten
       }
     }
+    }
   }
 
+#ifdef GG_EXP_NO_EPILOGUE        // measurement build: main loop only
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 1234.5678f) a.y[0] = t;
+    return;
+  }
+#endif
   const bool atomic = a.splitk > 1;
   const int ochan0 = (pn * a.groups + g) * a.cout_g;
   const float* osc = a.out_scale ? a.out_scale + ochan0 : nullptr;
@@ -2058,6 +2149,13 @@ static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
+// 256-pixel (8-wave, one block per CU) tiles halve the weight stream per output, which pays once the reduction is
+// deep; with <= 64 input channels a tile's main loop is two chunks long and two co-resident 128-pixel blocks hide
+// each other's prologue / epilogue instead (64 -> 64 @128^2, batch 16: 80 vs 69 us)
+static int patch256_min_cin() {
+  static const int v = env_int("GG_PATCH256_MIN_CIN", 64);
+  return v;
+}
 static int split_at_patch() {
   static const int v = env_int("GG_SPLIT_PATCH", 2 * gg::kNumCu);
   return v;
@@ -2206,7 +2304,8 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     int tw_log2;
     if (!((limbs == 1 || limbs == 2) && KS == 3 && mode == 0 && stride == 1 && pad == 1)) return kNotFused;
     const long long tiles256 = (long long)a.batch * a.oh * a.ow / 256 * ((a.cout_g + 127) / 128) * a.groups;
-    if (tiles256 >= 2 * gg::kNumCu && patch_geometry(a, 256, tw_log2)) return launch_conv_patch(a, limbs, tw_log2, 256, st);
+    if (tiles256 >= 2 * gg::kNumCu && a.cin_g > patch256_min_cin() && patch_geometry(a, 256, tw_log2))
+      return launch_conv_patch(a, limbs, tw_log2, 256, st);
     if (patch_geometry(a, 128, tw_log2)) return launch_conv_patch(a, limbs, tw_log2, 128, st);
     return kNotFused;
   }
@@ -2217,7 +2316,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     int tw_log2;
     // 256-pixel tiles when they still fill the chip (>= 2 blocks per CU), else 128-pixel tiles
     const long long tiles256 = (long long)a.batch * a.oh * a.ow / 256 * ((a.cout_g + 127) / 128) * a.groups;
-    if (limbs <= 2 && tiles256 >= 2 * gg::kNumCu && patch_geometry(a, 256, tw_log2))
+    if (limbs <= 2 && tiles256 >= 2 * gg::kNumCu && a.cin_g > patch256_min_cin() && patch_geometry(a, 256, tw_log2))
       return launch_conv_patch(a, limbs, tw_log2, 256, st);
     if (patch_geometry(a, 128, tw_log2, limbs)) return launch_conv_patch(a, limbs, tw_log2, 128, st);
   }

@@ -483,7 +483,12 @@ def test_generator_fusions_do_not_change_the_image(cuda):
     img_on, g_on = run(())
     img_off, g_off = run(('style_bank', 'torgb_bias', 'noise_bank'))
     torch.testing.assert_close(img_on, img_off, atol=2e-5, rtol=1e-5)
-    torch.testing.assert_close(g_on, g_off, atol=1e-6 + 1e-4 * float(g_off.abs().max()), rtol=0)
+    # the two runs differ by fp32 rounding (different kernels carry the bias / the adds), which the split-K atomics'
+    # run-to-run ordering also produces; a leaky-ReLU input that lands on the other side of zero turns that into a
+    # visible gradient entry, so the gradient is compared in L2 with a bounded worst entry
+    scale = float(g_off.abs().max())
+    assert float((g_on - g_off).norm() / g_off.norm()) < 1e-3
+    assert float((g_on - g_off).abs().max()) < 1e-6 + 5e-3 * scale
     assert float(g_on[:, 4:].abs().max()) == 0.0 and float(g_on[:, :4].abs().max()) > 0
 
 
