@@ -20,11 +20,14 @@ NOT_SERVED = -1000            # GG_NOT_SERVED of the header
 _PROTOS = {
     'gg_fused_bias_act_f32': 'ppppiiffqqis',
     'gg_fused_bias_act_f64': 'ppppiiddqqis',
+    'gg_fused_bias_act_f16': 'ppppiiffqqis',
     'gg_fused_lrelu_bwd_f32': 'ppppffiiqs',
     'gg_fused_lrelu_bwd_f64': 'ppppddiiqs',
+    'gg_fused_lrelu_bwd_f16': 'ppppffiiqs',
     'gg_noise_bias_act_f32': 'pppppffiiqs',
     'gg_upfirdn2d_f32': 'pppiiiiiiiiiiiiis',
     'gg_upfirdn2d_f64': 'pppiiiiiiiiiiiiis',
+    'gg_upfirdn2d_f16': 'pppiiiiiiiiiiiiis',
     'gg_blur4_fused_f32': 'pppiiiiiiiippppffs',
     'gg_splat_forward_f32': 'pppppiiiiis',
     'gg_splat2d_f32': 'ppppppiiiiiis',

@@ -86,6 +86,60 @@ __global__ __launch_bounds__(256) void fused_lrelu_bwd_kernel(
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// binary16 tensors (the reference dispatches half, fused_bias_act_kernel.cu:89): fp32 arithmetic, one rounding per
+// element.  VEC = 8: 16 bytes per lane, all 8 elements under one bias entry.
+typedef _Float16 h16;
+struct H8 { h16 v[8]; };
+template <int VEC>
+__global__ __launch_bounds__(256) void fused_bias_act_f16_kernel(h16* __restrict__ out, const h16* __restrict__ x,
+                                                                 const h16* __restrict__ b, const h16* __restrict__ ref,
+                                                                 int mode, float alpha, float scale, long long n_items,
+                                                                 long long step_b, int size_b) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += stride) {
+    const long long e = i * VEC;
+    const float bias = b ? (float)b[(e / step_b) % size_b] : 0.f;
+    if (VEC == 8) {
+      const H8 xv = *reinterpret_cast<const H8*>(x + e);
+      H8 rv;
+      if (ref) rv = *reinterpret_cast<const H8*>(ref + e);
+      H8 yv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        yv.v[j] = (h16)act_apply<float>((float)xv.v[j] + bias, ref ? (float)rv.v[j] : 0.f, mode, alpha, scale);
+      *reinterpret_cast<H8*>(out + e) = yv;
+    } else {
+      out[e] = (h16)act_apply<float>((float)x[e] + bias, ref ? (float)ref[e] : 0.f, mode, alpha, scale);
+    }
+  }
+}
+
+// grid = (splits, C) as fused_lrelu_bwd_kernel; the bias gradient is accumulated in fp32
+__global__ __launch_bounds__(256) void fused_lrelu_bwd_f16_kernel(h16* __restrict__ gin, float* __restrict__ gbias,
+                                                                  const h16* __restrict__ gout,
+                                                                  const h16* __restrict__ outv, float alpha, float scale,
+                                                                  int n, int c, long long hw, long long chunk) {
+  __shared__ float red[4];
+  const int ch = blockIdx.y;
+  const long long lo = (long long)blockIdx.x * chunk;
+  long long hi = lo + chunk;
+  if (hi > hw) hi = hw;
+  float acc = 0.f;
+  for (int s = 0; s < n; ++s) {
+    const long long base = ((long long)s * c + ch) * hw;
+    for (long long p = lo + threadIdx.x; p < hi; p += 256) {
+      const float g = (float)gout[base + p], o = (float)outv[base + p];
+      const h16 r = (h16)(((o > 0.f) ? g : g * alpha) * scale);
+      gin[base + p] = r;
+      acc += (float)r;                 // the reference sums the rounded grad_input (fused_act.py:33-38)
+    }
+  }
+  if (gbias) {
+    const float tot = gg::block_sum_256<float>(acc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(gbias + ch, tot);
+  }
+}
+
 // StyledConv tail in one pass (networks.py:291-298,344-350): y = lrelu(x + nw * noise[n,0,hw] + b[c]) * scale.
 // 12 B/elem of the big tensor instead of 3 passes (mul, add, activation).
 __global__ __launch_bounds__(256) void noise_bias_act_kernel(float* __restrict__ out, const float* __restrict__ x,
@@ -176,6 +230,50 @@ extern "C" int gg_fused_bias_act_f64(double* out, const double* x, const double*
                                      int grad, double alpha, double scale, long long size_x, long long step_b,
                                      int size_b, void* stream) {
   return fused_bias_act_impl<double>(out, x, bias, ref, act, grad, alpha, scale, size_x, step_b, size_b, stream);
+}
+extern "C" int gg_fused_bias_act_f16(unsigned short* out, const unsigned short* x, const unsigned short* bias,
+                                     const unsigned short* ref, int act, int grad, float alpha, float scale,
+                                     long long size_x, long long step_b, int size_b, void* stream) {
+  if (size_x == 0) return 0;
+  if (size_x < 0 || !out || !x) return gg::fail(-2, "fused_bias_act: bad arguments");
+  if (bias && (step_b <= 0 || size_b <= 0)) return gg::fail(-2, "fused_bias_act: bias needs step_b, size_b > 0");
+  const int mode = act * 10 + grad;
+  const bool vec = (size_x % 8 == 0) && (!bias || step_b % 8 == 0) && aligned16(out) && aligned16(x) &&
+                   (!ref || aligned16(ref));
+  hipStream_t st = gg::as_stream(stream);
+  h16* o = reinterpret_cast<h16*>(out);
+  const h16 *xi = reinterpret_cast<const h16*>(x), *bi = reinterpret_cast<const h16*>(bias),
+            *ri = reinterpret_cast<const h16*>(ref);
+  if (vec)
+    fused_bias_act_f16_kernel<8><<<gg::stream_grid(size_x / 8, 256), 256, 0, st>>>(o, xi, bi, ri, mode, alpha, scale,
+                                                                                   size_x / 8, step_b, size_b);
+  else
+    fused_bias_act_f16_kernel<1><<<gg::stream_grid(size_x, 256), 256, 0, st>>>(o, xi, bi, ri, mode, alpha, scale, size_x,
+                                                                               step_b, size_b);
+  return gg::launch_status("fused_bias_act");
+}
+extern "C" int gg_fused_lrelu_bwd_f16(unsigned short* grad_in, float* grad_bias, const unsigned short* grad_out,
+                                      const unsigned short* out, float alpha, float scale, int n, int c, long long hw,
+                                      void* stream) {
+  if (n <= 0 || c <= 0 || hw <= 0) return 0;
+  if (!grad_in || !grad_out || !out) return gg::fail(-2, "fused_lrelu_bwd: null pointer");
+  if (c > 65535) return gg::fail(-2, "fused_lrelu_bwd: more than 65535 channels");
+  hipStream_t st = gg::as_stream(stream);
+  if (grad_bias) {
+    hipError_t e = hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)c, st);
+    if (e != hipSuccess) return gg::fail((int)e, "fused_lrelu_bwd: memset failed");
+  }
+  long long splits = (2048 + c - 1) / c;
+  const long long max_splits = (hw + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const long long chunk = (hw + splits - 1) / splits;
+  splits = (hw + chunk - 1) / chunk;
+  dim3 grid((unsigned)splits, (unsigned)c);
+  fused_lrelu_bwd_f16_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<h16*>(grad_in), grad_bias,
+                                                   reinterpret_cast<const h16*>(grad_out),
+                                                   reinterpret_cast<const h16*>(out), alpha, scale, n, c, hw, chunk);
+  return gg::launch_status("fused_lrelu_bwd");
 }
 extern "C" int gg_noise_bias_act_f32(float* out, const float* x, const float* noise, const float* noise_weight,
                                      const float* bias, float alpha, float scale, int n, int c, long long hw,

@@ -317,12 +317,14 @@ int launch_blur4(float* out, const float* in, const float* kernel, long long pla
 
 constexpr int MAX_LDS_TAPS = 1024;
 
-template <typename T>
+// K = tap / accumulator type: T itself for float and double; float for binary16 tensors (the reference's kernel
+// accumulates in scalar_t, upfirdn2d_kernel.cu:191-201; one rounding at the end is the tighter result)
+template <typename T, typename K = T>
 __global__ __launch_bounds__(256) void upfirdn2d_direct(
-    T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ kernel,
+    T* __restrict__ out, const T* __restrict__ in, const K* __restrict__ kernel,
     long long total, int in_h, int in_w, int out_h, int out_w, int kh, int kw,
     int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_y0, const T* __restrict__ addend = nullptr) {
-  __shared__ T sk[MAX_LDS_TAPS];
+  __shared__ K sk[MAX_LDS_TAPS];
   const bool lds_taps = kh * kw <= MAX_LDS_TAPS;
   if (lds_taps) {
     for (int i = threadIdx.x; i < kh * kw; i += 256) {
@@ -343,17 +345,17 @@ __global__ __launch_bounds__(256) void upfirdn2d_direct(
     const int tx0 = ix0 * up_x + pad_x0 - ox * down_x;
     const int ty0 = iy0 * up_y + pad_y0 - oy * down_y;
     const T* src = in + (size_t)plane * in_h * in_w;
-    T acc = T(0);
+    K acc = K(0);
     for (int ty = ty0, iy = iy0; ty < kh; ty += up_y, ++iy) {
       if (iy < 0 || iy >= in_h) continue;
       for (int tx = tx0, ix = ix0; tx < kw; tx += up_x, ++ix) {
         if (ix < 0 || ix >= in_w) continue;
-        const T kv = lds_taps ? sk[ty * kw + tx] : kernel[(kh - 1 - ty) * kw + (kw - 1 - tx)];
-        acc += src[(size_t)iy * in_w + ix] * kv;
+        const K kv = lds_taps ? sk[ty * kw + tx] : kernel[(kh - 1 - ty) * kw + (kw - 1 - tx)];
+        acc += K(src[(size_t)iy * in_w + ix]) * kv;
       }
     }
-    if (addend) acc += addend[o];
-    out[o] = acc;
+    if (addend) acc += K(addend[o]);
+    out[o] = T(acc);
   }
 }
 
@@ -424,6 +426,23 @@ extern "C" int gg_blur4_fused_f32(float* out, const float* in, const float* kern
   if (epi) return launch_blur4<true, false>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
   if (pro) return launch_blur4<false, true>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
   return launch_blur4<false, false>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+}
+// binary16 tensors (the reference dispatches half, upfirdn2d_kernel.cu:311); taps stay fp32
+extern "C" int gg_upfirdn2d_f16(unsigned short* out, const unsigned short* in, const float* kernel, int major, int in_h,
+                                int in_w, int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y,
+                                int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+  if (up_x < 1 || up_y < 1 || down_x < 1 || down_y < 1 || kernel_h < 1 || kernel_w < 1 || major < 0 || in_h < 0 ||
+      in_w < 0)
+    return gg::fail(-2, "upfirdn2d: bad arguments");
+  const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kernel_h + down_y) / down_y;
+  const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w + down_x) / down_x;
+  if (out_h <= 0 || out_w <= 0 || major == 0) return 0;
+  if (!out || !in || !kernel) return gg::fail(-2, "upfirdn2d: null pointer");
+  const long long total = (long long)major * out_h * out_w;
+  upfirdn2d_direct<_Float16, float><<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(
+      reinterpret_cast<_Float16*>(out), reinterpret_cast<const _Float16*>(in), kernel, total, in_h, in_w, out_h, out_w,
+      kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0);
+  return gg::launch_status("upfirdn2d_direct");
 }
 extern "C" int gg_upfirdn2d_f64(double* out, const double* in, const double* kernel, int major, int in_h, int in_w,
                                 int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0,

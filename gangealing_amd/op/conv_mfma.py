@@ -375,37 +375,44 @@ class _Conv2d(Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        stride, padding, groups, transposed, output_padding, has_bias, cin_g, cout_g, k, wscale = ctx.conf
-        dy = dy.contiguous()
-        batch = x.shape[0]
-        h, w = x.shape[-2:]
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            if not transposed:
-                if stride == 1:
-                    wm = packed(weight, groups, cin_g, cout_g, k, 1, 1, wscale)
-                    dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, k - 1 - padding, 0)
-                else:
-                    wm = packed(weight, groups, cin_g, cout_g, k, 1, 0, wscale)
-                    dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 1, out_hw=(h, w))
-            else:
-                if stride == 1:
-                    wm = packed(weight, groups, cin_g, cout_g, k, 0, 0, wscale)
-                    dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, padding, 0)
-                else:
-                    wm = packed(weight, groups, cin_g, cout_g, k, 0, 0, wscale)
-                    dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 0)
-                    dx = dx[..., :h, :w].contiguous() if dx.shape[-2:] != (h, w) else dx
-        if ctx.needs_input_grad[1]:
-            slot = _slot_for(weight)
-            if not transposed:
-                dw = conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, padding, wscale, into=slot)
-            else:
-                # dW[ci,co,ky,kx] = sum x[ci,i] * dy[co, i*s + k - p]: a mode-0 weight gradient with roles swapped
-                dw = conv_wgrad(dy, x, batch, groups, cout_g, cin_g, k, stride, padding, wscale, into=slot)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum(dim=(0, 2, 3))
+        dx, dw, db = conv2d_backward(x, weight, dy, ctx.conf, ctx.needs_input_grad[:3])
         return dx, dw, db, None, None, None, None, None, None
+
+
+def conv2d_backward(x, weight, dy, conf, needs):
+    """Data / weight / bias gradients of _Conv2d (also the autograd formula of torch.ops.gangealing.conv2d /
+    conv_transpose2d, op/library.py).  conf as saved by _Conv2d.forward; needs = (dx, dw, db) wanted."""
+    stride, padding, groups, transposed, output_padding, has_bias, cin_g, cout_g, k, wscale = conf
+    dy = dy.contiguous()
+    batch = x.shape[0]
+    h, w = x.shape[-2:]
+    dx = dw = db = None
+    if needs[0]:
+        if not transposed:
+            if stride == 1:
+                wm = packed(weight, groups, cin_g, cout_g, k, 1, 1, wscale)
+                dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, k - 1 - padding, 0)
+            else:
+                wm = packed(weight, groups, cin_g, cout_g, k, 1, 0, wscale)
+                dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 1, out_hw=(h, w))
+        else:
+            if stride == 1:
+                wm = packed(weight, groups, cin_g, cout_g, k, 0, 0, wscale)
+                dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, padding, 0)
+            else:
+                wm = packed(weight, groups, cin_g, cout_g, k, 0, 0, wscale)
+                dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 0)
+                dx = dx[..., :h, :w].contiguous() if dx.shape[-2:] != (h, w) else dx
+    if needs[1]:
+        slot = _slot_for(weight)
+        if not transposed:
+            dw = conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, padding, wscale, into=slot)
+        else:
+            # dW[ci,co,ky,kx] = sum x[ci,i] * dy[co, i*s + k - p]: a mode-0 weight gradient with roles swapped
+            dw = conv_wgrad(dy, x, batch, groups, cout_g, cin_g, k, stride, padding, wscale, into=slot)
+    if has_bias and needs[2]:
+        db = dy.sum(dim=(0, 2, 3))
+    return dx, dw, db
 
 
 class _Conv3x3BiasAct(Function):

@@ -12,7 +12,7 @@ from torch.autograd import Function
 
 from .. import _lib
 
-_SUFFIX = {torch.float32: 'f32', torch.float64: 'f64'}
+_SUFFIX = {torch.float32: 'f32', torch.float64: 'f64', torch.float16: 'f16'}
 
 
 def _bias_act(x, bias, ref, act, grad, alpha, scale):
@@ -42,10 +42,11 @@ class FusedLeakyReLUFunctionBackward(Function):
         n, c = out.shape[0], out.shape[1]
         hw = out.numel() // max(n * c, 1)
         grad_input = torch.empty_like(grad_output)
-        grad_bias = torch.empty(c, dtype=out.dtype, device=out.device)
+        # half tensors: the kernel accumulates the bias gradient in an fp32 buffer
+        grad_bias = torch.empty(c, dtype=torch.float32 if out.dtype == torch.float16 else out.dtype, device=out.device)
         _lib.call('gg_fused_lrelu_bwd_' + _SUFFIX[out.dtype], grad_input, grad_bias, grad_output, out,
                   negative_slope, scale, n, c, hw)
-        return grad_input, grad_bias
+        return grad_input, grad_bias.to(out.dtype)
 
     @staticmethod
     def backward(ctx, gradgrad_input, gradgrad_bias):

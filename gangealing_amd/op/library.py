@@ -115,12 +115,81 @@ def _warp_fake(inputs, grid, max_level, min_level, padding_mode, antialias):
     return inputs.new_empty((n, c, ho, wo)), inputs.new_empty((n, ho, wo))
 
 
+# ---- conv2d / conv_transpose2d (conv2d_gradfix.py:22-75): the implicit-GEMM MFMA convolutions -------------------
+# (the autograd formula is conv_mfma.conv2d_backward: data and weight gradients are further HIP launches)
+_define('conv2d(Tensor input, Tensor weight, Tensor? bias, int stride, int padding, int groups) -> Tensor')
+_define('conv_transpose2d(Tensor input, Tensor weight, Tensor? bias, int stride, int padding, int output_padding, '
+        'int groups) -> Tensor')
+
+
+def _conv2d_impl(input, weight, bias, stride, padding, groups):
+    from . import conv_mfma
+    with torch.no_grad():
+        return conv_mfma.conv2d(input, weight, bias, stride, padding, 1, groups)
+
+
+def _conv_conf(weight, bias, stride, padding, groups, transposed, output_padding):
+    k = weight.shape[-1]
+    if transposed:
+        cin_g, cout_g = weight.shape[0] // groups, weight.shape[1]
+    else:
+        cin_g, cout_g = weight.shape[1], weight.shape[0] // groups
+    return (stride, padding, groups, transposed, output_padding, bias is not None, cin_g, cout_g, k, 1.0)
+
+
+def _conv2d_setup(ctx, inputs, output):
+    input, weight, bias, stride, padding, groups = inputs
+    ctx.save_for_backward(input, weight)
+    ctx.conf = _conv_conf(weight, bias, stride, padding, groups, False, 0)
+
+
+def _convT_setup(ctx, inputs, output):
+    input, weight, bias, stride, padding, output_padding, groups = inputs
+    ctx.save_for_backward(input, weight)
+    ctx.conf = _conv_conf(weight, bias, stride, padding, groups, True, output_padding)
+
+
+def _conv2d_backward(ctx, grad):
+    from . import conv_mfma
+    x, weight = ctx.saved_tensors
+    dx, dw, db = conv_mfma.conv2d_backward(x.contiguous(), weight.contiguous(), grad, ctx.conf, ctx.needs_input_grad[:3])
+    return (dx, dw, db) + (None,) * (4 if ctx.conf[3] else 3)
+
+
+def _conv2d_fake(input, weight, bias, stride, padding, groups):
+    n, _, h, w = input.shape
+    k = weight.shape[-1]
+    return input.new_empty((n, weight.shape[0], (h + 2 * padding - k) // stride + 1, (w + 2 * padding - k) // stride + 1))
+
+
+def _convT_impl(input, weight, bias, stride, padding, output_padding, groups):
+    from . import conv_mfma
+    with torch.no_grad():
+        return conv_mfma.conv_transpose2d(input, weight, bias, stride, padding, output_padding, groups)
+
+
+def _convT_fake(input, weight, bias, stride, padding, output_padding, groups):
+    n, _, h, w = input.shape
+    k = weight.shape[-1]
+    return input.new_empty((n, weight.shape[1] * groups, (h - 1) * stride - 2 * padding + k + output_padding,
+                            (w - 1) * stride - 2 * padding + k + output_padding))
+
+
 def _register():
     for name, impl, fake in (('upfirdn2d', _upfirdn2d_impl, _upfirdn2d_fake), ('fused_leaky_relu', _flr_impl, _flr_fake),
                              ('splat2d', _splat_impl, _splat_fake), ('mipmap_warp', _warp_impl, _warp_fake)):
         try:
             _lib_def.impl(name, impl, 'CUDA')
             torch.library.register_fake(f'gangealing::{name}', fake, lib=_lib_def)
+        except RuntimeError:
+            pass
+    for name, impl, fake in (('conv2d', _conv2d_impl, _conv2d_fake), ('conv_transpose2d', _convT_impl, _convT_fake)):
+        try:
+            _lib_def.impl(name, impl, 'CUDA')
+            torch.library.register_fake(f'gangealing::{name}', fake, lib=_lib_def)
+            torch.library.register_autograd(f'gangealing::{name}', _conv2d_backward,
+                                            setup_context=_conv2d_setup if name == 'conv2d' else _convT_setup,
+                                            lib=_lib_def)
         except RuntimeError:
             pass
     try:

@@ -1,5 +1,5 @@
 """upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)) - same signature and semantics as
-models/stylegan2/op/upfirdn2d.py:147-158, running gg_upfirdn2d_f32/f64 (csrc/upfirdn2d.hip).
+models/stylegan2/op/upfirdn2d.py:147-158, running gg_upfirdn2d_f32/f64/f16 (csrc/upfirdn2d.hip).
 
 The gradient of upfirdn2d is upfirdn2d with up<->down, flipped taps and the g_pad of
 upfirdn2d.py:113-118, so a single autograd Function whose backward re-applies itself gives
@@ -11,7 +11,7 @@ from torch.autograd import Function
 
 from .. import _lib
 
-_SUFFIX = {torch.float32: 'f32', torch.float64: 'f64'}
+_SUFFIX = {torch.float32: 'f32', torch.float64: 'f64', torch.float16: 'f16'}
 
 
 def _out_size(in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
@@ -22,12 +22,13 @@ def _out_size(in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, py1
 
 def _launch(x, kernel, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
     if x.dtype not in _SUFFIX:
-        raise TypeError(f'upfirdn2d: unsupported dtype {x.dtype} (float32 / float64)')
+        raise TypeError(f'upfirdn2d: unsupported dtype {x.dtype} (float32 / float64 / float16)')
     n, c, in_h, in_w = x.shape
     kh, kw = kernel.shape
     out_h, out_w = _out_size(in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, py1)
     x = x.contiguous()
-    kernel = kernel.to(dtype=x.dtype).contiguous()
+    # half tensors: fp32 taps and accumulation inside the kernel
+    kernel = kernel.to(dtype=torch.float32 if x.dtype == torch.float16 else x.dtype).contiguous()
     out = torch.empty((n, c, max(out_h, 0), max(out_w, 0)), dtype=x.dtype, device=x.device)
     if out.numel():
         _lib.call('gg_upfirdn2d_' + _SUFFIX[x.dtype], out, x, kernel, n * c, in_h, in_w, kh, kw,

@@ -44,6 +44,11 @@ int gg_fused_bias_act_f32(float* out, const float* x, const float* bias, const f
 int gg_fused_bias_act_f64(double* out, const double* x, const double* bias, const double* ref,
                           int act, int grad, double alpha, double scale,
                           long long size_x, long long step_b, int size_b, void* stream);
+/* IEEE binary16 tensors passed as their 16-bit patterns (the reference dispatches half:
+ * fused_bias_act_kernel.cu:89); fp32 arithmetic inside, one rounding per element. */
+int gg_fused_bias_act_f16(unsigned short* out, const unsigned short* x, const unsigned short* bias,
+                          const unsigned short* ref, int act, int grad, float alpha, float scale,
+                          long long size_x, long long step_b, int size_b, void* stream);
 
 /* Backward of fused_leaky_relu in ONE pass: grad_in = (out > 0 ? g : alpha*g) * scale and
  * grad_bias[c] = sum_{n,hw} grad_in (the reference re-reads grad_in in a second torch reduction,
@@ -53,6 +58,11 @@ int gg_fused_lrelu_bwd_f32(float* grad_in, float* grad_bias, const float* grad_o
                            float alpha, float scale, int n, int c, long long hw, void* stream);
 int gg_fused_lrelu_bwd_f64(double* grad_in, double* grad_bias, const double* grad_out, const double* out,
                            double alpha, double scale, int n, int c, long long hw, void* stream);
+/* binary16 tensors; grad_bias is an fp32 buffer of c entries (sum of the ROUNDED grad_in values, as the
+ * reference's grad_input.sum does) */
+int gg_fused_lrelu_bwd_f16(unsigned short* grad_in, float* grad_bias, const unsigned short* grad_out,
+                           const unsigned short* out, float alpha, float scale, int n, int c, long long hw,
+                           void* stream);
 
 /* StyledConv tail (networks.py:291-298,344-350) in one pass:
  *   out = lrelu(x + noise_weight[0] * noise[n,0,hw] + bias[c], alpha) * scale
@@ -75,6 +85,11 @@ int gg_upfirdn2d_f32(float* out, const float* in, const float* kernel,
                      int up_x, int up_y, int down_x, int down_y,
                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 int gg_upfirdn2d_f64(double* out, const double* in, const double* kernel,
+                     int major, int in_h, int in_w, int kernel_h, int kernel_w,
+                     int up_x, int up_y, int down_x, int down_y,
+                     int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+/* binary16 tensors (the reference dispatches half: upfirdn2d_kernel.cu:311), fp32 taps and accumulation */
+int gg_upfirdn2d_f16(unsigned short* out, const unsigned short* in, const float* kernel,
                      int major, int in_h, int in_w, int kernel_h, int kernel_w,
                      int up_x, int up_y, int down_x, int down_y,
                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);

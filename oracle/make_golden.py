@@ -652,6 +652,37 @@ def gen_annealing():
     save('annealing', cases)
 
 
+def gen_half_ops():
+    """binary16 inputs through the reference's CPU bodies (the CUDA kernels dispatch half: upfirdn2d_kernel.cu:311,
+    fused_bias_act_kernel.cu:89; the CPU bodies are the runnable specification).  Stored as float16."""
+    from models.stylegan2.op.upfirdn2d import upfirdn2d_native
+    from models.stylegan2.op.fused_act import fused_leaky_relu
+    from models.stylegan2.networks import make_kernel
+    k1331 = make_kernel([1, 3, 3, 1])
+    cases = []
+    specs = [((2, 3, 9, 9), k1331 * 4, 1, 1, (1, 1, 1, 1)), ((2, 3, 8, 8), k1331 * 4, 2, 1, (2, 1, 2, 1)),
+             ((2, 2, 16, 16), k1331, 1, 1, (2, 2, 2, 2)), ((1, 2, 8, 8), k1331, 1, 2, (1, 1, 1, 1)),
+             ((1, 2, 37, 41), k1331, 1, 1, (2, 2, 2, 2)), ((1, 1, 6, 6), k1331, 2, 2, (2, 1, 2, 1))]
+    for i, (shape, k, up, down, pad) in enumerate(specs):
+        x = rnd(f'half.ux{i}', shape).half().requires_grad_(True)
+        out = upfirdn2d_native(x, k.half(), up, up, down, down, *pad)
+        g = rnd(f'half.ug{i}', out.shape).half()
+        (gx,) = torch.autograd.grad(out, x, g)
+        # fp32 evaluation of the same (rounded) inputs: the yardstick for "how far is half arithmetic from exact"
+        out32 = upfirdn2d_native(x.detach().float(), k.half().float(), up, up, down, down, *pad)
+        cases.append(dict(kind='upfirdn2d', x=x, k=k, out=out, out32=out32, g=g, gx=gx,
+                          meta=dict(kind='upfirdn2d', up=up, down=down, pad=list(pad))))
+    for i, shape in enumerate([(4, 8), (2, 6, 5, 5), (3, 16, 8, 8), (2, 4, 3, 7)]):
+        x = rnd(f'half.fx{i}', shape).half().requires_grad_(True)
+        b = rnd(f'half.fb{i}', (shape[1],), 0.5).half().requires_grad_(True)
+        out = fused_leaky_relu(x, b)
+        g = rnd(f'half.fg{i}', shape).half()
+        gx, gb = torch.autograd.grad(out, (x, b), g)
+        cases.append(dict(x=x, b=b, out=out, g=g, gx=gx, gb=gb,
+                          meta=dict(kind='fused_leaky_relu', negative_slope=0.2, scale=2 ** 0.5)))
+    save('half_ops', cases)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -661,7 +692,8 @@ if __name__ == '__main__':
     gens = dict(upfirdn2d=gen_upfirdn2d, fused_act=gen_fused_act, mipmap_warp=gen_mipmap_warp, heads=gen_heads,
                 misc=gen_misc, modconv=gen_modconv, generator=gen_generator, stn=gen_stn,
                 train_step=gen_train_step, cluster_classifier=gen_cluster_classifier,
-                point_transfer=gen_point_transfer, warp_indices=gen_warp_indices, annealing=gen_annealing, stn_inference=gen_stn_inference)
+                point_transfer=gen_point_transfer, warp_indices=gen_warp_indices, annealing=gen_annealing, stn_inference=gen_stn_inference,
+                half_ops=gen_half_ops)
     for name, fn in gens.items():
         if only and name not in only:
             continue

@@ -39,6 +39,45 @@ def test_upfirdn2d_golden(case, cuda):
     close(x.grad, case['gx'], 1e-5)
 
 
+@pytest.mark.parametrize('case', load_golden('half_ops'), ids=lambda c: c['meta']['kind'])
+def test_half_tensors_against_reference(case, cuda):
+    """binary16 upfirdn2d / fused_leaky_relu (the reference dispatches half: upfirdn2d_kernel.cu:311,
+    fused_bias_act_kernel.cu:89) against the reference's CPU bodies run on half tensors.  The HIP kernels compute in
+    fp32 and round once: within 1.5 (upfirdn2d) / 2.5 (three roundings in the reference's activation) half ulps of the
+    reference's result, and correctly rounded with respect to the fp32 evaluation of the same inputs."""
+    import torch
+    from gangealing_amd.op import upfirdn2d, fused_leaky_relu
+    m = case['meta']
+    ulp = 2.0 ** -10
+
+    def near(a, b, ulps=1.5):
+        a, b = a.float().cpu(), torch.from_numpy(np.asarray(b)).float()
+        tol = ulps * ulp * b.abs().clamp_min(float(b.abs().max()) * 2 ** -4)
+        assert a.dtype == torch.float32 and bool(((a - b).abs() <= tol).all()), float(((a - b).abs() / tol).max())
+
+    x = torch.from_numpy(case['x']).to(cuda).requires_grad_(True)
+    assert x.dtype == torch.float16
+    g = torch.from_numpy(case['g']).to(cuda)
+    if m['kind'] == 'upfirdn2d':
+        pad = m['pad']
+        out = upfirdn2d(x, torch.from_numpy(case['k']).to(cuda), up=m['up'], down=m['down'], pad=(pad[0], pad[1]))
+        assert out.dtype == torch.float16
+        near(out, case['out'])
+        exact = torch.from_numpy(case['out32'])          # fp32 evaluation of the same rounded inputs
+        assert bool(((out.float().cpu() - exact).abs() <= 2.0 ** -11 * exact.abs() + 2e-6 * float(exact.abs().max())).all())
+        out.backward(g)
+        near(x.grad, case['gx'])
+    else:
+        b = torch.from_numpy(case['b']).to(cuda).requires_grad_(True)
+        out = fused_leaky_relu(x, b, m['negative_slope'], m['scale'])
+        assert out.dtype == torch.float16
+        near(out, case['out'], ulps=2.5)            # the reference rounds after the add, the slope and the gain
+        out.backward(g)
+        near(x.grad, case['gx'], ulps=2.5)
+        assert b.grad.dtype == torch.float16
+        near(b.grad, case['gb'], ulps=4.0)          # a sum of up to 192 rounded terms, accumulated in fp32 here
+
+
 def test_upfirdn2d_hot_shapes_vs_oracle(cuda):
     from gangealing_amd.op import upfirdn2d
     from oracle import np_ops
@@ -539,6 +578,25 @@ def test_torch_library_ops_run_the_hip_kernels(cuda):
     img = torch.zeros(2, 3, 9, 9, device=cuda)
     torch.testing.assert_close(torch.ops.gangealing.splat2d(img, coords, vals, sigma, False),
                                splat2d(img, coords, vals, sigma, False), atol=1e-6, rtol=1e-5)
+    # convolutions: dispatcher op == module function, gradients through the Autograd-key registration
+    from gangealing_amd.op import conv_mfma
+    xc = torch.randn(2, 32, 16, 16, generator=g).to(cuda).requires_grad_(True)
+    wc = (torch.randn(64, 32, 3, 3, generator=g) * 0.1).to(cuda).requires_grad_(True)
+    bc = torch.randn(64, generator=g).to(cuda).requires_grad_(True)
+    a = torch.ops.gangealing.conv2d(xc, wc, bc, 2, 1, 1)
+    b = conv_mfma.conv2d(xc, wc, bc, stride=2, padding=1)
+    torch.testing.assert_close(a, b, atol=1e-5, rtol=1e-5)        # (small launches split K with fp32 atomics: last-bit run-to-run noise)
+    gy = torch.randn_like(a)
+    for u, v in zip(torch.autograd.grad(a, (xc, wc, bc), gy), torch.autograd.grad(b, (xc, wc, bc), gy)):
+        torch.testing.assert_close(u, v, atol=1e-5, rtol=1e-5)
+    wt = (torch.randn(32, 48, 3, 3, generator=g) * 0.1).to(cuda).requires_grad_(True)
+    a = torch.ops.gangealing.conv_transpose2d(xc, wt, None, 2, 0, 0, 1)
+    b = conv_mfma.conv_transpose2d(xc, wt, None, stride=2, padding=0)
+    assert a.shape == (2, 48, 33, 33)
+    torch.testing.assert_close(a, b, atol=1e-5, rtol=1e-5)
+    gy = torch.randn_like(a)
+    for u, v in zip(torch.autograd.grad(a, (xc, wt), gy), torch.autograd.grad(b, (xc, wt), gy)):
+        torch.testing.assert_close(u, v, atol=1e-5, rtol=1e-5)
 
 
 def test_splat_points_overlay_against_reference_kernel(cuda):

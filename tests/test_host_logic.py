@@ -252,7 +252,7 @@ def test_torch_library_ops_are_registered_with_fake_kernels():
     """torch.ops.gangealing.*: schemas exist and shape inference works without a GPU (fake tensors)."""
     import gangealing_amd.op.library  # noqa: F401
     from torch._subclasses.fake_tensor import FakeTensorMode
-    for name in ('upfirdn2d', 'fused_leaky_relu', 'splat2d', 'mipmap_warp'):
+    for name in ('upfirdn2d', 'fused_leaky_relu', 'splat2d', 'mipmap_warp', 'conv2d', 'conv_transpose2d'):
         assert hasattr(torch.ops.gangealing, name)
     with FakeTensorMode():
         x = torch.empty(2, 3, 8, 8, device='cuda')
@@ -262,3 +262,8 @@ def test_torch_library_ops_are_registered_with_fake_kernels():
         assert torch.ops.gangealing.fused_leaky_relu(x, torch.empty(3, device='cuda'), 0.2, 2 ** 0.5).shape == x.shape
         out, levels = torch.ops.gangealing.mipmap_warp(x, torch.empty(2, 5, 6, 2, device='cuda'), 2.5, 0.0, 'border', True)
         assert out.shape == (2, 3, 5, 6) and levels.shape == (2, 5, 6)
+        with torch.no_grad():
+            w = torch.empty(7, 3, 3, 3, device='cuda')
+            assert torch.ops.gangealing.conv2d(x, w, None, 2, 1, 1).shape == (2, 7, 4, 4)
+            wt = torch.empty(3, 5, 3, 3, device='cuda')
+            assert torch.ops.gangealing.conv_transpose2d(x, wt, None, 2, 0, 0, 1).shape == (2, 5, 17, 17)
