@@ -171,9 +171,12 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_tile(
 //   * rows are fetched eight at a time (eight independent loads in flight per wave) before they are consumed.
 // Separable taps (every Blur of the networks: make_kernel is an outer product, networks.py:34-41) cost 3 DPP moves +
 // 8 FMAs per output; general taps keep the three shifted copies of each window row (16 FMAs per output).
-// Read amplification: 64/61 columns x (SROWS+3)/SROWS rows = 1.15, served by L2.
+// Read amplification: 64/61 columns x (SROWS+3)/SROWS rows = 1.25, served by L2 (neighbouring strips run together).
+// Strip height, measured on the three hot shapes at batch 16 (TB/s of in + out bytes): 8 rows 4.0-4.7 / 3.8 / 4.6,
+// 16 rows 4.67 / 4.70 / 4.49, 32 rows 4.45 / 4.35 / 4.26, 64 rows 4.19 / 4.17 / 3.57, 128 rows 3.94 / 3.90 / 3.21:
+// taller strips save halo reads that L2 already absorbs and lose memory-level parallelism (fewer waves per plane).
 constexpr int SW_OUT = 61;      // outputs per wave row
-constexpr int SROWS = 32;       // output rows per wave
+constexpr int SROWS = 16;       // output rows per wave
 
 __device__ __forceinline__ float wave_shl1(float v) {     // lane i <- lane i+1; lane 63 <- 0
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
