@@ -1121,33 +1121,48 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
         __syncthreads();
         if (iv + 1 < 9 / TPI) load_w(chunk, iv + 1);
         else if (chunk + 1 < chunk1) load_w(chunk + 1, 0);
-#pragma unroll
-        for (int u = 0; u < TPI; ++u) {
+        // (tap, k-step) units of the interval, software-pipelined: the fragments of unit q + 1 are fetched before the
+        // MFMAs of unit q, so that an LDS round trip is covered by 6 (two limbs) MFMAs per wave instead of being
+        // waited for in front of them (with 255 registers in use the scheduler otherwise fetches just in time)
+        // (three limbs: 9 fragments per unit - two sets no longer fit the register file, fetch in place)
+        constexpr int UNITS = TPI * (BKS / 16);
+        constexpr bool PF = LIMBS <= 2;
+        bf16x8 fa[PF ? 2 : 1][LIMBS], fb[PF ? 2 : 1][LIMBS][NJ];
+        auto fetch = [&](int slot, int q) {
+          const int u = q / (BKS / 16), ks = q % (BKS / 16);
           const int t = iv * TPI + u;
           const int ky = t / 3, kx = t - ky * 3;
-          const int cls = (ky & 1) * 2 + (kx & 1);
           // x[q - j]: patch row/col (q - y0) + 1 - j
           const int tapoff = ((1 - (ky >> 1)) * PW + (1 - (kx >> 1))) * ROWB;
 #pragma unroll
-          for (int ks = 0; ks < BKS / 16; ++ks) {
-            bf16x8 fa[LIMBS], fb[LIMBS][NJ];
+          for (int l = 0; l < LIMBS; ++l) {
+            fa[slot][l] =
+                *reinterpret_cast<const bf16x8*>(&sW[u * LIMBS + l][(wco * 32 + l31) * ROWB + ks * 32 + kh * 16]);
 #pragma unroll
-            for (int l = 0; l < LIMBS; ++l) {
-              fa[l] = *reinterpret_cast<const bf16x8*>(&sW[u * LIMBS + l][(wco * 32 + l31) * ROWB + ks * 32 + kh * 16]);
+            for (int j = 0; j < NJ; ++j)
+              fb[slot][l][j] = *reinterpret_cast<const bf16x8*>(&sP[l][pbase[j] + tapoff + ks * 32 + kh * 16]);
+          }
+        };
+        if (PF) fetch(0, 0);
+#pragma unroll
+        for (int q = 0; q < UNITS; ++q) {
+          const int slot = PF ? (q & 1) : 0;
+          if (!PF) fetch(0, q);
+          else if (q + 1 < UNITS) fetch(slot ^ 1, q + 1);
+          if (PF) __builtin_amdgcn_sched_barrier(0);
+          const int t = iv * TPI + q / (BKS / 16);
+          const int ky = t / 3, kx = t - ky * 3;
+          const int cls = (ky & 1) * 2 + (kx & 1);
+#pragma unroll
+          for (int sum = LIMBS - 1; sum >= 0; --sum)
+#pragma unroll
+            for (int la = 0; la <= sum; ++la) {
+              const int lb = sum - la;
 #pragma unroll
               for (int j = 0; j < NJ; ++j)
-                fb[l][j] = *reinterpret_cast<const bf16x8*>(&sP[l][pbase[j] + tapoff + ks * 32 + kh * 16]);
+                acc[cls][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][la], fb[slot][lb][j], acc[cls][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int sum = LIMBS - 1; sum >= 0; --sum)
-#pragma unroll
-              for (int la = 0; la <= sum; ++la) {
-                const int lb = sum - la;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                  acc[cls][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la], fb[lb][j], acc[cls][j], 0, 0, 0);
-              }
-          }
+          if (PF) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
       }
