@@ -207,7 +207,7 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
                 tiles256 = (batch * oh * ow + 255) // 256 * ((cout_g + 127) // 128) * groups
                 pow2 = ow >= 16 and (ow & (ow - 1)) == 0
                 if (limbs in (1, 2) and stride == 1 and pad == 1 and in_scale is not None and pow2 and tiles256 >= 512
-                        and oh % (256 // min(ow, 64)) == 0):
+                        and cin_g > 64 and oh % (256 // min(ow, 64)) == 0):
                     prof = PROFILER
                 # bf16x6: the same layers run conv3x3_patch_kernel<3, true, 128>
                 if (limbs == 3 and stride == 1 and pad == 1 and in_scale is not None and pow2 and tiles256 >= 512

@@ -24,6 +24,17 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/benc
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch -- python $R/scripts/pmc_calibrate.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/cal_write -- python $R/scripts/pmc_calibrate.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+# stall attribution of the dominant kernel on its own (per-layer benchmark, 512 -> 512 @64^2): SQ wave-cycle breakdown
+( export GANGEALING_CONV_PRECISION=bf16x3 ITERS=5
+  i=0
+  for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" \
+             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" \
+             "GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    rocprofv3 --pmc $grp --output-format csv -d $O/stall$i -- python $R/scripts/conv_bench.py "G conv 64" > /dev/null 2>&1
+    python $R/scripts/pmc_kernel.py $O/stall$i "patch_kernel" >> $O/sq_stall.txt 2>&1
+    rm -rf $O/stall$i
+  done )
 cd $R
 DB=$(find $O/trace -name "*.db" | head -1)
 python scripts/rocpd_stats.py $DB 90 > $O/kernel_stats.txt 2>&1
