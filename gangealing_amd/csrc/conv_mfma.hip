@@ -2311,6 +2311,82 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   return gg::launch_status("convT3x3s2_patch");
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1x1 convolution with <= 4 output channels (ToRGB, networks.py:353-372: 128..512 -> 3): a streaming reduction over
+// the input channels - every input element is read exactly once, 16 B per lane, and meets NCO FMAs.  HBM-bound
+// (4 * Cin B per pixel in, 4 * NCO out); on the 32-wide MFMA tile the same layer reached 3.0 TB/s.
+// Block = 256 pixels of one image (64 lanes x 4 consecutive pixels) x 4 waves splitting the channels; the waves'
+// partial sums meet in LDS.  wmat: [ci][co] (fp32 GEMM layout of pack_weight_kernel), in_scale: (N, Cin) or null.
+// ------------------------------------------------------------------------------------------------
+constexpr int FEWOUT_MAX_CIN = 512;
+template <int NCO>
+__global__ __launch_bounds__(256) void conv1x1_fewout_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                             const float* __restrict__ wmat,
+                                                             const float* __restrict__ in_scale,
+                                                             const float* __restrict__ out_scale,
+                                                             const float* __restrict__ bias, int cin, long long hw) {
+  __shared__ float sw[NCO][FEWOUT_MAX_CIN];
+  __shared__ float4 red[4][NCO][64];
+  const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  for (int i = tid; i < cin * NCO; i += 256) {
+    const int ci = i / NCO, j = i - ci * NCO;
+    sw[j][ci] = wmat[i] * (in_scale ? in_scale[(size_t)n * cin + ci] : 1.f);
+  }
+  __syncthreads();
+  const long long p = (long long)blockIdx.x * 256 + lane * 4;
+  const bool ok = p < hw;                                   // hw % 4 == 0: a lane's four pixels are in or out together
+  float4 acc[NCO];
+#pragma unroll
+  for (int j = 0; j < NCO; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    const int per = (cin + 3) / 4, k0 = g * per, k1 = (k0 + per < cin) ? k0 + per : cin;
+    const float* src = x + ((size_t)n * cin + k0) * hw + p;
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k, src += hw) {
+      const float4 v = *reinterpret_cast<const float4*>(src);
+#pragma unroll
+      for (int j = 0; j < NCO; ++j) {
+        const float wj = sw[j][k];
+        acc[j].x += v.x * wj; acc[j].y += v.y * wj; acc[j].z += v.z * wj; acc[j].w += v.w * wj;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NCO; ++j) red[g][j][lane] = acc[j];
+  __syncthreads();
+  if (g < NCO && ok) {                                      // wave j finishes output channel j
+    const int j = g;
+    float4 r = red[0][j][lane];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      const float4 t = red[q][j][lane];
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    const float sc = out_scale ? out_scale[(size_t)n * NCO + j] : 1.f, bi = bias ? bias[j] : 0.f;
+    r.x = r.x * sc + bi; r.y = r.y * sc + bi; r.z = r.z * sc + bi; r.w = r.w * sc + bi;
+    *reinterpret_cast<float4*>(y + ((size_t)n * NCO + j) * hw + p) = r;
+  }
+}
+
+bool fewout_serves(const ConvArgs& a, int stride, int pad, int mode) {
+  const long long hw = (long long)a.h * a.w;
+  return mode == 0 && stride == 1 && pad == 0 && a.groups == 1 && a.cout_g >= 1 && a.cout_g <= 4 && a.wmat &&
+         a.cin_g <= FEWOUT_MAX_CIN && hw % 4 == 0 && !a.act && !a.mask_ref && a.batch <= 65535 &&
+         (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
+}
+
+int launch_conv1x1_fewout(const ConvArgs& a, hipStream_t st) {
+  const long long hw = (long long)a.h * a.w;
+  dim3 grid((unsigned)((hw + 255) / 256), (unsigned)a.batch);
+  switch (a.cout_g) {
+    case 1: conv1x1_fewout_kernel<1><<<grid, 256, 0, st>>>(a.y, a.x, a.wmat, a.in_scale, a.out_scale, a.bias, a.cin_g, hw); break;
+    case 2: conv1x1_fewout_kernel<2><<<grid, 256, 0, st>>>(a.y, a.x, a.wmat, a.in_scale, a.out_scale, a.bias, a.cin_g, hw); break;
+    case 3: conv1x1_fewout_kernel<3><<<grid, 256, 0, st>>>(a.y, a.x, a.wmat, a.in_scale, a.out_scale, a.bias, a.cin_g, hw); break;
+    default: conv1x1_fewout_kernel<4><<<grid, 256, 0, st>>>(a.y, a.x, a.wmat, a.in_scale, a.out_scale, a.bias, a.cin_g, hw); break;
+  }
+  return gg::launch_status("conv1x1_fewout");
+}
+
 constexpr int kNotFused = GG_NOT_SERVED;      // masked-input request that no kernel serves: nothing was launched
 
 template <int KS>
@@ -2324,6 +2400,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     if (patch_geometry(a, 128, tw_log2)) return launch_conv_patch(a, limbs, tw_log2, 128, st);
     return kNotFused;
   }
+  if (KS == 1 && limbs == 0 && fewout_serves(a, stride, pad, mode)) return launch_conv1x1_fewout(a, st);
   if (!a.act && limbs && KS == 3 && mode == 1 && pad <= 1 && a.w >= 4 && (a.w & (a.w - 1)) == 0 &&
       (long long)a.cin_g * a.h * a.w * 4 < (1LL << 31) && (long long)a.cout_g * a.oh * a.ow * 4 < (1LL << 31))
     return launch_convT_patch(a, limbs, pad, st);

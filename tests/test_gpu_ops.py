@@ -521,7 +521,10 @@ def test_generator_fusions_do_not_change_the_image(cuda):
             conv_mfma.DISABLED = old
     img_on, g_on = run(())
     img_off, g_off = run(('style_bank', 'torgb_bias', 'noise_bank'))
-    torch.testing.assert_close(img_on, img_off, atol=2e-5, rtol=1e-5)
+    # (batch 3 at 64^2: every layer splits K with fp32 atomics, so two runs of the SAME configuration already differ in
+    # the last bits, and 14 layers amplify that: typical difference 1e-6, occasionally above 2e-5)
+    assert float((img_on - img_off).norm() / img_off.norm()) < 2e-5
+    torch.testing.assert_close(img_on, img_off, atol=2e-4, rtol=1e-4)
     # the two runs differ by fp32 rounding (different kernels carry the bias / the adds), which the split-K atomics'
     # run-to-run ordering also produces; a leaky-ReLU input that lands on the other side of zero turns that into a
     # visible gradient entry, so the gradient is compared in L2 with a bounded worst entry
@@ -549,6 +552,58 @@ def test_lpips_tap_accumulates_into_the_downstream_gradient(cuda):
         (gb,) = torch.autograd.grad([(fb1 * wnext).sum(), lpips_tail(fb1, use_lin)], fb, [torch.ones((), device=cuda), gv])
         torch.testing.assert_close(val, lpips_tail(f, use_lin), atol=1e-6, rtol=1e-5)
         torch.testing.assert_close(ga, gb, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 16, 16, 3), (3, 512, 4, 4, 3), (2, 96, 8, 12, 4), (1, 33, 6, 6, 1),
+                                   (2, 64, 10, 10, 2)])
+def test_conv1x1_few_outputs_streaming_kernel(shape, cuda):
+    """ToRGB-shaped 1x1 convolutions (<= 4 outputs) run the streaming channel-reduction kernel: against F.conv2d on the
+    CPU, with per-sample input / output scales and a bias, and against the MFMA path's answer for 5 outputs."""
+    import torch.nn.functional as F
+    from gangealing_amd.op import conv_mfma
+    n, cin, h, w, cout = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    b = torch.randn(cout, generator=g)
+    s_in, s_out = torch.rand(n, cin, generator=g) + 0.5, torch.rand(n, cout, generator=g) + 0.5
+    ref = F.conv2d(x.double() * s_in.double()[:, :, None, None], wt.double()) * s_out.double()[:, :, None, None] \
+        + b.double()[None, :, None, None]
+    wm = conv_mfma.PackedWeight(wt.to(cuda), 1, cout, cin, 1, 0, 0)
+    y = conv_mfma.conv_forward(x.to(cuda), wm, n, 1, cin, cout, 1, 1, 0, 0, in_scale=s_in.to(cuda), out_scale=s_out.to(cuda),
+                               bias=b.to(cuda))
+    assert float((y.double().cpu() - ref).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max()))
+    y0 = conv_mfma.conv2d(x.to(cuda), wt.to(cuda), None)
+    assert float((y0.double().cpu() - F.conv2d(x.double(), wt.double())).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max()))
+
+
+def test_unsplit_launches_are_bitwise_reproducible(cuda):
+    """Launches that do not split K (no float atomics) must give bit-identical results run after run: the wave-level
+    LDS staging of the epilogues and the double-buffered, software-pipelined tap loop have no cross-wave hazards."""
+    from gangealing_amd.op import conv_mfma
+    old = conv_mfma.PRECISION
+    conv_mfma.set_precision('bf16x3')
+    try:
+        g = torch.Generator().manual_seed(5)
+        cases = [  # (n, cin, cout, h, k, stride, pad, mode, scaled)
+            (32, 128, 128, 64, 3, 1, 1, 0, True),      # 512 tiles of 256 pixels: pipelined loop
+            (16, 128, 128, 64, 3, 1, 1, 0, False),     # 512 tiles of 128 pixels
+            (16, 64, 64, 64, 3, 1, 1, 0, False),       # narrow (64-channel) tile
+            (16, 256, 256, 64, 3, 2, 0, 1, True),      # transposed, 128-q tiles (1088 blocks)
+            (12, 128, 128, 32, 3, 2, 0, 1, False),     # transposed, 64-q tiles (216 blocks: unsplit)
+        ]
+        for (n, cin, cout, h, k, stride, pad, mode, scaled) in cases:
+            x = torch.randn(n, cin, h, h, generator=g).to(cuda)
+            w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(cuda)
+            wm = conv_mfma.PackedWeight(w, 1, cout, cin, k, 0, 0)
+            s_in = (torch.rand(n, cin, generator=g) + 0.5).to(cuda) if scaled else None
+            s_out = (torch.rand(n, cout, generator=g) + 0.5).to(cuda) if scaled else None
+            first = conv_mfma.conv_forward(x, wm, n, 1, cin, cout, k, stride, pad, mode, in_scale=s_in, out_scale=s_out)
+            for _ in range(30):
+                again = conv_mfma.conv_forward(x, wm, n, 1, cin, cout, k, stride, pad, mode, in_scale=s_in, out_scale=s_out)
+                assert torch.equal(first, again), (n, cin, cout, h, mode)
+    finally:
+        conv_mfma.set_precision(old)
 
 
 def test_torch_library_ops_run_the_hip_kernels(cuda):
