@@ -61,6 +61,8 @@ _PROTOS = {
     'gg_style_demod_f32': 'pppqpppiiiifffs',
     'gg_lpips_tail_fwd_f32': 'pppiiqfs',
     'gg_lpips_tail_bwd_f32': 'ppppiiqfis',
+    'gg_maxpool2x2_fwd_f32': 'pppqiis',
+    'gg_maxpool2x2_bwd_f32': 'pppqiis',
     'gg_torgb_dgrad_add_f32': 'ppppfiiqs',
     'gg_plane_dot_f32': 'pppiqs',
     'gg_adam_ema_f32': 'pppppqffffiffs',

@@ -2370,7 +2370,8 @@ __global__ __launch_bounds__(256) void conv1x1_fewout_kernel(float* __restrict__
 
 bool fewout_serves(const ConvArgs& a, int stride, int pad, int mode) {
   const long long hw = (long long)a.h * a.w;
-  return mode == 0 && stride == 1 && pad == 0 && a.groups == 1 && a.cout_g >= 1 && a.cout_g <= 4 && a.wmat &&
+  static const bool off = getenv("GG_NO_FEWOUT") != nullptr;      // measurement switch
+  return !off && mode == 0 && stride == 1 && pad == 0 && a.groups == 1 && a.cout_g >= 1 && a.cout_g <= 4 && a.wmat &&
          a.cin_g <= FEWOUT_MAX_CIN && hw % 4 == 0 && !a.act && !a.mask_ref && a.batch <= 65535 &&
          (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
 }

@@ -108,6 +108,77 @@ __global__ __launch_bounds__(256) void lpips_tail_bwd_kernel(float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 2x2 / stride-2 max pooling of the VGG16 trunk (lpips_backbones.py:101-121 via torchvision's features; ATen
+// max_pool2d semantics: the window is scanned row-major and a later element replaces the maximum only if it is
+// strictly greater or NaN).  The forward also writes the winner's position (0..3) as one byte per output, so the
+// backward is a pure scatter-free stream: dx (4 B x 4 per output) is written once from dy and the code - no int64
+// index tensor (8 B per output), no zero fill, no atomics.  Even H and W; W % 4 == 0 takes the 16-byte path.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pool_window(float a, float b, float c, float d, float& m, unsigned char& code) {
+  m = a; code = 0;
+  if (b > m || b != b) { m = b; code = 1; }
+  if (c > m || c != c) { m = c; code = 2; }
+  if (d > m || d != d) { m = d; code = 3; }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void maxpool2x2_fwd_kernel(float* __restrict__ out, unsigned char* __restrict__ code,
+                                                             const float* __restrict__ x, long long nunits, int oh,
+                                                             int ow) {
+  // unit = VEC ? two horizontally adjacent outputs : one output
+  const int upr = VEC ? ow / 2 : ow;                       // units per output row
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < nunits; u += stride) {
+    const long long row = u / upr;                          // plane * oh + oy
+    const int ux = (int)(u - row * upr);
+    const float* r0 = x + (size_t)row * 2 * (2 * ow) + (VEC ? 4 * ux : 2 * ux);
+    const float* r1 = r0 + 2 * ow;
+    if (VEC) {
+      const float4 a = *reinterpret_cast<const float4*>(r0), b = *reinterpret_cast<const float4*>(r1);
+      float m0, m1;
+      unsigned char c0, c1;
+      pool_window(a.x, a.y, b.x, b.y, m0, c0);
+      pool_window(a.z, a.w, b.z, b.w, m1, c1);
+      *reinterpret_cast<float2*>(out + (size_t)row * ow + 2 * ux) = make_float2(m0, m1);
+      *reinterpret_cast<uchar2*>(code + (size_t)row * ow + 2 * ux) = make_uchar2(c0, c1);
+    } else {
+      float m;
+      unsigned char c;
+      pool_window(r0[0], r0[1], r1[0], r1[1], m, c);
+      out[(size_t)row * ow + ux] = m;
+      code[(size_t)row * ow + ux] = c;
+    }
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(float* __restrict__ dx, const float* __restrict__ dy,
+                                                             const unsigned char* __restrict__ code, long long nunits,
+                                                             int oh, int ow) {
+  const int upr = VEC ? ow / 2 : ow;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < nunits; u += stride) {
+    const long long row = u / upr;
+    const int ux = (int)(u - row * upr);
+    float* r0 = dx + (size_t)row * 2 * (2 * ow) + (VEC ? 4 * ux : 2 * ux);
+    float* r1 = r0 + 2 * ow;
+    if (VEC) {
+      const float2 g = *reinterpret_cast<const float2*>(dy + (size_t)row * ow + 2 * ux);
+      const uchar2 c = *reinterpret_cast<const uchar2*>(code + (size_t)row * ow + 2 * ux);
+      *reinterpret_cast<float4*>(r0) = make_float4(c.x == 0 ? g.x : 0.f, c.x == 1 ? g.x : 0.f, c.y == 0 ? g.y : 0.f,
+                                                   c.y == 1 ? g.y : 0.f);
+      *reinterpret_cast<float4*>(r1) = make_float4(c.x == 2 ? g.x : 0.f, c.x == 3 ? g.x : 0.f, c.y == 2 ? g.y : 0.f,
+                                                   c.y == 3 ? g.y : 0.f);
+    } else {
+      const float g = dy[(size_t)row * ow + ux];
+      const unsigned char c = code[(size_t)row * ow + ux];
+      r0[0] = c == 0 ? g : 0.f; r0[1] = c == 1 ? g : 0.f;
+      r1[0] = c == 2 ? g : 0.f; r1[1] = c == 3 ? g : 0.f;
+    }
+  }
+}
+
 dim3 tail_grid(int n, long long hw) {
   long long bx = (hw + PIX - 1) / PIX;
   if (bx > 8192) bx = 8192;
@@ -135,4 +206,32 @@ extern "C" int gg_lpips_tail_bwd_f32(float* dfeats, const float* feats, const fl
   lpips_tail_bwd_kernel<<<tail_grid(n, hw), 256, 0, gg::as_stream(stream)>>>(dfeats, feats, lin, grad_out, n, c, hw, eps,
                                                                             1.f / (float)hw, accumulate);
   return gg::launch_status("lpips_tail_bwd");
+}
+
+extern "C" int gg_maxpool2x2_fwd_f32(float* out, unsigned char* code, const float* x, long long planes, int h, int w,
+                                     void* stream) {
+  if (planes <= 0) return 0;
+  if (!out || !code || !x || h <= 0 || w <= 0 || (h & 1) || (w & 1)) return gg::fail(-2, "maxpool2x2: even H, W required");
+  const int oh = h / 2, ow = w / 2;
+  const bool vec = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(code) & 1) == 0;
+  const long long nunits = planes * oh * (vec ? ow / 2 : ow);
+  hipStream_t st = gg::as_stream(stream);
+  if (vec) maxpool2x2_fwd_kernel<true><<<gg::stream_grid(nunits, 256), 256, 0, st>>>(out, code, x, nunits, oh, ow);
+  else maxpool2x2_fwd_kernel<false><<<gg::stream_grid(nunits, 256), 256, 0, st>>>(out, code, x, nunits, oh, ow);
+  return gg::launch_status("maxpool2x2_fwd");
+}
+
+extern "C" int gg_maxpool2x2_bwd_f32(float* dx, const float* dy, const unsigned char* code, long long planes, int h,
+                                     int w, void* stream) {
+  if (planes <= 0) return 0;
+  if (!dx || !dy || !code || h <= 0 || w <= 0 || (h & 1) || (w & 1)) return gg::fail(-2, "maxpool2x2: even H, W required");
+  const int oh = h / 2, ow = w / 2;
+  const bool vec = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(code) & 1) == 0;
+  const long long nunits = planes * oh * (vec ? ow / 2 : ow);
+  hipStream_t st = gg::as_stream(stream);
+  if (vec) maxpool2x2_bwd_kernel<true><<<gg::stream_grid(nunits, 256), 256, 0, st>>>(dx, dy, code, nunits, oh, ow);
+  else maxpool2x2_bwd_kernel<false><<<gg::stream_grid(nunits, 256), 256, 0, st>>>(dx, dy, code, nunits, oh, ow);
+  return gg::launch_status("maxpool2x2_bwd");
 }

@@ -4,6 +4,7 @@ default --loss_fn vgg_ssl, :13-17) whose convolutions run on the MFMA implicit-G
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from torch.autograd import Function
 
 from . import _lib
 from .op import conv_mfma
@@ -198,6 +199,39 @@ def vgg16_feature_layers():
     return list(enumerate(layers))[:30]
 
 
+class _MaxPool2x2(Function):
+    """F.max_pool2d(x, 2, 2) of the VGG16 trunk on gg_maxpool2x2_*: the forward keeps one byte per output (which of the
+    four inputs won, ATen's tie rule) instead of an int64 index, the backward writes dx in one pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        out = torch.empty((n, c, h // 2, w // 2), dtype=x.dtype, device=x.device)
+        code = torch.empty((n, c, h // 2, w // 2), dtype=torch.uint8, device=x.device)
+        _lib.call('gg_maxpool2x2_fwd_f32', out, code, x, n * c, h, w)
+        ctx.save_for_backward(code)
+        ctx.shape = (n, c, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (code,) = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        dx = torch.empty((n, c, h, w), dtype=grad.dtype, device=grad.device)
+        _lib.call('gg_maxpool2x2_bwd_f32', dx, grad.contiguous(), code, n * c, h, w)
+        return dx
+
+
+def max_pool2x2(x):
+    """2x2 / stride-2 max pooling; odd sizes (floor mode drops the last row / column) and non-fp32 tensors use ATen's
+    operator on the same device (no host path: the HIP entry point raises for tensors that are not on the GPU)."""
+    if (x.dtype != torch.float32 or x.dim() != 4 or x.shape[-1] % 2 or x.shape[-2] % 2
+            or 'maxpool' in conv_mfma.DISABLED):          # GG_DISABLE=maxpool: A/B measurements
+        return F.max_pool2d(x, 2, 2)
+    return _MaxPool2x2.apply(x)
+
+
 class vgg16(nn.Module):
     """VGG16 trunk with the module names of the reference wrapper (lpips_backbones.py:98-140: `slice1`..`slice5`,
     children named by their torchvision `features` index), so both torchvision-layout `features` state_dicts
@@ -266,7 +300,7 @@ class vgg16(nn.Module):
                     else:                        # 3-channel stem: fp32 kernel + separate ReLU
                         x = F.relu(conv_mfma.conv2d(x, mod.weight, mod.bias, stride=1, padding=1))
                 elif isinstance(mod, nn.MaxPool2d):
-                    x = F.max_pool2d(x, 2, 2)
+                    x = max_pool2x2(x)
                 # nn.ReLU: applied in the convolution above
             if tap is not None:
                 x, val = tap(si, x)

@@ -343,6 +343,15 @@ int gg_lpips_tail_fwd_f32(float* out, const float* feats, const float* lin, int 
                           void* stream);
 int gg_lpips_tail_bwd_f32(float* dfeats, const float* feats, const float* lin, const float* grad_out, int n, int c,
                           long long hw, float eps, int accumulate, void* stream);
+
+/* 2x2 / stride-2 max pooling of the VGG16 perceptual-loss trunk (models/losses/lpips_backbones.py:101-121: torchvision's
+ * `features` -> ATen max_pool2d: row-major window scan, a later element wins only if strictly greater or NaN).
+ * x: (planes, h, w) dense, h and w even.  `code` (planes * h/2 * w/2 bytes) receives the winner's position 0..3 and
+ * is all the backward needs: dx (planes, h, w) is written in full from dy and code (no zero fill, no atomics). */
+int gg_maxpool2x2_fwd_f32(float* out, unsigned char* code, const float* x, long long planes, int h, int w,
+                          void* stream);
+int gg_maxpool2x2_bwd_f32(float* dx, const float* dy, const unsigned char* code, long long planes, int h, int w,
+                          void* stream);
 /* Data gradient of a modulated 1x1 ToRGB convolution (networks.py:352-372, no demodulation) ADDED into an existing
  * gradient:  g[n,c,p] += sum_{k<3} w[k,c] * wscale * style[n,c] * grad_rgb[n,k,p].
  * g (n,c,hw) accumulates, grad_rgb (n,3,hw), w (3,c) = the ToRGB weight, style (n,c) its modulation; hw % 4 == 0,

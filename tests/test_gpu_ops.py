@@ -606,6 +606,27 @@ def test_unsplit_launches_are_bitwise_reproducible(cuda):
         conv_mfma.set_precision(old)
 
 
+@pytest.mark.parametrize('shape', [(2, 3, 8, 8), (1, 2, 6, 10), (3, 5, 16, 32), (2, 4, 2, 2)])
+def test_maxpool2x2_matches_aten(shape, cuda):
+    """VGG16's 2x2 max pooling (torchvision features -> ATen max_pool2d): values, the tie rule (first maximum in
+    row-major order keeps the gradient) and NaN propagation against F.max_pool2d on the CPU, forward and backward."""
+    import torch.nn.functional as F
+    from gangealing_amd.losses import max_pool2x2
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    x = (x * 2).round() / 2                       # half-integer values: many exact ties inside windows
+    x[0, 0, 0, 1] = float('nan')
+    gy = torch.randn(shape[0], shape[1], shape[2] // 2, shape[3] // 2, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 2, 2)
+    ref.backward(gy)
+    xc = x.to(cuda).requires_grad_(True)
+    out = max_pool2x2(xc)
+    out.backward(gy.to(cuda))
+    assert torch.equal(torch.nan_to_num(out.detach().cpu(), nan=123.0), torch.nan_to_num(ref.detach(), nan=123.0))
+    assert torch.equal(xc.grad.cpu(), xr.grad)
+
+
 def test_torch_library_ops_run_the_hip_kernels(cuda):
     """torch.ops.gangealing.{upfirdn2d, fused_leaky_relu, splat2d, mipmap_warp} == the module-level operators,
     including autograd through the registered formulas."""
