@@ -1330,10 +1330,122 @@ __device__ __forceinline__ void pack_weight_body(float* __restrict__ wmat, const
                                                  int cout_g, int cin_g, int kh, int kw, int transpose_io, int flip,
                                                  float scale, long long first, long long stride);
 
+// LDS-staged form of pack_weight_split_body for the one-launch re-pack: the element-wise kernel reads the source
+// with a stride of kk (or cout_g * kk, transposed layout) floats between neighbouring lanes and leans on the caches
+// for the rest of each line (1.4 TB/s over the 43 M trainable weights).  Here a block stages a tile with coalesced
+// reads and writes whole runs of the destination:
+//   plain layout      tile = one output channel c: cin_g * kk contiguous source floats -> kk rows of cin_g bf16
+//   transposed layout tile = 64 reduction channels r x 16 output channels c: per r a run of 16 * kk source floats
+//                     -> per (c, tap) a run of 64 bf16
+// Odd row lengths in LDS (kk = 9 / 1, 16 * kk + 1) keep the transposing reads conflict-free.
+constexpr int PACK_LDS_FLOATS = 64 * (16 * 9 + 1);          // 9280 floats = 37 KB
+constexpr int PACK_RT = 64, PACK_CT = 16;
+
+__device__ __forceinline__ bool pack_tiled_ok(const PackJob& j) {
+  const int kk = j.kh * j.kw;
+  if (!j.limbs || kk > 9) return false;
+  return j.transpose_io ? true : (long long)j.cin_g * kk <= PACK_LDS_FLOATS;
+}
+
+__device__ __forceinline__ void store_limbs(unsigned short* __restrict__ dst, long long limb_stride, int limbs, float v) {
+  for (int l = 0; l < limbs; ++l) {
+    const __bf16 h = (__bf16)v;
+    dst[(size_t)l * limb_stride] = __builtin_bit_cast(unsigned short, h);
+    v -= (float)h;
+  }
+}
+// two neighbouring reduction channels per lane: one 4-byte store per limb (dst 4-byte aligned: even cin_g, even r,
+// even limb_stride)
+__device__ __forceinline__ void store_limbs2(unsigned short* __restrict__ dst, long long limb_stride, int limbs, float a,
+                                             float b) {
+  for (int l = 0; l < limbs; ++l) {
+    const unsigned pk = pack_bf16x2(a, b);
+    *reinterpret_cast<unsigned*>(dst + (size_t)l * limb_stride) = pk;
+    a -= bf16_lo(pk);
+    b -= bf16_hi(pk);
+  }
+}
+
+__device__ void pack_weight_split_tiled(const PackJob& j, float* __restrict__ lds, int block, int nblocks) {
+  const int kk = j.kh * j.kw, tid = threadIdx.x;
+  const int groups = (int)(j.total / ((long long)j.cout_g * j.cin_g * kk));
+  unsigned short* wl = reinterpret_cast<unsigned short*>(j.dst);
+  const bool pairs = (j.cin_g & 1) == 0 && (j.limb_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(wl) & 3) == 0;
+  if (!j.transpose_io) {
+    const int ntiles = groups * j.cout_g, run = j.cin_g * kk;
+    for (int tile = block; tile < ntiles; tile += nblocks) {
+      const float* src = j.src + (size_t)tile * run;          // tile = g * cout_g + c
+      for (int i = tid; i < run; i += 256) lds[i] = src[i] * j.scale;
+      __syncthreads();
+      unsigned short* dst = wl + (size_t)tile * run;
+      if (pairs) {
+        for (int o = 2 * tid; o < run; o += 512) {            // o = tap' * cin_g + r, r even
+          const int tap = o / j.cin_g, r = o - tap * j.cin_g;
+          int ky = tap / j.kw, kx = tap - ky * j.kw;
+          if (j.flip) { ky = j.kh - 1 - ky; kx = j.kw - 1 - kx; }
+          const int t = ky * j.kw + kx;
+          store_limbs2(dst + o, j.limb_stride, j.limbs, lds[r * kk + t], lds[(r + 1) * kk + t]);
+        }
+      } else {
+        for (int o = tid; o < run; o += 256) {
+          const int tap = o / j.cin_g, r = o - tap * j.cin_g;
+          int ky = tap / j.kw, kx = tap - ky * j.kw;
+          if (j.flip) { ky = j.kh - 1 - ky; kx = j.kw - 1 - kx; }
+          store_limbs(dst + o, j.limb_stride, j.limbs, lds[r * kk + ky * j.kw + kx]);
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  const int LD = PACK_CT * kk + 1;
+  const int rt = (j.cin_g + PACK_RT - 1) / PACK_RT, ct = (j.cout_g + PACK_CT - 1) / PACK_CT;
+  const int ntiles = groups * rt * ct;
+  for (int tile = block; tile < ntiles; tile += nblocks) {
+    const int g = tile / (rt * ct), rem = tile - g * rt * ct;
+    const int r0 = (rem / ct) * PACK_RT, c0 = (rem % ct) * PACK_CT;
+    const int nr = min(PACK_RT, j.cin_g - r0), nc = min(PACK_CT, j.cout_g - c0);
+    const int run = nc * kk;
+    // source: ((g * cin_g + r) * cout_g + c) * kk + tap
+    for (int i = tid; i < nr * run; i += 256) {
+      const int r = i / run, e = i - r * run;
+      lds[r * LD + e] = j.src[((size_t)(g * j.cin_g + r0 + r) * j.cout_g + c0) * kk + e] * j.scale;
+    }
+    __syncthreads();
+    // destination: ((g * cout_g + c) * kk + tap') * cin_g + r
+    if (pairs) {
+      for (int o = tid; o < nc * kk * (PACK_RT / 2); o += 256) {
+        const int r = (o & (PACK_RT / 2 - 1)) * 2, ct_ = o >> 5;   // ct_ = c * kk + tap'
+        if (r >= nr) continue;                                  // (nr is even: cin_g is)
+        const int c = ct_ / kk, tap = ct_ - c * kk;
+        int ky = tap / j.kw, kx = tap - ky * j.kw;
+        if (j.flip) { ky = j.kh - 1 - ky; kx = j.kw - 1 - kx; }
+        const int e = c * kk + ky * j.kw + kx;
+        store_limbs2(wl + ((size_t)(g * j.cout_g + c0 + c) * kk + tap) * j.cin_g + r0 + r, j.limb_stride, j.limbs,
+                     lds[r * LD + e], lds[(r + 1) * LD + e]);
+      }
+    } else {
+      for (int o = tid; o < nc * kk * PACK_RT; o += 256) {
+        const int r = o & (PACK_RT - 1), ct_ = o >> 6;
+        if (r >= nr) continue;
+        const int c = ct_ / kk, tap = ct_ - c * kk;
+        int ky = tap / j.kw, kx = tap - ky * j.kw;
+        if (j.flip) { ky = j.kh - 1 - ky; kx = j.kw - 1 - kx; }
+        store_limbs(wl + ((size_t)(g * j.cout_g + c0 + c) * kk + tap) * j.cin_g + r0 + r, j.limb_stride, j.limbs,
+                    lds[r * LD + c * kk + ky * j.kw + kx]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_weight_many_kernel(const PackJob* __restrict__ jobs) {
+  __shared__ float lds[PACK_LDS_FLOATS];
   const PackJob j = jobs[blockIdx.y];
   const long long first = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
-  if (j.limbs)
+  if (pack_tiled_ok(j))
+    pack_weight_split_tiled(j, lds, (int)blockIdx.x, (int)gridDim.x);
+  else if (j.limbs)
     pack_weight_split_body(reinterpret_cast<unsigned short*>(j.dst), j.src, j.total, j.limb_stride, j.cout_g, j.cin_g,
                            j.kh, j.kw, j.transpose_io, j.flip, j.scale, j.limbs, first, stride);
   else

@@ -627,6 +627,38 @@ def test_maxpool2x2_matches_aten(shape, cuda):
     assert torch.equal(xc.grad.cpu(), xr.grad)
 
 
+def test_repack_many_equals_single_packs(cuda):
+    """gg_conv_pack_weights_many (one launch re-packing every trainable weight after the optimizer step; LDS-staged
+    transposes) writes bit for bit what the per-weight entry point writes, for both layouts, flips, 1x1 / 3x3, ragged
+    channel counts and groups."""
+    from gangealing_amd import _lib
+    dt = np.dtype([('dst', '<u8'), ('src', '<u8'), ('total', '<i8'), ('limb_stride', '<i8'), ('cout_g', '<i4'),
+                   ('cin_g', '<i4'), ('kh', '<i4'), ('kw', '<i4'), ('transpose_io', '<i4'), ('flip', '<i4'),
+                   ('limbs', '<i4'), ('scale', '<f4')])
+    g = torch.Generator().manual_seed(21)
+    specs = [  # groups, cout_g, cin_g, k, transpose_io, flip, limbs, scale
+        (1, 512, 512, 3, 0, 0, 2, 0.5), (1, 512, 512, 3, 1, 1, 2, 0.5), (1, 128, 64, 3, 1, 0, 2, 1.0),
+        (1, 128, 64, 1, 0, 0, 2, 1.0), (1, 64, 128, 1, 1, 0, 2, 0.25), (2, 40, 96, 3, 1, 1, 3, 1.0),
+        (2, 40, 96, 3, 0, 1, 1, 1.0), (1, 576, 512, 3, 1, 1, 2, 1.0), (1, 33, 70, 3, 1, 0, 2, 1.0),
+        (1, 64, 3, 3, 0, 0, 2, 1.0),
+    ]
+    keep, rows, singles = [], [], []
+    for (groups, cout_g, cin_g, k, tio, flip, limbs, scale) in specs:
+        shape = (groups * cin_g, cout_g, k, k) if tio else (groups * cout_g, cin_g, k, k)
+        w = torch.randn(*shape, generator=g).to(cuda)
+        n = groups * cout_g * cin_g * k * k
+        many = torch.zeros((limbs, n), dtype=torch.int16, device=cuda)
+        one = torch.zeros((limbs, n), dtype=torch.int16, device=cuda)
+        _lib.call('gg_conv_pack_weight_split', one, w, groups, cout_g, cin_g, k, k, tio, flip, scale, limbs)
+        rows.append((many.data_ptr(), w.data_ptr(), n, n, cout_g, cin_g, k, k, tio, flip, limbs, scale))
+        keep.append((w, many))
+        singles.append(one)
+    jobs = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).reshape(-1).copy()).to(cuda)
+    _lib.call('gg_conv_pack_weights_many', jobs, len(rows))
+    for spec, (_, many), one in zip(specs, keep, singles):
+        assert torch.equal(many, one), spec
+
+
 def test_torch_library_ops_run_the_hip_kernels(cuda):
     """torch.ops.gangealing.{upfirdn2d, fused_leaky_relu, splat2d, mipmap_warp} == the module-level operators,
     including autograd through the registered formulas."""
