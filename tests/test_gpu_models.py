@@ -219,7 +219,7 @@ def test_cluster_classifier_golden(case, cuda):
     net = load_det(net, m['scale_rules']).to(cuda)
     x = T(case['x'], cuda)
     logits = net(x)
-    close(logits, case['logits'], 2e-4)
+    close(logits, case['logits'], 1e-4)
     loss = torch.nn.functional.cross_entropy(logits, T(case['labels'], cuda))
     close(loss, case['loss'], 1e-5)
     loss.backward()
@@ -241,7 +241,7 @@ def test_cluster_classifier_golden(case, cuda):
         assert np.array_equal(flipped.cpu().numpy(), case['run_flip_images'])
         kept, kept_logits = net.run(x, 1)
         assert np.array_equal(kept.cpu().numpy(), case['run_kept'])
-        close(kept_logits, case['run_kept_logits'], 2e-4)
+        close(kept_logits, case['run_kept_logits'], 1e-4)
         cart, policy = net.run_flip_cartesian(x[:2])
         assert np.array_equal(cart.cpu().numpy(), case['cart_images'])
         assert np.array_equal(policy.cpu().numpy(), case['cart_policy'])
@@ -300,9 +300,9 @@ def test_point_transfer_golden(case, cuda):
             out, warp, flow, inputs, flips = stn.forward_with_flip(imgA, return_flow=True, return_warp=True,
                                                                     return_inputs=True, return_flip_indices=True, **kw)
             assert np.array_equal(flips.cpu().numpy(), case['fwf_flips'])
-            close(out, case['fwf_out'], 5e-4)
-            close(warp, case['fwf_warp'], 5e-4)
-            close(flow, case['fwf_flow'], 5e-4)
+            close(out, case['fwf_out'], 1e-4)
+            close(warp, case['fwf_warp'], 1e-4)
+            close(flow, case['fwf_flow'], 1e-4)
             _, _, pa2, pb2, pick = stn.match_flows(imgA, imgB, pts, pts.flip(1), **kw)
             assert np.array_equal(pick.cpu().numpy(), case['mf_pick'])
             close(pa2, case['mf_pointsA'], 1e-4)
@@ -350,7 +350,7 @@ def test_trainer_shortcuts_are_consistent_across_optimizer_steps(cuda):
     from gangealing_amd.op import conv_mfma
     from gangealing_amd.train_step import GangealingTrainer
     tr = GangealingTrainer(cuda, gen_size=64, flow_size=64, batch=2, transform=('similarity', 'flow'), inject=3,
-                           ndirs=2, perturb_heads=0.02, seed=5)
+                           ndirs=2, perturb_heads=0.02, seed=5, stn_lr=1e-4, ll_lr=1e-4)
     off = frozenset(('slots', 'pack_registry', 'style_demod', 'fuse_act', 'lpips_tail', 'mask_dgrad', 'wgrad_rows',
                      'torgb_fuse'))
 
@@ -370,9 +370,13 @@ def test_trainer_shortcuts_are_consistent_across_optimizer_steps(cuda):
     for step in range(3):
         l_off, g_off, gl_off = loss_and_grad(off, 100 + step)
         l_on, g_on, gl_on = loss_and_grad(frozenset(), 100 + step)
-        assert abs(l_on - l_off) <= 2e-5 * abs(l_off), (step, l_on, l_off)
-        assert float((g_on - g_off).abs().max()) <= 2e-3 * float(g_off.abs().max()), step
-        assert float((gl_on - gl_off).abs().max()) <= 1e-2 * float(gl_off.abs().max()) + 1e-9, step
+        # (a stale pack or a lost accumulation is an O(1) relative error; two evaluations of the SAME configuration
+        # differ by split-K atomics ordering, which leaky-ReLU sign flips and the perceptual distance's eps = 1e-10
+        # normalisation occasionally blow up to 1e-3 of the largest gradient entry - hence L2 + a loose worst entry)
+        assert abs(l_on - l_off) <= 2e-4 * abs(l_off), (step, l_on, l_off)
+        assert float((g_on - g_off).norm()) <= 5e-3 * float(g_off.norm()), step
+        assert float((g_on - g_off).abs().max()) <= 5e-2 * float(g_off.abs().max()), step
+        assert float((gl_on - gl_off).abs().max()) <= 5e-2 * float(gl_off.abs().max()) + 1e-9, step
         torch.manual_seed(100 + step)
         tr.step(psi=0.5)                                   # optimizer + EMA + re-pack, shortcuts on
     assert torch.isfinite(tr.stn_arena.param).all()
@@ -574,7 +578,7 @@ def test_stn_inference_options_golden(case, cuda):
                                         output_resolution=96, padding_mode='border')
             assert np.array_equal(oob3.cpu().numpy(), case['oob3'])
             out1, oob1 = stn(x, return_out_of_bounds=True, padding_mode='reflection')
-            close(out1, case['out1'], 2e-4)
+            close(out1, case['out1'], 1e-4)
             assert np.array_equal(oob1.cpu().numpy(), case['oob1'])
             bounds = T(case['bounds'], cuda)
             oob_b = torch.cat([stn(x[i:i + 1], return_out_of_bounds=True, padding_mode='border',
@@ -588,8 +592,8 @@ def test_stn_inference_options_golden(case, cuda):
             out3, grid3, m3 = stn(x, iters=3, return_warp=True, return_flow=True, output_resolution=96,
                                   padding_mode='border')
             outs, mats = stn(x, iters=2, return_intermediates=True, padding_mode='reflection')
-        close(out3, case['out3'], 3e-4)
+        close(out3, case['out3'], 1e-4)
         close(grid3, case['grid3'], 2e-5)
         close(m3, case['m3'], 2e-5)
-        close(torch.stack(outs), case['inter_out'], 3e-4)
+        close(torch.stack(outs), case['inter_out'], 1e-4)
         close(torch.stack(mats), case['inter_m'], 2e-5)
