@@ -565,3 +565,33 @@ def modulated_conv2d(x, weight, style, demodulate=True, upsample=False, blur_ker
         out = conv2d(x.reshape(1, n * cin, h, wd), w.reshape(n * cout, cin, k, k), padding=k // 2, groups=n)
         out = out.reshape(n, cout, h, wd)
     return out
+
+
+def max_pool2x2(x, return_code=False):
+    """2x2 / stride-2 max pooling with ATen's max_pool2d rule (torchvision's VGG16 `features`, reference
+    models/losses/lpips_backbones.py:101-121): the window is scanned row-major and a later element replaces the
+    running maximum only if it is strictly greater or NaN; odd trailing rows / columns are dropped (floor mode).
+    -> out (N, C, H//2, W//2) [, code 0..3 = winner's position dy * 2 + dx]."""
+    x = np.asarray(x)
+    n, c, h, w = x.shape
+    oh, ow = h // 2, w // 2
+    win = np.stack([x[:, :, 0:2 * oh:2, 0:2 * ow:2], x[:, :, 0:2 * oh:2, 1:2 * ow:2],
+                    x[:, :, 1:2 * oh:2, 0:2 * ow:2], x[:, :, 1:2 * oh:2, 1:2 * ow:2]], 0)
+    out = win[0].copy()
+    code = np.zeros(out.shape, np.uint8)
+    for k in range(1, 4):
+        take = (win[k] > out) | np.isnan(win[k])
+        out = np.where(take, win[k], out)
+        code = np.where(take, np.uint8(k), code)
+    return (out, code) if return_code else out
+
+
+def max_pool2x2_backward(grad_out, code, in_hw):
+    """Gradient of max_pool2x2: each output's gradient goes to the winner's position, everything else is zero."""
+    g = np.asarray(grad_out)
+    n, c, oh, ow = g.shape
+    dx = np.zeros((n, c) + tuple(in_hw), g.dtype)
+    for k in range(4):
+        dy_, dx_ = divmod(k, 2)
+        dx[:, :, dy_:2 * oh:2, dx_:2 * ow:2] = np.where(code == k, g, 0)
+    return dx

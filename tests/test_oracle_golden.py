@@ -218,3 +218,22 @@ def test_torch_ref_cluster_classifier_matches_reference(case):
     scores = torch.from_numpy(case['scores'])
     assert float(R.reverse_topk_accuracy(logits, scores)) == float(case['acc1'])
     assert float(R.reverse_topk_accuracy(logits, scores, k=2)) == float(case['acc2'])
+
+
+def test_max_pool_restatement_matches_aten():
+    """np_ops.max_pool2x2 (+ backward) against F.max_pool2d on the CPU - the operator torchvision's VGG16 runs in the
+    reference's perceptual loss - incl. exact ties inside windows, NaNs and odd sizes."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import np_ops
+    rs = np.random.RandomState(3)
+    for shape in [(2, 3, 8, 8), (1, 2, 7, 9), (2, 1, 2, 2)]:
+        x = (rs.randn(*shape) * 2).round().astype(np.float32) / 2
+        x[0, 0, 0, 1] = np.nan
+        xt = torch.from_numpy(x).requires_grad_(True)
+        ref = F.max_pool2d(xt, 2, 2)
+        g = rs.randn(*ref.shape).astype(np.float32)
+        ref.backward(torch.from_numpy(g))
+        out, code = np_ops.max_pool2x2(x, return_code=True)
+        np.testing.assert_array_equal(np.nan_to_num(out, nan=123.0), np.nan_to_num(ref.detach().numpy(), nan=123.0))
+        np.testing.assert_array_equal(np_ops.max_pool2x2_backward(g, code, shape[2:]), xt.grad.numpy())
