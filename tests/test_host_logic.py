@@ -267,3 +267,28 @@ def test_torch_library_ops_are_registered_with_fake_kernels():
             assert torch.ops.gangealing.conv2d(x, w, None, 2, 1, 1).shape == (2, 7, 4, 4)
             wt = torch.empty(3, 5, 3, 3, device='cuda')
             assert torch.ops.gangealing.conv_transpose2d(x, wt, None, 2, 0, 0, 1).shape == (2, 5, 17, 17)
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The bench line committed under profiles/ (printed by bench.py on the GPU box) carries every field of the driver's
+    contract, BASELINE.json's metric, a self-consistent roofline entry and the CPU baseline."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.loads(open(os.path.join(root, 'profiles', 'bench_r02_bf16x3.json')).read().strip().splitlines()[-1])
+    base = json.load(open(os.path.join(root, 'BASELINE.json')))
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in line, key
+    assert line['metric'].split(',')[0] in json.dumps(base) and line['unit'] == 'images/sec'
+    assert line['higher_is_better'] is True and line['scaling'] == 'weak' and line['vs_baseline'] is None
+    assert line['data'] == 'synthetic' and 'workload' in line['config'] and 'model' not in line['config']
+    # value = images of the whole job / time of exactly `steps` iterations
+    assert abs(line['value'] - line['config']['global_batch'] * 1e3 / line['ms_per_step']) < 1e-2 * line['value']
+    r = line['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0 < r['frac'] < 1
+    assert abs(r['achieved'] - r['avg_launch_gflop'] / r['avg_launch_ms']) < 1e-2 * r['achieved']     # GFLOP / ms = TFLOP/s
+    assert r['traffic'] is None or r['traffic'] > 0
+    c = line['cpu_baseline']
+    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
