@@ -49,6 +49,43 @@ def set_precision(mode):
     PRECISION = mode
 
 
+# The similarity STN regresses FOUR numbers (rotation, scale, shift) that place every output sample: a relative error
+# of 4e-5 in them - what two bf16 limbs leave after the 14 convolutions of its trunk - moves the samples near the image
+# corners by ~1e-3 pixel, i.e. 3e-4 on a textured image of amplitude 2, above north_star's 1e-4.  Every layer of the
+# trunk contributes about equally (scripts/study_bf16x3_stn.py: an emulation of the limb arithmetic on the reference
+# STN; upgrading only the <= 8^2 or <= 32^2 layers leaves 1.6e-4 / 1.2e-4), so in the bf16x3 mode the FORWARD pass of
+# that trunk (12.6 GFLOP per image, 3 % of the step's convolution work) runs with three limbs (fp32-class products:
+# 4.8e-5 in the same study); its backward stays on two limbs, like everything else.  GANGEALING_SIM_PRECISION overrides.
+REGRESSION_PRECISION = {'bf16x3': _os.environ.get('GANGEALING_SIM_PRECISION', 'bf16x6')}
+
+
+class forward_precision:
+    """Context manager: the convolutions issued inside run in `mode` (None: unchanged).  Backward passes read the
+    global mode when THEY run, so this only affects forward launches."""
+
+    def __init__(self, mode):
+        if mode is not None and mode not in _LIMBS:
+            raise ValueError(f'unknown conv precision {mode!r}')
+        self.mode = mode
+
+    def __enter__(self):
+        global PRECISION
+        self.prev = PRECISION
+        if self.mode is not None:
+            PRECISION = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global PRECISION
+        PRECISION = self.prev
+        return False
+
+
+def regression_precision():
+    """forward_precision for the similarity STN's regression trunk under the current global mode."""
+    return forward_precision(REGRESSION_PRECISION.get(PRECISION))
+
+
 class PackedWeight:
     """GEMM-layout view(s) of one convolution weight, built lazily per arithmetic mode.
     (cout_g, cin_g) are those OF THE CONVOLUTION BEING RUN (reduction channels = cin_g)."""

@@ -10,6 +10,7 @@ import torch.nn as nn
 from .antialiased_sampling import BilinearDownsample
 from .warping_heads import SimilarityHead, FlowHead
 from ..stylegan2.networks import EqualLinear, ConvLayer, ResBlock, CHANNELS
+from ..op import conv_mfma
 from .point_transfer import ComposedStnPointOps, SingleStnPointOps, unravel_index  # noqa: F401
 
 
@@ -137,8 +138,13 @@ class SpatialTransformer(SingleStnPointOps, nn.Module):
         """spatial_transformer.py:569-615.  pack=True returns everything the warp head returned."""
         regression_input = self.input_downsample(input_img) if input_img.size(-1) > self.stn_in_size else input_img
         source = input_img if input_img_for_sampling is None else input_img_for_sampling
-        feats = self.final_conv(self.convs(regression_input))
-        if not self.is_flow:
+        if self.is_flow:
+            feats = self.final_conv(self.convs(regression_input))
+        else:
+            # the four similarity parameters place every output sample: their trunk runs with fp32-class products in
+            # the split-precision mode (conv_mfma.REGRESSION_PRECISION)
+            with conv_mfma.regression_precision():
+                feats = self.final_conv(self.convs(regression_input))
             feats = self.final_linear(feats.view(feats.shape[0], -1))
         res = output_resolution if output_resolution is not None else self.stn_in_size
         out, grid, m, oob = self.warp_head(source, feats, output_resolution=res, base_warp=base_warp,

@@ -192,12 +192,12 @@ def test_c2_stn_batch16(ci, mode, cuda):
                     input_img_for_sampling=x if m['sample_from_full_res'] else None)
     test = f'c2_stn[{ci}]'
     # (image-like input, oracle/config_cases.smooth_images: on WHITE NOISE, where neighbouring pixels differ by ~0.7, a
-    # flow error of 1e-6 - 1e-4 pixel - already moves the bilinear sample by 1e-4; measured there: 3e-5 fp32, 1.6e-4 bf16x3)
-    # `out` in bf16x3: the similarity parameters (rotation, scale, shift) come out of 8192-long dot products with
-    # ~5e-6 relative error, which moves the samples near the image corners by ~1e-3 pixel - 1.2e-4 .. 3.3e-4 on this
-    # textured input of amplitude 2 (fp32 kernels: 4e-5); the benchmark configuration's own images stay below 6e-5 in
-    # both modes (test_config_loss_step).  The flow is held to 1e-4 in both modes.
-    check_batch(test, mode, out, c, 'out', tol=ACT_TOL if mode == 'fp32' else 2.5e-4)
+    # flow error of 1e-6 - 1e-4 pixel - already moves the bilinear sample by 1e-4.)
+    # Both arithmetic modes are held to the same 1e-4.  In bf16x3 the similarity trunk's FORWARD runs with three limbs
+    # (conv_mfma.REGRESSION_PRECISION): with two, the four similarity parameters carried ~4e-5 relative error, which
+    # moved the samples near the image corners by ~1e-3 pixel - 3.3e-4 on this textured input of amplitude 2
+    # (round 2, and reproduced on CPU by scripts/study_bf16x3_stn.py, which also predicts 4.8e-5 for this form).
+    check_batch(test, mode, out, c, 'out')
     check_batch(test, mode, flow, c, 'flow')
     gout = D(f'c2stn.g{ci}', tuple(out.shape), cuda)
     loss = (out * gout).mean() + 10.0 * total_variation_loss(flow) + flow_identity_loss(flow)
