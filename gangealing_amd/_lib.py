@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GANGEALING_HIP_LIB selects another build of the same library (kernel A/B measurements); the ABI check still applies.
 LIB_PATH = os.environ.get('GANGEALING_HIP_LIB') or os.path.join(_HERE, 'lib', 'libgangealing_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 NOT_SERVED = -1000            # GG_NOT_SERVED of the header
 
 # signature alphabet: p device pointer (tensor or None), i int, q long long, f float, d double, s stream
@@ -70,6 +70,7 @@ _PROTOS = {
     'gg_upfirdn2d_add_f32': 'ppppiiiiiiiiiiiiis',
     'gg_add_scale_f32': 'pppfqs',
     'gg_style_bank_f32': 'ppqipiipiiis',
+    'gg_scratch_reserve': 'qs',
 }
 _CTYPE = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'q': ctypes.c_longlong, 'f': ctypes.c_float,
           'd': ctypes.c_double, 's': ctypes.c_void_p}
@@ -82,7 +83,7 @@ class HipLibraryError(RuntimeError):
 
 
 def exported_symbols():
-    return ['gg_abi_version', 'gg_last_error', 'gg_build_arch'] + sorted(_PROTOS)
+    return ['gg_abi_version', 'gg_last_error', 'gg_build_arch', 'gg_scratch_release'] + sorted(_PROTOS)
 
 
 def load():
@@ -98,6 +99,8 @@ def load():
     lib.gg_abi_version.restype = ctypes.c_int
     lib.gg_last_error.restype = ctypes.c_char_p
     lib.gg_build_arch.restype = ctypes.c_char_p
+    lib.gg_scratch_release.restype = ctypes.c_int
+    lib.gg_scratch_release.argtypes = []
     if lib.gg_abi_version() != ABI_VERSION:
         raise HipLibraryError(f'ABI mismatch: library {lib.gg_abi_version()} != python {ABI_VERSION}; rebuild')
     for name, proto in _PROTOS.items():

@@ -14,8 +14,8 @@
 //   narrow:  32 co x 256 pix, waves 1x4, each wave 1x2 MFMA tiles  (ToRGB / flow heads, Cout <= 32)
 // K is consumed in BK = 16 slabs, register-staged double buffering (global loads of slab t+1 are in
 // flight while slab t is multiplied; one __syncthreads per slab).  Small spatial layers (4^2..16^2)
-// do not produce 256 tiles, so K is split across blockIdx.y and partial sums are combined with
-// fp32 atomics (the epilogue is linear: out_scale * partial, bias added by split 0).
+// do not produce 256 tiles, so K is split across blockIdx.y; the splits' raw partial sums go to the stream's scratch
+// and a reduce pass adds them in a fixed order and applies the epilogue (no float atomics: bitwise reproducible).
 //
 // The modulated convolution (networks.py:233-282) is run in its shared-weight form: the per-sample
 // style multiplies the activation while it is gathered (in_scale) and the demodulation multiplies
@@ -72,6 +72,12 @@ struct ConvArgs {
   const float* act_noise_w;       // device scalar
   const float* act_bias;          // (groups*cout_g)
   float act_alpha, act_gain;
+  // split-K launches (and launches that share an output with one): instead of y, block (tile, split) writes its RAW
+  // accumulators to part + split * part_stride (same element offsets as y); splitk_reduce_kernel then adds the
+  // splits in ascending order and applies out_scale / bias / activation.  A fixed summation order: results are
+  // bitwise reproducible (float atomics onto y would combine the splits in arrival order).
+  float* part;
+  long long part_stride;
 };
 
 // k -> (ci, ky, kx, dy, dx).  MODE 0: correlation taps; MODE 1: taps of one parity class.
@@ -244,7 +250,8 @@ __global__ __launch_bounds__(WCO * WPIX * 64) void conv_igemm_kernel(const ConvA
 
   // ---- epilogue: D[co][pix], lane -> pixel (lane & 31), reg r -> co = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int ohw = a.oh * a.ow;
-  const bool atomic = a.splitk > 1;
+  const bool partial = a.part != nullptr;
+  float* ybase = partial ? a.part + (size_t)split * a.part_stride : a.y;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const long long mm = m0 + (wpix * NJ + j) * 32 + (lane & 31);
@@ -255,9 +262,9 @@ __global__ __launch_bounds__(WCO * WPIX * 64) void conv_igemm_kernel(const ConvA
     const int qy = rem / a.mw, qx = rem - qy * a.mw;
     const int oy = qy * a.ys + a.yo, ox = qx * a.xs + a.xo;
     const int ochan0 = (on * a.groups + g) * a.cout_g;
-    float* yp = a.y + (size_t)ochan0 * ohw + (size_t)oy * a.ow + ox;
-    const float* osc = a.out_scale ? a.out_scale + ochan0 : nullptr;
-    const float* bia = (a.bias && split == 0) ? a.bias + g * a.cout_g : nullptr;
+    float* yp = ybase + (size_t)ochan0 * ohw + (size_t)oy * a.ow + ox;
+    const float* osc = (a.out_scale && !partial) ? a.out_scale + ochan0 : nullptr;
+    const float* bia = (a.bias && !partial) ? a.bias + g * a.cout_g : nullptr;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -267,8 +274,7 @@ __global__ __launch_bounds__(WCO * WPIX * 64) void conv_igemm_kernel(const ConvA
         float v = acc[i][j][r];
         if (osc) v *= osc[co];
         if (bia) v += bia[co];
-        if (atomic) unsafeAtomicAdd(yp + (size_t)co * ohw, v);
-        else yp[(size_t)co * ohw] = v;
+        yp[(size_t)co * ohw] = v;
       }
     }
   }
@@ -495,7 +501,8 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
   }
 
   const int ohw = a.oh * a.ow;
-  const bool atomic = a.splitk > 1;
+  const bool partial = a.part != nullptr;
+  float* ybase = partial ? a.part + (size_t)split * a.part_stride : a.y;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const long long mm = m0 + (wpix * NJ + j) * 32 + (lane & 31);
@@ -506,9 +513,9 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
     const int qy = rem / a.mw, qx = rem - qy * a.mw;
     const int oy = qy * a.ys + a.yo, ox = qx * a.xs + a.xo;
     const int ochan0 = (on * a.groups + g) * a.cout_g;
-    float* yp = a.y + (size_t)ochan0 * ohw + (size_t)oy * a.ow + ox;
-    const float* osc = a.out_scale ? a.out_scale + ochan0 : nullptr;
-    const float* bia = (a.bias && split == 0) ? a.bias + g * a.cout_g : nullptr;
+    float* yp = ybase + (size_t)ochan0 * ohw + (size_t)oy * a.ow + ox;
+    const float* osc = (a.out_scale && !partial) ? a.out_scale + ochan0 : nullptr;
+    const float* bia = (a.bias && !partial) ? a.bias + g * a.cout_g : nullptr;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -518,8 +525,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
         float v = acc[i][j][r];
         if (osc) v *= osc[co];
         if (bia) v += bia[co];
-        if (atomic) unsafeAtomicAdd(yp + (size_t)co * ohw, v);
-        else yp[(size_t)co * ohw] = v;
+        yp[(size_t)co * ohw] = v;
       }
     }
   }
@@ -857,26 +863,22 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
     return;
   }
 #endif
-  const bool atomic = a.splitk > 1;
   const int ochan0 = (pn * a.groups + g) * a.cout_g;
   const float* osc = a.out_scale ? a.out_scale + ochan0 : nullptr;
-  const float* bia = (a.bias && split == 0) ? a.bias + g * a.cout_g : nullptr;
-  if (atomic) {
+  const float* bia = a.bias ? a.bias + g * a.cout_g : nullptr;
+  if (a.part) {               // split-K: raw partial sums; splitk_reduce_kernel finishes (scale, bias, activation)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int p = (wpix * NJ + j) * 32 + (lane & 31);
       const int oy = y0 + (p >> tw_log2), ox = x0 + (p & (TW - 1));
-      float* yp = a.y + (size_t)ochan0 * hw + (size_t)oy * a.w + ox;
+      float* yp = a.part + (size_t)split * a.part_stride + (size_t)ochan0 * hw + (size_t)oy * a.w + ox;
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + (wco * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           if (co >= a.cout_g) continue;
-          float v = acc[i][j][r];
-          if (osc) v *= osc[co];
-          if (bia) v += bia[co];
-          unsafeAtomicAdd(yp + (size_t)co * hw, v);
+          yp[(size_t)co * hw] = acc[i][j][r];
         }
       }
     }
@@ -1182,12 +1184,11 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
     return;
   }
 #endif
-  const bool atomic = a.splitk > 1;
   const int ohw = a.oh * a.ow;
   const int ochan0 = (pn * a.groups + g) * a.cout_g;
   const float* osc = a.out_scale ? a.out_scale + ochan0 : nullptr;
-  const float* bia = (a.bias && split == 0) ? a.bias + g * a.cout_g : nullptr;
-  if (atomic) {
+  const float* bia = a.bias ? a.bias + g * a.cout_g : nullptr;
+  if (a.part) {               // split-K: raw partial sums; splitk_reduce_kernel finishes (scale, bias)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -1195,15 +1196,12 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
         const int p = (wpix * NJ + j) * 32 + l31;
         const int oy = 2 * (y0 + (p >> tw_log2)) + (c >> 1) - pad, ox = 2 * (x0 + (p & (TW - 1))) + (c & 1) - pad;
         if ((unsigned)oy >= (unsigned)a.oh || (unsigned)ox >= (unsigned)a.ow) continue;
-        float* yp = a.y + (size_t)ochan0 * ohw + (size_t)oy * a.ow + ox;
+        float* yp = a.part + (size_t)split * a.part_stride + (size_t)ochan0 * ohw + (size_t)oy * a.ow + ox;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           if (co >= a.cout_g) continue;
-          float v = acc[c][j][r];
-          if (osc) v *= osc[co];
-          if (bia) v += bia[co];
-          unsafeAtomicAdd(yp + (size_t)co * ohw, v);
+          yp[(size_t)co * ohw] = acc[c][j][r];
         }
       }
     }
@@ -1458,8 +1456,8 @@ __global__ __launch_bounds__(256) void pack_weight_many_kernel(const PackJob* __
 //   D[i = co][j = (ci,ky,kx)], reduction index k = pixel.  Both global operands are contiguous
 //   along the pixel axis, so they are loaded lane-along-k (128 B rows) and stored to LDS as
 //   [k][row] with an odd row stride (129): lane-along-k writes and lane-along-row fragment reads
-//   are both conflict free.  K (= N*OH*OW, up to 10^6) is split across blockIdx.y; partial tiles
-//   are combined with fp32 atomics into the zero-initialised dW.
+//   are both conflict free.  K (= N*OH*OW, up to 10^6) is split across blockIdx.y; partial tiles go to the
+//   stream's scratch and are summed in split order by a reduce pass (no float atomics: reproducible).
 // ------------------------------------------------------------------------------------------------
 constexpr int WBK = 32;
 constexpr int WT = 128;          // tile edge (co and j)
@@ -1481,6 +1479,10 @@ struct WgradArgs {
   const float* mask_ref;
   float mask_alpha, mask_gain;
   float* dbias;
+  // generic kernels: K-splits write their raw tiles to part[(split * groups + g) * cout_g * jtot + ...] (summed in
+  // split order by a reduce pass - no float atomics); null: a single split stores (or adds, `accumulate`) into dw
+  float* part;
+  int accumulate;
 };
 
 template <int KS>
@@ -1592,7 +1594,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
   }
   // D[i = co][j]: lane -> j column (lane & 31), reg r -> co row
-  float* dwg = a.dw + (size_t)g * a.cout_g * a.jtot;
+  float* dwg = a.part ? a.part + ((size_t)blockIdx.y * a.groups + g) * a.cout_g * a.jtot
+                      : a.dw + (size_t)g * a.cout_g * a.jtot;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int jj = j0 + (wj * 2 + j) * 32 + (lane & 31);
@@ -1603,7 +1606,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + (wco * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (co >= a.cout_g) continue;
-        unsafeAtomicAdd(dwg + (size_t)co * a.jtot + jj, acc[i][j][r] * a.scale);
+        float* d = dwg + (size_t)co * a.jtot + jj;
+        if (a.part) *d = acc[i][j][r];
+        else *d = (a.accumulate ? *d : 0.f) + acc[i][j][r] * a.scale;
       }
     }
   }
@@ -1616,7 +1621,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 // bf16 matrix pipe.  The reduction index (pixels) is the contiguous axis of BOTH global operands, which
 // is exactly the k-contiguous [row][k] LDS layout the bf16 fragments want: a thread loads 4 consecutive
 // pixels of one row (16 B; 8 lanes cover a 128 B line), splits them into limbs and writes 8 B per limb.
-// K (= N*OH*OW) is split across blockIdx.y; partial tiles are combined with fp32 atomics.
+// K (= N*OH*OW) is split across blockIdx.y; partial tiles go to scratch and are summed in split order.
 // ------------------------------------------------------------------------------------------------
 template <int KS, int LIMBS>
 __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradArgs a) {
@@ -1748,7 +1753,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradArgs a
       __syncthreads();
     }
   }
-  float* dwg = a.dw + (size_t)g * a.cout_g * a.jtot;
+  float* dwg = a.part ? a.part + ((size_t)blockIdx.y * a.groups + g) * a.cout_g * a.jtot
+                      : a.dw + (size_t)g * a.cout_g * a.jtot;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int jj = j0 + (wj * NJ + j) * 32 + (lane & 31);
@@ -1759,7 +1765,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradArgs a
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + (wco * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (co >= a.cout_g) continue;
-        unsafeAtomicAdd(dwg + (size_t)co * a.jtot + jj, acc[i][j][r] * a.scale);
+        float* d = dwg + (size_t)co * a.jtot + jj;
+        if (a.part) *d = acc[i][j][r];
+        else *d = (a.accumulate ? *d : 0.f) + acc[i][j][r] * a.scale;
       }
     }
   }
@@ -1776,7 +1784,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradArgs a
 //   * the B fragment of tap (ky, kx) is 8 consecutive pixels of row slot (y+ky-1) starting at px+kx-1: kx = 1
 //     is an aligned 16-byte read, kx = 0 / 2 are built from it and one neighbouring dword with v_alignbit.
 // Each wave owns 32 co x 32 ci and keeps the nine 32x32 accumulators (one per tap): 54 MFMAs per slab.
-// K-splits (image, strip, row block) are combined with fp32 atomics into dw (torch layout [co][ci][3][3]).
+// K-splits (image, strip, row block) go to the workspace [tile][split][tap][co][ci] and are summed in split order by
+// wgrad_reduce_kernel into dw (torch layout [co][ci][3][3]).
 // ------------------------------------------------------------------------------------------------
 // SW = strip width: 32 (one image row segment per 32-pixel slab) or 16 (16-wide images: a slab is TWO full rows, the
 // window holds 4 rows and the k-half of a fragment selects the row instead of the column)
@@ -1990,12 +1999,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
   }
 
   if (MASK && dbws && tile_ci == 0) {
-    // bias gradient: per-row sums of this block (LDS atomics), one plain store per (split, channel); summed by
-    // wgrad_reduce_kernel.  (Global atomics onto the <= 512 bias addresses from every block serialise.)
+    // bias gradient: per-row sums of this block, one plain store per (split, channel); summed by wgrad_reduce_kernel
     float* sdb = reinterpret_cast<float*>(&sD[0][0]);          // the main loop's last barrier freed sD
-    if (tid < TCO) sdb[tid] = 0.f;
-    __syncthreads();
-    atomicAdd(&sdb[drow], bsum);
+    float rowsum = bsum;                                       // the DPARTS movers of a row are neighbouring lanes
+#pragma unroll
+    for (int m = 1; m < DPARTS; m <<= 1) rowsum += __shfl_xor(rowsum, m, 64);
+    if (dpart == 0) sdb[drow] = rowsum;
     __syncthreads();
     if (tid < TCO && co0 + tid < a.cout_g)
       dbws[((size_t)blockIdx.y * a.groups + g) * a.cout_g + co0 + tid] = sdb[tid];
@@ -2014,18 +2023,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rows_kernel(const WgradA
       }
     return;
   }
-  float* dwg = a.dw + (size_t)g * a.cout_g * a.cin_g * 9;
-  const int ci = ci0 + wci * 32 + l31;
-  if (ci < a.cin_g) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (co >= a.cout_g) continue;
-      float* dst = dwg + ((size_t)co * a.cin_g + ci) * 9;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) unsafeAtomicAdd(dst + t, acc[t][r] * a.scale);
-    }
-  }
+  // (no workspace: not launched - the host falls back to the generic kernel)
 }
 
 // 1x1 / stride 1 weight gradient with very few input channels (the STN's 3 -> 64 RGB stem): dW[co][ci] =
@@ -2077,6 +2075,18 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(float* __restrict__ ou
   for (int b = lane; b < nblocks; b += 64) sum += ws[(size_t)b * count + i];
   sum = gg::wave_sum(sum);
   if (lane == 0) out[i] = (accumulate ? out[i] : 0.f) + sum * scale;
+}
+
+// out[i] (+)= scale * sum_b ws[b * count + i], one thread per element (few partials, many elements; coalesced)
+__global__ __launch_bounds__(256) void partial_sum_flat_kernel(float* __restrict__ out, const float* __restrict__ ws,
+                                                               int nblocks, long long count, float scale,
+                                                               int accumulate) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    float sum = ws[i];
+    for (int b = 1; b < nblocks; ++b) sum += ws[(size_t)b * count + i];
+    out[i] = (accumulate ? out[i] : 0.f) + sum * scale;
+  }
 }
 
 // dw[g][co][ci][tap] (+)= scale * sum_split ws[tile][split][tap][co_l][ci_l]
@@ -2172,6 +2182,78 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(float* __restrict__ out,
   }
   const float tot = gg::block_sum_256<float>(acc, red);
   if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+
+// y = epilogue(sum over splits of part[s]), splits added in ascending order (see ConvArgs::part).  The epilogue is the
+// one the un-split kernels apply: * out_scale[n, c], + bias[c], then optionally the StyledConv tail
+// lrelu(v + noise_w * noise[n, pix] + act_bias[c]) * gain.  VEC = 4 needs ohw % 4 == 0 (a float4 never straddles planes).
+template <int VEC>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ y, const float* __restrict__ part,
+                                                            long long stride, int splits, long long nvec,
+                                                            const ConvArgs a) {
+  const long long ohw = (long long)a.oh * a.ow;
+  const int C = a.groups * a.cout_g;
+  const float anw = (a.act && a.act_noise) ? a.act_noise_w[0] : 0.f;
+  const long long gstride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gstride) {
+    const long long e = i * VEC;
+    float v[VEC];
+    if (VEC == 4) {
+      float4 t = *reinterpret_cast<const float4*>(part + e);
+      for (int sidx = 1; sidx < splits; ++sidx) {
+        const float4 u = *reinterpret_cast<const float4*>(part + (size_t)sidx * stride + e);
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      v[0] = t.x; v[1 % VEC] = t.y; v[2 % VEC] = t.z; v[3 % VEC] = t.w;
+    } else {
+      float t = part[e];
+      for (int sidx = 1; sidx < splits; ++sidx) t += part[(size_t)sidx * stride + e];
+      v[0] = t;
+    }
+    const long long plane = e / ohw;
+    const int c = (int)(plane % C);
+    const float sc = a.out_scale ? a.out_scale[plane] : 1.f, bi = a.bias ? a.bias[c] : 0.f;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) v[q] = a.out_scale ? v[q] * sc + bi : v[q] + bi;
+    if (a.act) {
+      const long long n = plane / C, p = e - plane * ohw;
+      const float ab = a.act_bias ? a.act_bias[c] : 0.f;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        const float t = v[q] + (a.act_noise ? anw * a.act_noise[n * ohw + p + q] : 0.f) + ab;
+        v[q] = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
+      }
+    }
+    if (VEC == 4) *reinterpret_cast<float4*>(y + e) = make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]);
+    else y[e] = v[0];
+  }
+}
+
+// Scratch for `splits` partial copies of the output of `a`; sets a.part / a.part_stride.  zero: clear it first
+// (launches that do not cover every output element: parity-class plans of the generic transposed path).
+int splitk_prepare(ConvArgs& a, int splits, bool zero, hipStream_t st) {
+  const long long elems = (long long)a.batch * a.groups * a.cout_g * a.oh * a.ow;
+  a.part_stride = (elems + 3) / 4 * 4;
+  const size_t bytes = sizeof(float) * (size_t)a.part_stride * splits;
+  a.part = reinterpret_cast<float*>(gg::scratch(st, bytes));
+  if (!a.part) return -3;
+  if (zero) {
+    hipError_t e = hipMemsetAsync(a.part, 0, bytes, st);
+    if (e != hipSuccess) return gg::fail((int)e, "conv2d: memset failed");
+  }
+  return 0;
+}
+
+int splitk_reduce(const ConvArgs& a, int splits, hipStream_t st) {
+  const long long elems = (long long)a.batch * a.groups * a.cout_g * a.oh * a.ow;
+  const long long ohw = (long long)a.oh * a.ow;
+  if (ohw % 4 == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
+      (!a.act_noise || (reinterpret_cast<uintptr_t>(a.act_noise) & 3) == 0))
+    splitk_reduce_kernel<4><<<gg::stream_grid(elems / 4, 256), 256, 0, st>>>(a.y, a.part, a.part_stride, splits,
+                                                                             elems / 4, a);
+  else
+    splitk_reduce_kernel<1><<<gg::stream_grid(elems, 256), 256, 0, st>>>(a.y, a.part, a.part_stride, splits, elems, a);
+  return gg::launch_status("splitk_reduce");
 }
 
 // Fill in tiling / split-K for one launch.  Returns false when the launch is empty.
@@ -2287,8 +2369,8 @@ static int split_at_patch() {
   static const int v = env_int("GG_SPLIT_PATCH", 2 * gg::kNumCu);
   return v;
 }
-// The transposed kernel's split-K epilogue is four classes of scattered atomics onto a zero-filled output, so it only
-// pays when most of the chip would otherwise idle.  Measured per generator pass at batch 16 (512 -> 512 channels):
+// The transposed kernel's split-K epilogue is four classes of scattered 4-byte stores plus a reduce pass, so it only
+// pays when most of the chip would otherwise idle (thresholds measured with the round-2 atomic epilogue).  Measured per generator pass at batch 16 (512 -> 512 channels):
 // 16^2 -> 33^2 (384 blocks) 0.308 ms split in two vs 0.143 unsplit; 8^2 -> 17^2 (192 blocks) 0.154 vs 0.124;
 // 4^2 -> 9^2 (128 blocks) 0.093 split vs 0.121 unsplit.
 static int split_at_convt() {
@@ -2327,15 +2409,11 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
   }
   a.slabs_per_split = (a.nslabs + splitk - 1) / splitk;
   a.splitk = (a.nslabs + a.slabs_per_split - 1) / a.slabs_per_split;
-  if (a.splitk > 1) {
-    const size_t out_elems = (size_t)a.batch * a.groups * a.cout_g * a.oh * a.ow;
-    hipError_t e = hipMemsetAsync(a.y, 0, sizeof(float) * out_elems, st);
-    if (e != hipSuccess) return gg::fail((int)e, "conv2d: memset failed");
+  if (a.splitk > 1) {       // every output element is covered by exactly one tile per split: no clearing needed
+    if (int rc = splitk_prepare(a, a.splitk, false, st)) return rc;
   }
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
-  const ConvArgs full = a;
-  if (a.splitk > 1) a.act = 0;                              // atomically combined partials: activation afterwards
   if (a.mask_ref) {          // limbs == 2 (checked by the caller)
     if (narrow && tpix == 256) {
       if (sc) LIMBS12(limbs, conv3x3_patch_kernel<L, true, 256, 1, true><<<grid, 512, 0, st>>>(a, tw_log2));
@@ -2367,8 +2445,8 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
     else conv3x3_patch_kernel<3, false, 128><<<grid, 256, 0, st>>>(a, tw_log2);
   }
   const int rc = gg::launch_status("conv3x3_patch");
-  if (rc || !full.act || a.act) return rc;
-  return post_activation(full, st);
+  if (rc || a.splitk <= 1) return rc;
+  return splitk_reduce(a, a.splitk, st);                    // + out_scale / bias / fused activation
 }
 
 // all-classes transposed 3x3 / stride 2 kernel: power-of-two input width >= 4
@@ -2403,7 +2481,12 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   }
   a.slabs_per_split = (a.nslabs + splitk - 1) / splitk;
   a.splitk = (a.nslabs + a.slabs_per_split - 1) / a.slabs_per_split;
+  // the q-grid's classes cover output rows / columns [-pad, 2 * size + 1 - pad]; anything beyond (output_padding
+  // with pad > 0) receives no contribution and has to read as zero
+  const bool covered = a.oh - 1 <= 2 * a.h + 1 - pad && a.ow - 1 <= 2 * a.w + 1 - pad;
   if (a.splitk > 1) {
+    if (int rc = splitk_prepare(a, a.splitk, !covered, st)) return rc;
+  } else if (!covered) {
     const size_t out_elems = (size_t)a.batch * a.groups * a.cout_g * a.oh * a.ow;
     hipError_t e = hipMemsetAsync(a.y, 0, sizeof(float) * out_elems, st);
     if (e != hipSuccess) return gg::fail((int)e, "conv2d: memset failed");
@@ -2420,7 +2503,9 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
     if (sc) convT3x3s2_patch_kernel<3, true, 64><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
     else convT3x3s2_patch_kernel<3, false, 64><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
   }
-  return gg::launch_status("convT3x3s2_patch");
+  const int rc = gg::launch_status("convT3x3s2_patch");
+  if (rc || a.splitk <= 1) return rc;
+  return splitk_reduce(a, a.splitk, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2570,8 +2655,15 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
       }
     }
   }
-  for (int i = 0; i < nplans; ++i) needs_zero = needs_zero || plans[i].splitk > 1;
-  if (needs_zero) {   // split-K partials are combined with atomics -> start from zero
+  int max_split = 1;
+  for (int i = 0; i < nplans; ++i) max_split = plans[i].splitk > max_split ? plans[i].splitk : max_split;
+  if (max_split > 1) {
+    // split-K somewhere: EVERY plan writes raw partials (its splits of the scratch copies; parity-class plans write
+    // disjoint output positions), then one reduce pass adds the copies in order and applies the epilogue.  With more
+    // than one plan (or a class that receives no tap) a copy is not fully covered by its writers: cleared first.
+    if (int rc = splitk_prepare(a, max_split, mode == 1, st)) return rc;
+    for (int i = 0; i < nplans; ++i) { plans[i].part = a.part; plans[i].part_stride = a.part_stride; }
+  } else if (needs_zero) {   // a parity class without taps stays zero
     const size_t out_elems = (size_t)a.batch * a.groups * a.cout_g * a.oh * a.ow;
     hipError_t e = hipMemsetAsync(a.y, 0, sizeof(float) * out_elems, st);
     if (e != hipSuccess) return gg::fail((int)e, "conv2d: memset failed");
@@ -2582,7 +2674,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     else rc = (mode == 0) ? launch_conv<KS, 0>(plans[i], narrow, st) : launch_conv<KS, 1>(plans[i], narrow, st);
     if (rc) return rc;
   }
-  return 0;
+  return max_split > 1 ? splitk_reduce(a, max_split, st) : 0;
 }
 
 }  // namespace
@@ -2635,6 +2727,7 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   ConvArgs a;
   a.y = y; a.x = x; a.wmat = wmat; a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
   a.wsplit = wsplit; a.wsplit_stride = wsplit_stride;
+  a.part = nullptr; a.part_stride = 0;
   a.mask_ref = mask.ref; a.mask_alpha = mask.alpha; a.mask_gain = mask.gain;
   a.act = act.on; a.act_noise = act.noise; a.act_noise_w = act.noise_w; a.act_bias = act.bias;
   a.act_alpha = act.alpha; a.act_gain = act.gain;
@@ -2736,6 +2829,7 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
   a.ow = (w + 2 * pad - ksize) / stride + 1;
   a.stride = stride; a.pad = pad; a.scale = scale;
   a.mask_ref = mask_ref; a.mask_alpha = mask_alpha; a.mask_gain = mask_gain; a.dbias = dbias;
+  a.part = nullptr; a.accumulate = accumulate ? 1 : 0;
   a.jtot = cin_g * ksize * ksize;
   auto zero_dw = [&]() -> int {  // the kernels combine their K-splits with atomic adds: start from zero unless adding
     if (accumulate) return 0;
@@ -2752,6 +2846,11 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
     // few-input-channel 1x1 stem: streaming reduction (fp32 exact in every precision mode)
     const int nblocks = 2 * gg::kNumCu;
     const long long need = (long long)nblocks * cout_g * cin_g * (long long)sizeof(float);
+    if (!workspace || workspace_bytes < need) {             // no caller workspace: the stream's scratch
+      workspace = reinterpret_cast<float*>(gg::scratch(st, (size_t)need));
+      if (!workspace) return -3;
+      workspace_bytes = need;
+    }
     if (workspace && workspace_bytes >= need) {
       dim3 grid((unsigned)nblocks, (unsigned)((cout_g + 63) / 64));
       const long long hw = (long long)h * w;
@@ -2795,6 +2894,11 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
     const long long splits = (total_units + upb - 1) / upb;
     const long long need_dw = tiles * splits * 9LL * 4096 * (long long)sizeof(float);
     const long long need = need_dw + (dbias ? splits * (long long)groups * cout_g * (long long)sizeof(float) : 0);
+    if ((!workspace || workspace_bytes < need) && need < (8LL << 30)) {   // no caller workspace: the stream's scratch
+      workspace = reinterpret_cast<float*>(gg::scratch(st, (size_t)need));
+      if (!workspace) return -3;
+      workspace_bytes = need;
+    }
     float* dbws = dbias ? workspace + need_dw / sizeof(float) : nullptr;
     if (workspace && workspace_bytes >= need && splits <= 65535 && (long long)a.tiles_co * a.tiles_j < (1LL << 31)) {
       dim3 grid((unsigned)(a.tiles_co * a.tiles_j), (unsigned)splits, (unsigned)groups);
@@ -2831,7 +2935,6 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
     }
   }
   if (mask_ref) return kNotFused;          // only the row-streaming kernel applies the mask; nothing was launched
-  if (int rc = zero_dw()) return rc;
   a.ktot = (long long)batch * a.oh * a.ow;
   a.tiles_co = (cout_g + WT - 1) / WT;
   a.tiles_j = (a.jtot + WT - 1) / WT;
@@ -2846,6 +2949,13 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
   kps = (kps + slab - 1) / slab * slab;
   splits = (a.ktot + kps - 1) / kps;
   a.k_per_split = kps;
+  const long long count = (long long)groups * cout_g * a.jtot;
+  a.part = nullptr;
+  a.accumulate = accumulate ? 1 : 0;
+  if (splits > 1) {
+    a.part = reinterpret_cast<float*>(gg::scratch(st, sizeof(float) * (size_t)count * splits));
+    if (!a.part) return -3;
+  }
   dim3 grid((unsigned)(a.tiles_co * a.tiles_j), (unsigned)splits, (unsigned)groups);
   if (limbs == 1 || limbs == 2) {
     if (ksize == 3) LIMBS12(limbs, conv_wgrad_split_kernel<3, L><<<grid, 256, 0, st>>>(a));
@@ -2858,7 +2968,15 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
   } else {
     conv_wgrad_kernel<1><<<grid, 256, 0, st>>>(a);
   }
-  return gg::launch_status("conv2d_wgrad");
+  int rc = gg::launch_status("conv2d_wgrad");
+  if (rc || !a.part) return rc;
+  if (splits >= 32 && count <= (1LL << 22))     // many partials of a small tile: one wave per element
+    partial_sum_kernel<<<(unsigned)((count + 3) / 4), 256, 0, st>>>(dw, a.part, (int)splits, (int)count, scale,
+                                                                    accumulate ? 1 : 0);
+  else
+    partial_sum_flat_kernel<<<gg::stream_grid(count, 256), 256, 0, st>>>(dw, a.part, (int)splits, count, scale,
+                                                                         accumulate ? 1 : 0);
+  return gg::launch_status("wgrad_partial_sum");
 }
 }  // namespace
 

@@ -46,11 +46,12 @@ __global__ __launch_bounds__(256) void fused_bias_act_kernel(
 }
 
 // Backward: grid = (splits, C).  Block (s, c) walks hw-range s of every sample n for channel c,
-// writes grad_in and accumulates the channel's partial bias gradient (one atomic per block).
+// writes grad_in and its share of the channel's bias gradient; the channel's last block adds the shares in block
+// order (gg::ordered_grid_sum: fixed summation order, no float atomics) and writes grad_bias[c].
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void fused_lrelu_bwd_kernel(
     T* __restrict__ gin, T* __restrict__ gbias, const T* __restrict__ gout, const T* __restrict__ outv,
-    T alpha, T scale, int n, int c, long long hw, long long chunk) {
+    T alpha, T scale, int n, int c, long long hw, long long chunk, T* part, unsigned* ticket) {
   __shared__ T red[4];
   const int ch = blockIdx.y;
   const long long lo = (long long)blockIdx.x * chunk;
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(256) void fused_lrelu_bwd_kernel(
     }
   }
   if (gbias) {
-    const T tot = gg::block_sum_256<T>(acc, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(gbias + ch, tot);
+    T v[1] = {gg::block_sum_256<T>(acc, red)};
+    if (gg::ordered_grid_sum<T, 1>(v, part, ticket, ch, blockIdx.x, gridDim.x, red)) gbias[ch] = v[0];
   }
 }
 
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(256) void fused_bias_act_f16_kernel(h16* __restrict
 __global__ __launch_bounds__(256) void fused_lrelu_bwd_f16_kernel(h16* __restrict__ gin, float* __restrict__ gbias,
                                                                   const h16* __restrict__ gout,
                                                                   const h16* __restrict__ outv, float alpha, float scale,
-                                                                  int n, int c, long long hw, long long chunk) {
+                                                                  int n, int c, long long hw, long long chunk,
+                                                                  float* part, unsigned* ticket) {
   __shared__ float red[4];
   const int ch = blockIdx.y;
   const long long lo = (long long)blockIdx.x * chunk;
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(256) void fused_lrelu_bwd_f16_kernel(h16* __restric
     }
   }
   if (gbias) {
-    const float tot = gg::block_sum_256<float>(acc, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(gbias + ch, tot);
+    float v[1] = {gg::block_sum_256<float>(acc, red)};
+    if (gg::ordered_grid_sum<float, 1>(v, part, ticket, ch, blockIdx.x, gridDim.x, red)) gbias[ch] = v[0];
   }
 }
 
@@ -196,10 +198,6 @@ int fused_lrelu_bwd_impl(T* gin, T* gbias, const T* gout, const T* outv, T alpha
   if (!gin || !gout || !outv) return gg::fail(-2, "fused_lrelu_bwd: null pointer");
   if (c > 65535) return gg::fail(-2, "fused_lrelu_bwd: more than 65535 channels");
   hipStream_t st = gg::as_stream(stream);
-  if (gbias) {
-    hipError_t e = hipMemsetAsync(gbias, 0, sizeof(T) * (size_t)c, st);
-    if (e != hipSuccess) return gg::fail((int)e, "fused_lrelu_bwd: memset failed");
-  }
   const bool vec = sizeof(T) == 4 && (hw % 4 == 0) && aligned16(gin) && aligned16(gout) && aligned16(outv);
   const int per = vec ? 4 : 1;
   // enough blocks to fill the chip (>= ~2048) but at least one full 256-thread sweep per block
@@ -211,11 +209,19 @@ int fused_lrelu_bwd_impl(T* gin, T* gbias, const T* gout, const T* outv, T alpha
   long long chunk = (hw + splits - 1) / splits;
   chunk = (chunk + per - 1) / per * per;
   splits = (hw + chunk - 1) / chunk;
+  if (c > gg::kTickets) { splits = 1; chunk = hw; }        // one ticket per channel
+  T* part = nullptr;
+  unsigned* ticket = nullptr;
+  if (gbias && splits > 1) {
+    part = reinterpret_cast<T*>(gg::scratch(st, sizeof(T) * (size_t)c * splits));
+    ticket = gg::tickets(st);
+    if (!part || !ticket) return -3;
+  }
   dim3 grid((unsigned)splits, (unsigned)c);
   if (vec)
-    fused_lrelu_bwd_kernel<T, 4><<<grid, 256, 0, st>>>(gin, gbias, gout, outv, alpha, scale, n, c, hw, chunk);
+    fused_lrelu_bwd_kernel<T, 4><<<grid, 256, 0, st>>>(gin, gbias, gout, outv, alpha, scale, n, c, hw, chunk, part, ticket);
   else
-    fused_lrelu_bwd_kernel<T, 1><<<grid, 256, 0, st>>>(gin, gbias, gout, outv, alpha, scale, n, c, hw, chunk);
+    fused_lrelu_bwd_kernel<T, 1><<<grid, 256, 0, st>>>(gin, gbias, gout, outv, alpha, scale, n, c, hw, chunk, part, ticket);
   return gg::launch_status("fused_lrelu_bwd");
 }
 
@@ -259,20 +265,25 @@ extern "C" int gg_fused_lrelu_bwd_f16(unsigned short* grad_in, float* grad_bias,
   if (!grad_in || !grad_out || !out) return gg::fail(-2, "fused_lrelu_bwd: null pointer");
   if (c > 65535) return gg::fail(-2, "fused_lrelu_bwd: more than 65535 channels");
   hipStream_t st = gg::as_stream(stream);
-  if (grad_bias) {
-    hipError_t e = hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)c, st);
-    if (e != hipSuccess) return gg::fail((int)e, "fused_lrelu_bwd: memset failed");
-  }
   long long splits = (2048 + c - 1) / c;
   const long long max_splits = (hw + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  if (c > gg::kTickets) splits = 1;
   const long long chunk = (hw + splits - 1) / splits;
   splits = (hw + chunk - 1) / chunk;
+  float* part = nullptr;
+  unsigned* ticket = nullptr;
+  if (grad_bias && splits > 1) {
+    part = reinterpret_cast<float*>(gg::scratch(st, sizeof(float) * (size_t)c * splits));
+    ticket = gg::tickets(st);
+    if (!part || !ticket) return -3;
+  }
   dim3 grid((unsigned)splits, (unsigned)c);
   fused_lrelu_bwd_f16_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<h16*>(grad_in), grad_bias,
                                                    reinterpret_cast<const h16*>(grad_out),
-                                                   reinterpret_cast<const h16*>(out), alpha, scale, n, c, hw, chunk);
+                                                   reinterpret_cast<const h16*>(out), alpha, scale, n, c, hw, chunk,
+                                                   part, ticket);
   return gg::launch_status("fused_lrelu_bwd");
 }
 extern "C" int gg_noise_bias_act_f32(float* out, const float* x, const float* noise, const float* noise_weight,

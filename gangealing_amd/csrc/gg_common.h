@@ -17,6 +17,13 @@ constexpr int kNumCu = 256;
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Per-(device, stream) scratch memory owned by the library (gg_runtime.hip): partial results of split reductions.
+// scratch(): >= bytes, 256-byte aligned, contents undefined; nullptr on failure (gg_last_error is set).
+// tickets(): kTickets zero-initialised counters; every kernel that uses them leaves them zero again.
+void* scratch(hipStream_t st, size_t bytes);
+constexpr int kTickets = 16384;
+unsigned* tickets(hipStream_t st);
+
 inline unsigned ceil_div_u(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
 // Grid for HBM-streaming kernels: enough blocks to fill 256 CUs x 8 blocks, grid-stride the rest.
@@ -59,6 +66,44 @@ __device__ __forceinline__ T block_sum_256(T v, T* smem) {
   if (threadIdx.x == 0) r = smem[0] + smem[1] + smem[2] + smem[3];
   __syncthreads();
   return r;
+}
+
+// Deterministic finish of a sum that is spread over the `nblk` blocks of one "row" of the grid (a channel, a sample,
+// the whole launch).  Block-collective for 256-thread blocks; v[] holds the block's NV totals in thread 0.  They are
+// stored to part[(row * nblk + blk) * NV ..], and the block that arrives LAST at the row's ticket counter re-reads
+// all of the row's partials (thread t takes blocks t, t + 256, ..., then the fixed tree of block_sum_256) - a fixed
+// summation order, whatever order the blocks ran in (one atomic add per block would combine them in arrival order: a
+// different rounding every run).  Returns true in thread 0 of that last block, with v[] = the totals; the counter is
+// left at zero for the next launch.  `smem`: >= 4 values of block-shared scratch.
+// Hand-off protocol of the CDNA4 guide (inter-workgroup communication): write-through (agent-scope relaxed atomic =
+// sc1) payload stores, drained, THEN the ticket; the last arriver issues one agent-scope acquire (per-CU L1 is never
+// refreshed by other CUs' stores) and reads with agent-scope loads.
+template <typename T, int NV>
+__device__ __forceinline__ bool ordered_grid_sum(T (&v)[NV], T* part, unsigned* ticket, int row, int blk, int nblk,
+                                                 T* smem) {
+  if (nblk == 1) return threadIdx.x == 0;
+  __shared__ unsigned last_arriver;
+  if (threadIdx.x == 0) {
+    T* mine = part + ((size_t)row * nblk + blk) * NV;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) __hip_atomic_store(mine + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_arriver = (t == (unsigned)(nblk - 1)) ? 1u : 0u;
+    if (t == (unsigned)(nblk - 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!last_arriver) return false;
+  T* all = part + (size_t)row * nblk * NV;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    T acc = T(0);
+    for (int b = threadIdx.x; b < nblk; b += 256)
+      acc += __hip_atomic_load(all + (size_t)b * NV + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v[i] = block_sum_256<T>(acc, smem);
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(ticket + row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return threadIdx.x == 0;
 }
 
 // Raw buffer access: address = resource base + voffset (per lane) + soffset (scalar).  A voffset at or beyond the

@@ -29,7 +29,8 @@ __device__ __forceinline__ void pixel_sums(float (&v)[NV], float (*red)[NV][PIX]
 
 __global__ __launch_bounds__(256) void lpips_tail_fwd_kernel(float* __restrict__ out, const float* __restrict__ f,
                                                              const float* __restrict__ lin, int n, int c,
-                                                             long long hw, float eps, float inv_hw) {
+                                                             long long hw, float eps, float inv_hw, float* part,
+                                                             unsigned* ticket) {
   __shared__ float red[CG][2][PIX];
   __shared__ float red4[4];
   const int s = blockIdx.y, px = threadIdx.x & (PIX - 1), grp = threadIdx.x >> 6;
@@ -54,8 +55,9 @@ __global__ __launch_bounds__(256) void lpips_tail_fwd_kernel(float* __restrict__
         acc += (lin ? lin[k] : 1.f) * t * t;
       }
   }
-  const float tot = gg::block_sum_256<float>(acc, red4);
-  if (threadIdx.x == 0) unsafeAtomicAdd(out + s, tot * inv_hw);
+  // the sample's blocks are summed in a fixed order (no float atomics: reproducible)
+  float v[1] = {gg::block_sum_256<float>(acc, red4)};
+  if (gg::ordered_grid_sum<float, 1>(v, part, ticket, s, blockIdx.x, gridDim.x, red4)) out[s] = v[0] * inv_hw;
 }
 
 // df0[c] = a0 * q[c] - u0[c] * (sum_k q[k] u0[k]) / n0,   q[c] = 2 g/(HW) lin[c] (u0[c] - u1[c]);  df1 with -q.
@@ -192,9 +194,16 @@ extern "C" int gg_lpips_tail_fwd_f32(float* out, const float* feats, const float
   if (n <= 0) return 0;
   if (!out || !feats || c <= 0 || hw <= 0 || n > 65535) return gg::fail(-2, "lpips_tail_fwd: bad arguments");
   hipStream_t st = gg::as_stream(stream);
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * n, st);
-  if (e != hipSuccess) return gg::fail((int)e, "lpips_tail_fwd: memset failed");
-  lpips_tail_fwd_kernel<<<tail_grid(n, hw), 256, 0, st>>>(out, feats, lin, n, c, hw, eps, 1.f / (float)hw);
+  const dim3 grid = tail_grid(n, hw);
+  float* part = nullptr;
+  unsigned* ticket = nullptr;
+  if (grid.x > 1) {
+    if (n > gg::kTickets) return gg::fail(-2, "lpips_tail_fwd: batch too large");
+    part = reinterpret_cast<float*>(gg::scratch(st, sizeof(float) * (size_t)n * grid.x));
+    ticket = gg::tickets(st);
+    if (!part || !ticket) return -3;
+  }
+  lpips_tail_fwd_kernel<<<grid, 256, 0, st>>>(out, feats, lin, n, c, hw, eps, 1.f / (float)hw, part, ticket);
   return gg::launch_status("lpips_tail_fwd");
 }
 

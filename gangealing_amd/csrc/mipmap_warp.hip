@@ -373,7 +373,8 @@ __device__ __forceinline__ void scatter_taps(float* __restrict__ gimg, int wl, c
 __global__ __launch_bounds__(256) void mipmap_warp_bwd_kernel(
     float* __restrict__ ggrid, GPyr gpyr, const float* __restrict__ gout, Pyr pyr, const float* __restrict__ grid,
     int n, int c, int h, int w, int hp, int wp, int pad_l, int ho, int wo, float max_level, float min_level,
-    int padding_mode, int antialias, int want_image_grad) {
+    int padding_mode, int antialias, int want_image_grad, int* __restrict__ nb_target,
+    float2* __restrict__ nb_grad) {
   const long long total = (long long)n * ho * wo;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
@@ -424,22 +425,59 @@ __global__ __launch_bounds__(256) void mipmap_warp_bwd_kernel(
       }
     }
     float gx = gix * t.dgx, gy = giy * t.dgy;
-    // gradient through the fractional level: level -> dist_max -> coords of self and of the arg neighbour
+    // gradient through the fractional level: level -> dist_max -> coords of self and of the arg neighbour.  The
+    // neighbour's share is not added here (that would be a float atomic: up to five contributions per grid point in
+    // arrival order) but recorded per SOURCE point; mipmap_warp_bwd_gather_kernel adds the records in a fixed order.
+    int target = -1;
+    float2 ng = make_float2(0.f, 0.f);
     if (antialias && li.arg >= 0 && li.dcoef != 0.f && gfrac != 0.f) {
       const float gsq = gfrac * li.dcoef;                    // d loss / d sq_dist
       const float gox = gsq * 2.f * li.ddx * ((float)(w - 1) / 2.f);
       const float goy = gsq * 2.f * li.ddy * ((float)(h - 1) / 2.f);
       const int nx = (li.arg == 0) ? max(ox - 1, 0) : (li.arg == 1) ? min(ox + 1, wo - 1) : ox;
       const int ny = (li.arg == 2) ? max(oy - 1, 0) : (li.arg == 3) ? min(oy + 1, ho - 1) : oy;
-      float* gn = ggrid_n + ((size_t)ny * wo + nx) * 2;
-      unsafeAtomicAdd(gn, gox);
-      unsafeAtomicAdd(gn + 1, goy);
+      target = ny * wo + nx;
+      ng = make_float2(gox, goy);
       gx -= gox;
       gy -= goy;
     }
     float* gs = ggrid_n + ((size_t)oy * wo + ox) * 2;
-    unsafeAtomicAdd(gs, gx);
-    unsafeAtomicAdd(gs + 1, gy);
+    gs[0] = gx;
+    gs[1] = gy;
+    if (nb_target) {
+      nb_target[o] = target;
+      nb_grad[o] = ng;
+    }
+  }
+}
+
+// grad_grid[p] += the recorded neighbour shares aimed at p, visited in a fixed order (self - at a clamped border the
+// "neighbour" is the point itself -, left, right, up, down): bitwise reproducible, no atomics
+__global__ __launch_bounds__(256) void mipmap_warp_bwd_gather_kernel(float* __restrict__ ggrid,
+                                                                     const int* __restrict__ nb_target,
+                                                                     const float2* __restrict__ nb_grad, long long total,
+                                                                     int ho, int wo) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const int ox = (int)(o % wo);
+    const long long q = o / wo;
+    const int oy = (int)(q % ho);
+    const long long base = (q / ho) * ho * wo;
+    const int self = oy * wo + ox;
+    float gx = ggrid[o * 2], gy = ggrid[o * 2 + 1];
+    const int cy[5] = {oy, oy, oy, oy - 1, oy + 1}, cx[5] = {ox, ox - 1, ox + 1, ox, ox};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      if ((unsigned)cy[k] >= (unsigned)ho || (unsigned)cx[k] >= (unsigned)wo) continue;
+      const long long src = base + (long long)cy[k] * wo + cx[k];
+      if (nb_target[src] == self) {
+        const float2 g = nb_grad[src];
+        gx += g.x;
+        gy += g.y;
+      }
+    }
+    ggrid[o * 2] = gx;
+    ggrid[o * 2 + 1] = gy;
   }
 }
 
@@ -524,13 +562,29 @@ extern "C" int gg_mipmap_warp_bwd_f32(float* grad_grid, float* grad_pyr0, float*
   if (want_img && antialias && (!grad_pyr1 || !grad_pyr2 || !grad_pyr3))
     return gg::fail(-2, "mipmap_warp_bwd: image gradient needs all 4 grad_pyr levels");
   hipStream_t st = gg::as_stream(stream);
-  hipError_t e = hipMemsetAsync(grad_grid, 0, sizeof(float) * (size_t)total * 2, st);
-  if (e != hipSuccess) return gg::fail((int)e, "mipmap_warp_bwd: memset failed");
-  if (c == 0) return 0;
+  if (c == 0) {
+    hipError_t e = hipMemsetAsync(grad_grid, 0, sizeof(float) * (size_t)total * 2, st);
+    return e == hipSuccess ? 0 : gg::fail((int)e, "mipmap_warp_bwd: memset failed");
+  }
+  if ((long long)ho * wo >= (1LL << 31)) return gg::fail(-2, "mipmap_warp_bwd: output too large");
+  // neighbour records (one int + one float2 per output point) live in the stream's scratch
+  int* nb_target = nullptr;
+  float2* nb_grad = nullptr;
+  if (antialias) {
+    char* sc = reinterpret_cast<char*>(gg::scratch(st, (size_t)total * 12));
+    if (!sc) return -3;
+    nb_grad = reinterpret_cast<float2*>(sc);
+    nb_target = reinterpret_cast<int*>(sc + (size_t)total * 8);
+  }
   Pyr pyr{{pyr0, pyr1, pyr2, pyr3}};
   GPyr gp{{grad_pyr0, grad_pyr1, grad_pyr2, grad_pyr3}};
   mipmap_warp_bwd_kernel<<<gg::stream_grid(total, 256), 256, 0, st>>>(grad_grid, gp, grad_out, pyr, grid, n, c, h, w,
                                                                       hp, wp, pad_l, ho, wo, max_level, min_level,
-                                                                      padding_mode, antialias, want_img);
-  return gg::launch_status("mipmap_warp_bwd");
+                                                                      padding_mode, antialias, want_img, nb_target,
+                                                                      nb_grad);
+  rc = gg::launch_status("mipmap_warp_bwd");
+  if (rc || !antialias) return rc;
+  mipmap_warp_bwd_gather_kernel<<<gg::stream_grid(total, 256), 256, 0, st>>>(grad_grid, nb_target, nb_grad, total, ho,
+                                                                             wo);
+  return gg::launch_status("mipmap_warp_bwd_gather");
 }

@@ -1,8 +1,10 @@
 // a7-a10  the small STN-side operators that the reference spreads over ~40 tiny torch launches:
 //   affine_grid (+bwd), RAFT convex flow upsampling + identity + affine composition (+bwd),
 //   bilinear flow resize (+bwd), BilinearDownsample (+bwd), TV / identity flow losses (+bwd).
-// All of them are latency bound at batch 16 (<= 10 MB of traffic), so each is ONE kernel per
-// direction, thread-per-output, reductions finished with one atomic per block.
+// All of them are latency bound at batch 16 (<= 10 MB of traffic), so each is one kernel per
+// direction (two for the scatter-shaped backward passes), thread-per-output.  No floating-point atomics: grid-wide
+// sums are finished in a fixed order by the last block (gg::ordered_grid_sum) and scatter-shaped gradients are
+// written per source and then GATHERED per destination, so every result is bitwise reproducible.
 #include "../../include/gangealing_hip.h"
 #include "gg_common.h"
 
@@ -34,7 +36,8 @@ __global__ __launch_bounds__(256) void affine_grid_kernel(float* __restrict__ gr
 
 // grid = (splits, n); each block reduces its share of one sample's pixels to 6 numbers.
 __global__ __launch_bounds__(256) void affine_grid_bwd_kernel(float* __restrict__ gtheta,
-                                                              const float* __restrict__ ggrid, int ho, int wo) {
+                                                              const float* __restrict__ ggrid, int ho, int wo,
+                                                              float* part, unsigned* ticket) {
   __shared__ float red[4];
   const int s = blockIdx.y;
   const long long pix = (long long)ho * wo;
@@ -48,9 +51,10 @@ __global__ __launch_bounds__(256) void affine_grid_bwd_kernel(float* __restrict_
     acc[3] += gy * x; acc[4] += gy * y; acc[5] += gy;
   }
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const float tot = gg::block_sum_256<float>(acc[k], red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(gtheta + s * 6 + k, tot);
+  for (int k = 0; k < 6; ++k) acc[k] = gg::block_sum_256<float>(acc[k], red);
+  if (gg::ordered_grid_sum<float, 6>(acc, part, ticket, s, blockIdx.x, gridDim.x, red)) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gtheta[s * 6 + k] = acc[k];
   }
 }
 
@@ -126,10 +130,12 @@ __global__ __launch_bounds__(256) void flow_compose_fwd_kernel(float* __restrict
   }
 }
 
+// contrib: per (n, k, ij, y, x) the share ds * s[k] * (gux, guy) that hi-res pixel (ij, y, x) sends to its low-res
+// neighbour k (same index layout as gmask); flow_compose_gather_kernel sums them per low-res pixel in a fixed order
 __global__ __launch_bounds__(256) void flow_compose_bwd_kernel(
-    float* __restrict__ glow, float* __restrict__ gmask, float* __restrict__ gbase, const float* __restrict__ g_flow,
+    float2* __restrict__ contrib, float* __restrict__ gmask, float* __restrict__ gbase, const float* __restrict__ g_flow,
     const float* __restrict__ g_delta, const float* __restrict__ low, const float* __restrict__ mask,
-    const float* __restrict__ base, int hl, int wl, int ds) {
+    const float* __restrict__ base, int hl, int wl, int ds, float* part, unsigned* ticket) {
   __shared__ float red[4];
   const int n = blockIdx.y;
   const int per = ds * ds * hl * wl;
@@ -170,24 +176,51 @@ __global__ __launch_bounds__(256) void flow_compose_bwd_kernel(
       gs[k] = gux * c.vx[k] + guy * c.vy[k];
       dot += c.s[k] * gs[k];
     }
-    float* gm = gmask + ((size_t)n * 9 * dd + ij) * plane + (size_t)y * wl + x;
-    float* gl = glow + (size_t)n * 2 * plane;
+    const size_t e0 = ((size_t)n * 9 * dd + ij) * plane + (size_t)y * wl + x;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      gm[(size_t)k * dd * plane] = c.s[k] * (gs[k] - dot);
-      const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-      if (yy >= 0 && yy < hl && xx >= 0 && xx < wl) {
-        unsafeAtomicAdd(gl + (size_t)yy * wl + xx, (float)ds * c.s[k] * gux);
-        unsafeAtomicAdd(gl + plane + (size_t)yy * wl + xx, (float)ds * c.s[k] * guy);
-      }
+      gmask[e0 + (size_t)k * dd * plane] = c.s[k] * (gs[k] - dot);
+      contrib[e0 + (size_t)k * dd * plane] = make_float2((float)ds * c.s[k] * gux, (float)ds * c.s[k] * guy);
     }
   }
   if (base && gbase) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const float tot = gg::block_sum_256<float>(accb[k], red);
-      if (threadIdx.x == 0) unsafeAtomicAdd(gbase + n * 6 + k, tot);
+    for (int k = 0; k < 6; ++k) accb[k] = gg::block_sum_256<float>(accb[k], red);
+    if (gg::ordered_grid_sum<float, 6>(accb, part, ticket, n, blockIdx.x, gridDim.x, red)) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gbase[n * 6 + k] = accb[k];
     }
+  }
+}
+
+// glow[n][c][yy][xx] = sum over the 9 neighbour slots k and the ds*ds sub-positions ij of the shares aimed at
+// (yy, xx).  One wave per low-res pixel: lane = ij (strided when ds*ds > 64), k ascending, then the wave's fixed
+// shuffle tree - a fixed order.  grid = (ceil(hl*wl / 4), n), 4 waves per block.
+__global__ __launch_bounds__(256) void flow_compose_gather_kernel(float* __restrict__ glow,
+                                                                  const float2* __restrict__ contrib, int hl, int wl,
+                                                                  int dd) {
+  const int n = blockIdx.y, lane = threadIdx.x & 63;
+  const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t plane = (size_t)hl * wl;
+  if (pix >= hl * wl) return;
+  const int yy = pix / wl, xx = pix - yy * wl;
+  float sx = 0.f, sy = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int y = yy - (k / 3 - 1), x = xx - (k % 3 - 1);          // the hi-res cell whose slot k is (yy, xx)
+    if (y < 0 || y >= hl || x < 0 || x >= wl) continue;
+    const float2* src = contrib + ((size_t)n * 9 + k) * dd * plane + (size_t)y * wl + x;
+    for (int ij = lane; ij < dd; ij += 64) {
+      const float2 v = src[(size_t)ij * plane];
+      sx += v.x;
+      sy += v.y;
+    }
+  }
+  sx = gg::wave_sum(sx);
+  sy = gg::wave_sum(sy);
+  if (lane == 0) {
+    glow[(size_t)n * 2 * plane + pix] = sx;
+    glow[(size_t)n * 2 * plane + plane + pix] = sy;
   }
 }
 
@@ -206,11 +239,10 @@ __device__ __forceinline__ Lin lin_src(int dst, float rscale, int size) {   // A
   return l;
 }
 
-template <bool BWD>
 __global__ __launch_bounds__(256) void flow_resize_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                           long long total, int hi, int wi, int ho, int wo,
                                                           float rscale) {
-  // fwd: dst = out (N,ho,wo,2), src = in (N,hi,wi,2).   bwd: dst = grad_in (accumulated), src = grad_out.
+  // dst = out (N,ho,wo,2), src = in (N,hi,wi,2)
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
     const int x = (int)(o % wo);
@@ -222,18 +254,58 @@ __global__ __launch_bounds__(256) void flow_resize_kernel(float* __restrict__ ds
     const size_t p00 = (b + (size_t)ly.i0 * wi + lx.i0) * 2, p01 = (b + (size_t)ly.i0 * wi + lx.i1) * 2;
     const size_t p10 = (b + (size_t)ly.i1 * wi + lx.i0) * 2, p11 = (b + (size_t)ly.i1 * wi + lx.i1) * 2;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      if (!BWD) {
-        dst[o * 2 + c] = ly.l0 * (lx.l0 * src[p00 + c] + lx.l1 * src[p01 + c]) +
-                         ly.l1 * (lx.l0 * src[p10 + c] + lx.l1 * src[p11 + c]);
-      } else {
-        const float g = src[o * 2 + c];
-        unsafeAtomicAdd(dst + p00 + c, g * ly.l0 * lx.l0);
-        unsafeAtomicAdd(dst + p01 + c, g * ly.l0 * lx.l1);
-        unsafeAtomicAdd(dst + p10 + c, g * ly.l1 * lx.l0);
-        unsafeAtomicAdd(dst + p11 + c, g * ly.l1 * lx.l1);
+    for (int c = 0; c < 2; ++c)
+      dst[o * 2 + c] = ly.l0 * (lx.l0 * src[p00 + c] + lx.l1 * src[p01 + c]) +
+                       ly.l1 * (lx.l0 * src[p10 + c] + lx.l1 * src[p11 + c]);
+  }
+}
+
+// Outputs whose interpolation footprint along one axis contains input index i: a conservative index range (the
+// footprint test itself is repeated with lin_src, so the weights are exactly the forward's).  src = rscale * (o + .5)
+// - .5 lies in (i - 1, i + 1) for interior outputs; outputs clamped to src = 0 belong to i = 0.
+__device__ __forceinline__ void resize_sources(int i, float rscale, int osize, int& lo, int& hi) {
+  const float inv = 1.f / rscale;
+  lo = (int)floorf(((float)i - 1.f + 0.5f) * inv - 0.5f) - 1;
+  hi = (int)ceilf(((float)i + 1.f + 0.5f) * inv - 0.5f) + 1;
+  if (i == 0) lo = 0;
+  if (lo < 0) lo = 0;
+  if (hi > osize - 1) hi = osize - 1;
+}
+
+// backward as a GATHER: thread per input pixel, visits the candidate outputs in index order (fixed summation order,
+// no atomics); dst = grad_in (N,hi,wi,2), src = grad_out (N,ho,wo,2)
+__global__ __launch_bounds__(256) void flow_resize_bwd_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                              long long total_in, int hi, int wi, int ho, int wo,
+                                                              float rscale) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total_in; p += stride) {
+    const int xi = (int)(p % wi);
+    const long long q = p / wi;
+    const int yi = (int)(q % hi);
+    const size_t n = (size_t)(q / hi);
+    int ylo, yhi, xlo, xhi;
+    resize_sources(yi, rscale, ho, ylo, yhi);
+    resize_sources(xi, rscale, wo, xlo, xhi);
+    float gx = 0.f, gy = 0.f;
+    for (int y = ylo; y <= yhi; ++y) {
+      const Lin ly = lin_src(y, rscale, hi);
+      if (ly.i0 != yi && ly.i1 != yi) continue;
+      const float* row = src + ((n * ho + y) * (size_t)wo) * 2;
+      for (int x = xlo; x <= xhi; ++x) {
+        const Lin lx = lin_src(x, rscale, wi);
+        if (lx.i0 != xi && lx.i1 != xi) continue;
+        // the forward's four products, kept separate so that every weight is formed exactly as there
+        float ax = 0.f, ay = 0.f;
+        if (ly.i0 == yi && lx.i0 == xi) { ax += row[x * 2] * ly.l0 * lx.l0; ay += row[x * 2 + 1] * ly.l0 * lx.l0; }
+        if (ly.i0 == yi && lx.i1 == xi) { ax += row[x * 2] * ly.l0 * lx.l1; ay += row[x * 2 + 1] * ly.l0 * lx.l1; }
+        if (ly.i1 == yi && lx.i0 == xi) { ax += row[x * 2] * ly.l1 * lx.l0; ay += row[x * 2 + 1] * ly.l1 * lx.l0; }
+        if (ly.i1 == yi && lx.i1 == xi) { ax += row[x * 2] * ly.l1 * lx.l1; ay += row[x * 2 + 1] * ly.l1 * lx.l1; }
+        gx += ax;
+        gy += ay;
       }
     }
+    dst[p * 2] = gx;
+    dst[p * 2 + 1] = gy;
   }
 }
 
@@ -332,7 +404,7 @@ __device__ __forceinline__ float huber_grad(float u) {
 
 __global__ __launch_bounds__(256) void flow_losses_kernel(float* __restrict__ losses, const float* __restrict__ d,
                                                           long long total, int hf, int wf, float inv_y, float inv_x,
-                                                          float inv_all) {
+                                                          float inv_all, float* part, unsigned* ticket) {
   __shared__ float red[4];
   float sy = 0.f, sx = 0.f, sq = 0.f;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -348,9 +420,10 @@ __global__ __launch_bounds__(256) void flow_losses_kernel(float* __restrict__ lo
   const float ty = gg::block_sum_256<float>(sy, red);
   const float tx = gg::block_sum_256<float>(sx, red);
   const float tq = gg::block_sum_256<float>(sq, red);
-  if (threadIdx.x == 0) {
-    unsafeAtomicAdd(losses, ty * inv_y + tx * inv_x);
-    unsafeAtomicAdd(losses + 1, tq * inv_all);
+  float v[2] = {ty * inv_y + tx * inv_x, tq * inv_all};
+  if (gg::ordered_grid_sum<float, 2>(v, part, ticket, 0, blockIdx.x, gridDim.x, red)) {
+    losses[0] = v[0];
+    losses[1] = v[1];
   }
 }
 
@@ -389,13 +462,22 @@ extern "C" int gg_affine_grid_bwd_f32(float* grad_theta, const float* grad_grid,
   if (n <= 0) return 0;
   if (!grad_theta || !grad_grid || n > 65535) return gg::fail(-2, "affine_grid_bwd: bad arguments");
   hipStream_t st = gg::as_stream(stream);
-  hipError_t e = hipMemsetAsync(grad_theta, 0, sizeof(float) * 6 * (size_t)n, st);
-  if (e != hipSuccess) return gg::fail((int)e, "affine_grid_bwd: memset failed");
   const long long pix = (long long)ho * wo;
-  if (pix <= 0) return 0;
+  if (pix <= 0) {
+    hipError_t e = hipMemsetAsync(grad_theta, 0, sizeof(float) * 6 * (size_t)n, st);
+    return e == hipSuccess ? 0 : gg::fail((int)e, "affine_grid_bwd: memset failed");
+  }
   unsigned splits = (unsigned)((pix + 4095) / 4096);
   if (splits > 64) splits = 64;
-  affine_grid_bwd_kernel<<<dim3(splits, n), 256, 0, st>>>(grad_theta, grad_grid, ho, wo);
+  if (n > gg::kTickets) splits = 1;
+  float* part = nullptr;
+  unsigned* ticket = nullptr;
+  if (splits > 1) {
+    part = reinterpret_cast<float*>(gg::scratch(st, sizeof(float) * 6 * (size_t)n * splits));
+    ticket = gg::tickets(st);
+    if (!part || !ticket) return -3;
+  }
+  affine_grid_bwd_kernel<<<dim3(splits, n), 256, 0, st>>>(grad_theta, grad_grid, ho, wo, part, ticket);
   return gg::launch_status("affine_grid_bwd");
 }
 
@@ -418,15 +500,24 @@ extern "C" int gg_flow_compose_bwd_f32(float* grad_low, float* grad_mask, float*
   if (!grad_low || !grad_mask || !low_flow || !mask || ds < 1 || n > 65535)
     return gg::fail(-2, "flow_compose_bwd: bad arguments");
   hipStream_t st = gg::as_stream(stream);
-  hipError_t e = hipMemsetAsync(grad_low, 0, sizeof(float) * 2 * (size_t)n * hl * wl, st);
-  if (e == hipSuccess && base && grad_base) e = hipMemsetAsync(grad_base, 0, sizeof(float) * 6 * (size_t)n, st);
-  if (e != hipSuccess) return gg::fail((int)e, "flow_compose_bwd: memset failed");
   const long long per = (long long)ds * ds * hl * wl;
   unsigned bx = (unsigned)((per + 255) / 256);
   if (bx > 1024) bx = 1024;
-  flow_compose_bwd_kernel<<<dim3(bx, n), 256, 0, st>>>(grad_low, grad_mask, grad_base, g_flow, g_delta, low_flow,
-                                                       mask, base, hl, wl, ds);
-  return gg::launch_status("flow_compose_bwd");
+  if (n > gg::kTickets) return gg::fail(-2, "flow_compose_bwd: batch too large");
+  // scratch: [contributions: n * 9 * ds^2 * hl * wl float2][partials of the base-matrix gradient: n * bx * 6]
+  const size_t contrib_bytes = sizeof(float2) * (size_t)n * 9 * per;
+  char* sc = reinterpret_cast<char*>(gg::scratch(st, contrib_bytes + sizeof(float) * 6 * (size_t)n * bx));
+  unsigned* ticket = gg::tickets(st);
+  if (!sc || !ticket) return -3;
+  float2* contrib = reinterpret_cast<float2*>(sc);
+  float* part = reinterpret_cast<float*>(sc + contrib_bytes);
+  flow_compose_bwd_kernel<<<dim3(bx, n), 256, 0, st>>>(contrib, grad_mask, grad_base, g_flow, g_delta, low_flow, mask,
+                                                       base, hl, wl, ds, part, ticket);
+  int rc = gg::launch_status("flow_compose_bwd");
+  if (rc) return rc;
+  flow_compose_gather_kernel<<<dim3((unsigned)((hl * wl + 3) / 4), n), 256, 0, st>>>(grad_low, contrib, hl, wl,
+                                                                                    ds * ds);
+  return gg::launch_status("flow_compose_gather");
 }
 
 extern "C" int gg_flow_resize_f32(float* out, const float* in, int n, int hi, int wi, int ho, int wo, float scale,
@@ -434,8 +525,8 @@ extern "C" int gg_flow_resize_f32(float* out, const float* in, int n, int hi, in
   const long long total = (long long)n * ho * wo;
   if (total <= 0) return 0;
   if (!out || !in || hi <= 0 || wi <= 0 || !(scale > 0.f)) return gg::fail(-2, "flow_resize: bad arguments");
-  flow_resize_kernel<false><<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(out, in, total, hi, wi,
-                                                                                           ho, wo, 1.f / scale);
+  flow_resize_kernel<<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(out, in, total, hi, wi, ho, wo,
+                                                                                    1.f / scale);
   return gg::launch_status("flow_resize");
 }
 
@@ -445,11 +536,13 @@ extern "C" int gg_flow_resize_bwd_f32(float* grad_in, const float* grad_out, int
   if (n <= 0 || hi <= 0 || wi <= 0) return 0;
   if (!grad_in || !grad_out || !(scale > 0.f)) return gg::fail(-2, "flow_resize_bwd: bad arguments");
   hipStream_t st = gg::as_stream(stream);
-  hipError_t e = hipMemsetAsync(grad_in, 0, sizeof(float) * 2 * (size_t)n * hi * wi, st);
-  if (e != hipSuccess) return gg::fail((int)e, "flow_resize_bwd: memset failed");
-  if (total <= 0) return 0;
-  flow_resize_kernel<true><<<gg::stream_grid(total, 256), 256, 0, st>>>(grad_in, grad_out, total, hi, wi, ho, wo,
-                                                                        1.f / scale);
+  if (total <= 0) {
+    hipError_t e = hipMemsetAsync(grad_in, 0, sizeof(float) * 2 * (size_t)n * hi * wi, st);
+    return e == hipSuccess ? 0 : gg::fail((int)e, "flow_resize_bwd: memset failed");
+  }
+  const long long total_in = (long long)n * hi * wi;
+  flow_resize_bwd_kernel<<<gg::stream_grid(total_in, 256), 256, 0, st>>>(grad_in, grad_out, total_in, hi, wi, ho, wo,
+                                                                         1.f / scale);
   return gg::launch_status("flow_resize_bwd");
 }
 
@@ -480,16 +573,25 @@ extern "C" int gg_bilinear_downsample_bwd_f32(float* grad_in, const float* grad_
 extern "C" int gg_flow_losses_f32(float* losses, const float* delta, int n, int hf, int wf, void* stream) {
   if (!losses) return gg::fail(-2, "flow_losses: null pointer");
   hipStream_t st = gg::as_stream(stream);
-  hipError_t e = hipMemsetAsync(losses, 0, sizeof(float) * 2, st);
-  if (e != hipSuccess) return gg::fail((int)e, "flow_losses: memset failed");
   const long long total = (long long)n * hf * wf * 2;
-  if (total <= 0) return 0;
+  if (total <= 0) {
+    hipError_t e = hipMemsetAsync(losses, 0, sizeof(float) * 2, st);
+    return e == hipSuccess ? 0 : gg::fail((int)e, "flow_losses: memset failed");
+  }
   if (!delta) return gg::fail(-2, "flow_losses: null pointer");
   const float inv_y = hf > 1 ? 1.f / (float)((long long)n * (hf - 1) * wf * 2) : 0.f;
   const float inv_x = wf > 1 ? 1.f / (float)((long long)n * hf * (wf - 1) * 2) : 0.f;
   unsigned blocks = gg::stream_grid(total, 256);
   if (blocks > 256) blocks = 256;
-  flow_losses_kernel<<<blocks, 256, 0, st>>>(losses, delta, total, hf, wf, inv_y, inv_x, 1.f / (float)total);
+  float* part = nullptr;
+  unsigned* ticket = nullptr;
+  if (blocks > 1) {
+    part = reinterpret_cast<float*>(gg::scratch(st, sizeof(float) * 2 * blocks));
+    ticket = gg::tickets(st);
+    if (!part || !ticket) return -3;
+  }
+  flow_losses_kernel<<<blocks, 256, 0, st>>>(losses, delta, total, hf, wf, inv_y, inv_x, 1.f / (float)total, part,
+                                             ticket);
   return gg::launch_status("flow_losses");
 }
 

@@ -331,45 +331,32 @@ DISABLED = frozenset(filter(None, os.environ.get('GG_DISABLE', '').split(',')))
 ENABLED = frozenset(filter(None, os.environ.get('GG_ENABLE', '').split(',')))
 
 
-_WORKSPACES = {}
-
-
-def _workspace(device, nbytes):
-    ws = _WORKSPACES.get(device)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = _WORKSPACES[device] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-    return ws
-
-
 def conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, pad, scale=1.0, into=None):
     """-> (groups*cout_g, cin_g, k, k) gradient of a mode-0 convolution's weight; `into`: add it to this tensor
-    instead (returns None)."""
+    instead (returns None).  The library picks the kernel (row-streaming 3x3 / RGB-stem reduction / generic) and keeps
+    the K-split partial sums in its per-stream scratch; they are added in a fixed order (no float atomics)."""
     h, w = x.shape[-2], x.shape[-1]
     oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     limbs = _LIMBS[PRECISION]
     split = bool(limbs and (oh * ow) % 32 == 0 and ow % 4 == 0 and cout_g >= 32 and cin_g * k * k >= 32
                  and dy.data_ptr() % 16 == 0)
     stem = k == 1 and stride == 1 and pad == 0 and groups == 1 and cin_g <= 4 and (h * w) % 64 == 0   # RGB stem
-    if (stem or (split and k == 3 and stride == 1 and pad == 1 and (w % 32 == 0 or (w == 16 and h % 2 == 0)))) \
-            and 'wgrad_rows' not in DISABLED:
-        # row-streaming kernel; its K-split partials go through a workspace (one per device, grown on demand)
-        ws = _workspace(x.device, 1200 * 147456)
-        dw = into if into is not None else torch.empty((groups * cout_g, cin_g, k, k), dtype=torch.float32,
-                                                       device=x.device)
-        _lib.call('gg_conv2d_wgrad_ws_f32', dw, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale,
-                  limbs, 1 if into is not None else 0, ws, ws.numel() * 4)
+    rows = split and k == 3 and stride == 1 and pad == 1 and (w % 32 == 0 or (w == 16 and h % 2 == 0))
+    dw = into if into is not None else torch.empty((groups * cout_g, cin_g, k, k), dtype=torch.float32, device=x.device)
+    if 'wgrad_rows' in DISABLED and (stem or rows):
+        # A/B switch: the generic kernels (the row-streaming kernel is what gg_conv2d_wgrad_ws_f32 would choose)
+        if into is not None:
+            _lib.call('gg_conv2d_wgrad_acc_f32', into, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale,
+                      limbs if split else 0)
+        elif split:
+            _lib.call('gg_conv2d_wgrad_split_f32', dw, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale,
+                      limbs)
+        else:
+            _lib.call('gg_conv2d_wgrad_f32', dw, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale)
         return None if into is not None else dw
-    if into is not None:
-        _lib.call('gg_conv2d_wgrad_acc_f32', into, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale,
-                  limbs if split else 0)
-        return None
-    dw = torch.empty((groups * cout_g, cin_g, k, k), dtype=torch.float32, device=x.device)
-    if split:
-        _lib.call('gg_conv2d_wgrad_split_f32', dw, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale,
-                  limbs)
-    else:
-        _lib.call('gg_conv2d_wgrad_f32', dw, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale)
-    return dw
+    _lib.call('gg_conv2d_wgrad_ws_f32', dw, x, dy, batch, groups, cin_g, cout_g, h, w, k, stride, pad, scale,
+              limbs if (split or stem) else 0, 1 if into is not None else 0, None, 0)
+    return None if into is not None else dw
 
 
 class _Conv2d(Function):
@@ -498,9 +485,8 @@ class _Conv3x3BiasAct(Function):
             if dx is not None or not ctx.needs_input_grad[0]:
                 db = torch.zeros(cout, dtype=torch.float32, device=dy.device) if need_db else None
                 dw = slot if slot is not None else torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dy.device)
-                ws = _workspace(dy.device, 1200 * 147456)
                 rc = _lib.call('gg_conv3x3_masked_wgrad_f32', dw, db, x, dy, y, alpha, gain, n, cin, cout, h, w, wscale,
-                               2, 1 if slot is not None else 0, ws, ws.numel() * 4, allow=(_lib.NOT_SERVED,))
+                               2, 1 if slot is not None else 0, None, 0, allow=(_lib.NOT_SERVED,))
                 if rc == 0:
                     return dx, (None if slot is not None else dw), db, None, None, None
         g = torch.empty_like(dy)

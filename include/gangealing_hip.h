@@ -12,8 +12,15 @@
  *     entry points gg_conv3x3_masked_dgrad_f32 / gg_conv3x3_masked_wgrad_f32 return GG_NOT_SERVED when
  *     their kernel does not cover the shape: nothing was launched and the caller uses the unfused pair.
  *   - all tensors are dense row-major ("contiguous" in torch terms); NCHW unless noted.
- *   - kernels are enqueued on `stream` and never synchronise; nothing is allocated internally
- *     (workspaces are caller-provided), so every call is hipGraph-capturable.
+ *   - kernels are enqueued on `stream` and never synchronise.
+ *   - reproducibility: no floating-point atomics on the training path.  Split reductions (split-K convolutions,
+ *     K-split weight gradients, grid-wide sums, scatter-shaped gradients) keep their partial results in a
+ *     per-(device, stream) SCRATCH buffer owned by the library and add them in a fixed order, so results are
+ *     bitwise identical run to run.  The scratch grows on demand with hipMalloc (a few times, during the first
+ *     calls at the largest shapes); hipMalloc is not legal while a stream is being captured into a hipGraph, so run
+ *     the step eagerly once before capturing it (or call gg_scratch_reserve).  Exceptions, documented at the entry
+ *     points: the IMAGE gradient of the warp (gg_mipmap_warp_bwd_f32 with grad_pyr*, gg_mip_downsample2x_bwd_f32) and
+ *     gg_splat_forward_f32 scatter with float atomics - neither is on the training path.
  *   - outputs are fully overwritten unless the comment says "accumulates".
  */
 #ifndef GANGEALING_HIP_H
@@ -25,7 +32,13 @@ extern "C" {
 
 #define GG_NOT_SERVED (-1000)
 
+/* 2: library-owned scratch (gg_scratch_*), gg_lpips_tail_bwd_f32 gained `accumulate` */
 int gg_abi_version(void);
+/* Pre-size the scratch buffer of `stream` on the current device to at least `bytes` (and create its ticket page).
+ * Optional: the entry points grow it on demand. */
+int gg_scratch_reserve(long long bytes, void* stream);
+/* Free every scratch buffer (synchronises the device).  Graphs captured earlier must not be replayed afterwards. */
+int gg_scratch_release(void);
 const char* gg_last_error(void);
 /* Name of the gfx target the device code was built for ("gfx950"). */
 const char* gg_build_arch(void);

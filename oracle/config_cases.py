@@ -11,6 +11,8 @@ generator is called through NoiseFeeder, which turns `noise=None` into explicit 
 
 Configurations:
   c2  LSUN Cats 256^2, similarity+flow STN at 128^2, per-GPU batch 16, vgg_ssl loss form      (the benchmark config)
+  c2t the same with textured generator images (noise-injection weights x10)
+  c1  LSUN Cats 64^2, similarity-only STN, batch 4 (BASELINE.json configs[0])
   c4  CelebA-HQ 512^2 flags (scripts/training/celeba.sh:4-6 at gen_size 512): BilinearDownsample(4), border padding,
       inject 6, ndirs 512, sample_from_full_res, tv 2500, LPIPS with lin layers; batch 2
   c5  LSUN Cars clustering (scripts/training/lsun_cars.sh:4-7): num_heads 4, flips, ndirs 5, inject 6,
@@ -30,6 +32,17 @@ STN_RULES = (('warp_head.linear', 0.02), ('flow_out.2', 0.02), ('mask_out', 0.5)
 CONFIGS = {
     'c2': dict(gen_size=256, flow_size=128, real_size=256, batch=16, transform=['similarity', 'flow'], num_heads=1,
                flips=False, inject=5, ndirs=1, padding_mode='reflection', tv_weight=1000.0, flow_identity_weight=1.0,
+               sample_from_full_res=False, loss='vgg_ssl', psi=0.5),
+    # c2 with O(1) high-frequency image content: the generator's noise-injection weights drawn with scale 1.0 instead of
+    # 0.1 (per-pixel N(0,1) noise enters every layer at full strength: neighbouring pixels of the 256^2 image differ by
+    # 0.55 on average, of the 128^2 STN input by 0.17 - a warp error of 1e-3 pixel is then worth ~2e-4)
+    'c2t': dict(gen_size=256, flow_size=128, real_size=256, batch=16, transform=['similarity', 'flow'], num_heads=1,
+                flips=False, inject=5, ndirs=1, padding_mode='reflection', tv_weight=1000.0, flow_identity_weight=1.0,
+                sample_from_full_res=False, loss='vgg_ssl', psi=0.5, gen_rules=(('noise', 1.0),)),
+    # BASELINE.json configs[0]: 64^2, similarity-only STN, batch 4 (delta_flow is the (N, 2, 3) matrix; no TV /
+    # identity terms: train.py only evaluates them for flow STNs)
+    'c1': dict(gen_size=64, flow_size=64, real_size=64, batch=4, transform=['similarity'], num_heads=1,
+               flips=False, inject=5, ndirs=1, padding_mode='reflection', tv_weight=0.0, flow_identity_weight=0.0,
                sample_from_full_res=False, loss='vgg_ssl', psi=0.5),
     'c4': dict(gen_size=512, flow_size=128, real_size=512, batch=2, transform=['similarity', 'flow'], num_heads=1,
                flips=False, inject=6, ndirs=512, padding_mode='border', tv_weight=2500.0, flow_identity_weight=1.0,
@@ -120,7 +133,7 @@ def build_models(api, cfg, tag, device, dtype=None):
     dtype=torch.float64 (reference on CPU only) gives the double-precision evaluation the gradient checks use as
     ground truth."""
     gen = api.Generator(cfg['gen_size'], 512, 8, channel_multiplier=2)
-    torch.nn.Module.load_state_dict(gen, det_state_dict(gen), strict=False)
+    torch.nn.Module.load_state_dict(gen, det_state_dict(gen, cfg.get('gen_rules', ())), strict=False)
     gen = gen.to(device).eval().requires_grad_(False)
     stn = api.get_stn(list(cfg['transform']), flow_size=cfg['flow_size'], supersize=cfg['real_size'],
                       channel_multiplier=0.5, num_heads=cfg['num_heads'])
@@ -169,9 +182,13 @@ def run_config(api, name, device, backward=True, dtype=None):
         else:
             ploss, delta = api.gangealing_loss(feeder, stn_tap, ll, loss_fn, resize_tap, cfg['psi'], cfg['batch'], 512,
                                                False, device, **common)
-    tv = api.total_variation_loss(delta)
-    idl = api.flow_identity_loss(delta)
-    total = ploss + cfg['tv_weight'] * tv + cfg['flow_identity_weight'] * idl
+    if 'flow' in cfg['transform']:
+        tv = api.total_variation_loss(delta)
+        idl = api.flow_identity_loss(delta)
+        total = ploss + cfg['tv_weight'] * tv + cfg['flow_identity_weight'] * idl
+    else:                               # train.py:113-123: the flow regularisers exist for flow STNs only
+        tv = idl = torch.zeros((), dtype=ploss.dtype, device=ploss.device)
+        total = ploss
     out = dict(unaligned=feeder.outputs[0].detach(), target=resize_tap.outputs[0].detach(),
                pred=stn_tap.outputs[0][0].detach(), stn_delta=stn_tap.outputs[0][1].detach(),
                delta_flow=delta.detach(), ploss=ploss.detach(), tv=tv.detach(), identity=idl.detach(),
