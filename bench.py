@@ -180,7 +180,7 @@ def measure(device, wl, precision, graph, steps, warmup, world, gdist, profile=T
     from gangealing_amd.train_step import GangealingTrainer
     conv_mfma.set_precision(precision)
     trainer = GangealingTrainer(device, perturb_heads=0.02, seed=0, use_graph=graph and world == 1,
-                                stn_lr=SYNTHETIC_LR, ll_lr=SYNTHETIC_LR, **wl)
+                                stn_lr=SYNTHETIC_LR, ll_lr=SYNTHETIC_LR, allow_random_loss=True, **wl)
 
     def barrier():
         torch.cuda.synchronize()

@@ -45,6 +45,17 @@ def sample_gan_supervised_pairs(generator, ll, resize_fake2stn, psi, batch, dim_
     # small batches (the reference recipes use 5 per GPU), opt-in (GG_ENABLE=two_streams) otherwise.
     overlap = (isinstance(generator, torch.nn.Module) and z.is_cuda and hasattr(generator, 'get_latent') and
                'two_streams' not in conv_mfma.DISABLED and (batch <= 8 or 'two_streams' in conv_mfma.ENABLED))
+    if overlap:
+        # Everything derived from the frozen weights (GEMM-layout packs, squared-weight tables, scaled EqualLinear
+        # weights, style-bank job tables) is built lazily by whichever pass touches a layer first and then cached on
+        # the host.  With two streams that would be the side stream, while the other pass reads the cached buffers on
+        # the main stream with no dependency between them: a read-before-write race on the first iteration and after
+        # every weight load.  So the first call for a given set of weight versions (and arithmetic mode) runs both
+        # passes on the current stream - which builds every cache there - and only later calls fork.
+        key = (conv_mfma.PRECISION, z.device, psi is not None) + tuple(p._version for p in generator.parameters())
+        if generator.__dict__.get('_two_stream_ready') != key:
+            generator.__dict__['_two_stream_ready'] = key
+            overlap = False
     if not overlap:
         with torch.no_grad():
             unaligned_in, w_noise = generator([z], noise=None, return_latents=True)
@@ -421,17 +432,23 @@ VGG_SSL_WEIGHTS = 'pretrained/simclr_vgg_phase150.pt'
 LPIPS_WEIGHTS = 'pretrained/lpips_vgg_v0.1.pt'
 
 
-def get_perceptual_loss(loss_fn, device, weights=None, allow_random=True):
+def get_perceptual_loss(loss_fn, device, weights=None, allow_random=False, trunk_weights=None):
     """lpips.py:11-23.  The reference downloads its weights; here they must already be on disk (`weights`, default the
-    reference's `pretrained/...` path).  Without them: `allow_random` -> a warning and a seeded random trunk (the
-    synthetic benchmark / parity configuration), else FileNotFoundError."""
+    reference's `pretrained/...` path).
+      vgg_ssl: `weights` = the SimCLR VGG16 `features` state_dict (simclr_vgg_phase150.pt).
+      lpips:   `weights` = lpips_vgg_v0.1.pt, which holds ONLY the learned `lin` layers (the reference takes the trunk
+               from torchvision's ImageNet VGG16, lpips_backbones.py:101); the trunk comes from `trunk_weights` (a
+               torchvision-layout `features` state_dict) unless the file itself carries `net.slice*` entries.
+    A missing file - or, for lpips, a trunk that was never loaded - raises unless `allow_random` (synthetic benchmark /
+    parity runs: a warning and the seeded random trunk)."""
     import os
     import warnings
     if loss_fn == 'vgg_ssl':
         path = VGG_SSL_WEIGHTS if weights is None else weights
         have = os.path.isfile(path)
         if not have and not allow_random:
-            raise FileNotFoundError(f'{path}: SimCLR VGG16 weights not found')
+            raise FileNotFoundError(f'{path}: SimCLR VGG16 weights not found (allow_random=True / '
+                                    f'GANGEALING_SYNTHETIC=1 runs on a seeded random trunk instead)')
         if not have:
             warnings.warn(f'perceptual loss: {path} not found - using a RANDOMLY INITIALISED VGG16 trunk '
                           f'(synthetic benchmark configuration; not a training objective)')
@@ -442,9 +459,27 @@ def get_perceptual_loss(loss_fn, device, weights=None, allow_random=True):
         if not os.path.isfile(path):
             raise FileNotFoundError(f'{path}: LPIPS needs its learned lin layers and an ImageNet VGG16 trunk; neither '
                                     f'can be downloaded here.  Build LPIPS(...) yourself and load a state_dict.')
+        sd = torch.load(path, map_location='cpu')
         model = LPIPS(net='vgg', pnet_rand=True, pretrained=False)
-        model.load_state_dict(torch.load(path, map_location='cpu'), strict=False)
+        missing_lins = [f'lin{k}.model.1.weight' for k in range(5) if f'lin{k}.model.1.weight' not in sd]
+        if missing_lins:
+            raise RuntimeError(f'{path}: not an LPIPS checkpoint (missing {missing_lins})')
+        model.load_state_dict(sd, strict=False)
         model.lins_loaded = True
+        if any(k.startswith('net.slice') for k in sd):
+            trunk_keys = {k for k in model.state_dict() if k.startswith('net.slice')}
+            absent = sorted(trunk_keys - set(sd))
+            if absent:
+                raise RuntimeError(f'{path}: incomplete VGG16 trunk (missing {absent[:4]} ...)')
+            model.net.weights_loaded = True
+        elif trunk_weights is not None:
+            model.net.load_features_state_dict(torch.load(trunk_weights, map_location='cpu'), strict=True)
+        if not model.net.weights_loaded:
+            msg = (f'{path} holds the lin layers only; the VGG16 trunk needs `trunk_weights` (torchvision vgg16 '
+                   f'`features` state_dict: the ImageNet weights the reference downloads)')
+            if not allow_random:
+                raise FileNotFoundError(msg)
+            warnings.warn('perceptual loss: ' + msg + ' - using a RANDOMLY INITIALISED trunk (synthetic run)')
         return model.to(device)
     raise NotImplementedError(loss_fn)
 

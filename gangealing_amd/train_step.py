@@ -167,7 +167,10 @@ class GangealingTrainer:
                  flow_identity_weight=1.0, stn_lr=1e-3, ll_lr=1e-2, sample_from_full_res=False, freeze_ll=False,
                  loss_fn='vgg_ssl', seed=0, perturb_heads=0.0, pipeline_update=None, anneal_psi=150000,
                  anneal_fn='cosine', period=37500, decay=0.9, tm=2, perceptual_weights=None, use_graph=False,
-                 graph_warmup=3):
+                 graph_warmup=3, allow_random_loss=None, perceptual_trunk_weights=None):
+        """allow_random_loss: run on a seeded RANDOM perceptual trunk when the weight files are missing (synthetic
+        benchmark / parity runs).  Default None = only when GANGEALING_SYNTHETIC=1 is set; training otherwise raises
+        FileNotFoundError instead of silently optimising a meaningless objective."""
         self.device = device
         self._pending = None
         self.batch = batch
@@ -201,7 +204,11 @@ class GangealingTrainer:
         self.t_ema.requires_grad_(False)
         self.ll = DirectionInterpolator(None, ndirs, inject, self.generator.n_latent, num_heads,
                                         dim_latent=dim_latent).to(device)
-        self.loss_fn = get_perceptual_loss(loss_fn, device, weights=perceptual_weights)
+        if allow_random_loss is None:
+            import os
+            allow_random_loss = os.environ.get('GANGEALING_SYNTHETIC', '0') == '1'
+        self.loss_fn = get_perceptual_loss(loss_fn, device, weights=perceptual_weights,
+                                           allow_random=allow_random_loss, trunk_weights=perceptual_trunk_weights)
         self.resize_fake2stn = BilinearDownsample(gen_size // flow_size, 3).to(device) if gen_size > flow_size \
             else nn.Sequential()
         conv_mfma.enable_pack_registry()     # trainable conv weights: packs rebuilt once per step (repack_trainable)
@@ -414,7 +421,7 @@ class GangealingTrainer:
 def smoke(device):
     """Tiny end-to-end iteration (used by __graft_entry__.smoke)."""
     tr = GangealingTrainer(device, gen_size=64, flow_size=64, batch=2, transform=('similarity', 'flow'), inject=3,
-                           ndirs=2, perturb_heads=0.02)
+                           ndirs=2, perturb_heads=0.02, allow_random_loss=True)
     before = tr.stn_arena.param.clone()
     parts = tr.step(psi=0.5)
     torch.cuda.synchronize()

@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault('GANGEALING_SYNTHETIC', '1')     # random perceptual trunk: synthetic run
 import sys; sys.path.insert(0, '/root/repo')
 import torch
 from gangealing_amd.train_step import GangealingTrainer

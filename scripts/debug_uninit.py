@@ -1,5 +1,7 @@
 """Does any kernel read memory it did not write?  Run the same loss + backward with the allocator's free pool poisoned
 with zeros, then with 1e30 / NaN: results must be identical up to atomics noise."""
+import os
+os.environ.setdefault('GANGEALING_SYNTHETIC', '1')     # random perceptual trunk: synthetic run
 import sys; sys.path.insert(0, '/root/repo')
 import torch
 from gangealing_amd.train_step import GangealingTrainer

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Time the one-launch re-pack of every trainable convolution weight (after the optimizer step) of config C2."""
 import os
+os.environ.setdefault('GANGEALING_SYNTHETIC', '1')     # random perceptual trunk: synthetic run
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402

@@ -9,6 +9,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
+# the tests build trainers without perceptual-loss weight files (none are reachable offline): opt in to the seeded
+# random trunk that GangealingTrainer otherwise refuses (gangealing_amd/train_step.py: allow_random_loss)
+os.environ.setdefault('GANGEALING_SYNTHETIC', '1')
 
 
 def pytest_configure(config):

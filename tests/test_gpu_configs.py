@@ -213,10 +213,12 @@ def test_c2_stn_batch16(ci, mode, cuda):
                 floor_scale=3.0)
 
 
-@pytest.mark.parametrize('name', ['c2', 'c4', 'c5'])
+@pytest.mark.parametrize('name', ['c1', 'c2', 'c2t', 'c4', 'c5'])
 def test_config_loss_step(name, mode, cuda):
     """One loss evaluation + backward of BASELINE config `name` (train.py:106-124) through the same driver that ran
-    the reference."""
+    the reference.  c2t = c2 with textured generator images (per-pixel noise at full strength: neighbouring pixels of
+    the warped 128^2 output differ by 0.07 on average at amplitude 2.5); c1 = configs[0], similarity-only STN (its
+    "flow" is the (N, 2, 3) matrix and there are no flow regularisers)."""
     from oracle import config_cases as cc
     (c,) = load_golden(f'cfg_{name}')
     res = cc.run_config(our_api(), name, cuda)
@@ -224,14 +226,19 @@ def test_config_loss_step(name, mode, cuda):
     for key in ('unaligned', 'target', 'pred', 'stn_delta', 'delta_flow'):
         assert list(res[key].shape) == c['meta']['shapes'][key], (key, res[key].shape)
         check_batch(test, mode, res[key], c, key)
-    for key in ('ploss', 'tv', 'identity', 'total'):
+    has_flow = 'flow' in cc.CONFIGS[name]['transform']
+    for key in ('ploss', 'total') + (('tv', 'identity') if has_flow else ()):
         err = record_parity(test, mode, key, res[key].cpu().numpy(), c[key])
         assert err <= 1e-4 * abs(float(c[key])) + 1e-9, (key, err, float(c[key]))       # every loss term to 1e-4 relative
     grads = res['grads']
     assert set(grads) == set(c['meta']['grad_norms'])
-    check_grads(test + '/flow-stage', mode, grads, c, select=lambda k: k.startswith('stns.1.'))
-    check_grads(test + '/similarity-stage', mode, grads, c, select=lambda k: k.startswith('stns.0.'), factor=SIM_FACTOR,
-                floor_scale=3.0)
+    if has_flow:
+        check_grads(test + '/flow-stage', mode, grads, c, select=lambda k: k.startswith('stns.1.'))
+        check_grads(test + '/similarity-stage', mode, grads, c, select=lambda k: k.startswith('stns.0.'),
+                    factor=SIM_FACTOR, floor_scale=3.0)
+    else:       # a single similarity STN: its parameters carry no `stns.N.` prefix
+        check_grads(test + '/similarity-stage', mode, grads, c, select=lambda k: k != 'll.coefficients',
+                    factor=SIM_FACTOR, floor_scale=3.0)
     check_grads(test + '/latent-learner', mode, grads, c, select=lambda k: k == 'll.coefficients')
 
 

@@ -6,7 +6,8 @@ Adam + EMA + re-pack deferred to the next STN forward - for three iterations and
   (i)   the replicas hold bit-identical STN / EMA / latent-learner parameters after every flush();
   (ii)  the gradient the optimiser consumed is exactly the sum of the two ranks' local gradients (the 1/world factor
         is folded into the Adam kernel), and the ranks really computed different local gradients;
-  (iii) the run agrees with the same three iterations in the immediate-update order (pipeline_update=False).
+  (iii) the run agrees BIT FOR BIT with the same three iterations in the immediate-update order
+        (pipeline_update=False): parameters, EMA, latent learner, consumed gradients, losses.
 """
 import os
 import socket
@@ -94,22 +95,15 @@ def _worker(rank, world, port, q):
             dist.all_gather(locs, rec['local'])
             ok_sum = ok_sum and torch.equal(rec['consumed'], locs[0] + locs[1])
             distinct = distinct or not torch.equal(locs[0], locs[1])
-        # (iii): same iterations, immediate order.  Split-K atomics make gradients differ in the last bits from run to
-        # run and Adam's first steps are ~lr * sign(g), so entries whose gradient is near zero take different signs
-        # in two runs of even the SAME order: compare what is robust - the gradient the first update consumed (both
-        # runs start from identical parameters), each step's update direction and length, and the losses.  A missing
-        # or doubled update gives a norm ratio of 0 / 2, a mis-ordered one a different gradient.
-        g_p, g_i = piped[0]['consumed'], immediate[0]['consumed']
-        first_grad = float((g_p - g_i).abs().max() / g_i.abs().max())
-        agree = []
-        prev_p = prev_i = init
-        for a, b in zip(piped, immediate):
-            dp, di = (a['param'] - prev_p).double(), (b['param'] - prev_i).double()
-            cos = float((dp * di).sum() / (dp.norm() * di.norm()))
-            agree.append((cos, float(dp.norm() / di.norm()), abs(a['loss'] - b['loss']) / max(abs(b['loss']), 1e-12)))
-            prev_p, prev_i = a['param'], b['param']
-        result.update(ok_sync=bool(ok_sync), ok_sum=bool(ok_sum), distinct=bool(distinct), agree=agree,
-                      first_grad=first_grad)
+        # (iii): same iterations, immediate order.  The library adds every partial sum in a fixed order (no float
+        # atomics), the pipelined order shows every forward exactly the parameters of the immediate order, and gloo's
+        # two-rank sum is commutative: the two runs must agree bit for bit.
+        same_order = all(torch.equal(a[key], b[key]) for a, b in zip(piped, immediate)
+                         for key in ('param', 'ema', 'll', 'consumed'))
+        worst = max(float((a['param'].double() - b['param'].double()).abs().max()) for a, b in zip(piped, immediate))
+        loss_same = all(a['loss'] == b['loss'] for a, b in zip(piped, immediate))
+        result.update(ok_sync=bool(ok_sync), ok_sum=bool(ok_sum), distinct=bool(distinct), same_order=bool(same_order),
+                      worst=worst, loss_same=bool(loss_same))
     except Exception as e:          # surface the failure in the parent instead of a queue timeout
         import traceback
         result['error'] = ''.join(traceback.format_exception(type(e), e, e.__traceback__))[-3000:]
@@ -132,10 +126,6 @@ def test_two_ranks_one_gpu_pipelined_trainer(cuda):
         assert 'error' not in res, res['error']
         assert res['ok_sync'], 'replicas diverged after flush()'
         assert res['ok_sum'] and res['distinct'], (res['ok_sum'], res['distinct'])
-        # same parameters, same data: the two orders consume the same gradient up to the arg-max routing of exactly
-        # tied mip-level distances, which last-bit noise of the split-K forward can flip
-        assert res['first_grad'] < 1e-2, res['first_grad']
-        for s, (cos, ratio, dl) in enumerate(res['agree']):
-            assert cos > 0.7 and 0.7 < ratio < 1.4 and dl < 5e-2, (s, cos, ratio, dl)
+        assert res['same_order'] and res['loss_same'], ('pipelined and immediate update orders differ', res['worst'])
     for p in procs:
         assert p.exitcode == 0

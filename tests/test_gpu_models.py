@@ -410,19 +410,13 @@ def test_pipelined_optimizer_update_matches_immediate_update(cuda):
     b0, b1, be, b2, lb = run(True)
     assert torch.equal(a0, b0)
 
-    def frac(x, y, tol):
-        return float(((x - y).abs() > tol).float().mean())
-
-    # Split-K atomics make gradients differ in the last bits from run to run, and Adam's first update is
-    # lr * sign(g) almost everywhere: two immediate-update runs differ in 0.1-0.7 % of the entries by up to 2 lr.
-    # The pipelined run has to sit in that band (a missing / doubled / mis-ordered update would move EVERY entry).
+    # nothing in the step adds floating-point numbers in a run-dependent order (no atomics), and the deferred update
+    # shows every forward the same parameters as the immediate one: bitwise equality
     assert float((a1 - a0).abs().max()) > 0
-    assert frac(a1, b1, 1e-6) < 0.03 and float((a1 - b1).abs().max()) <= 2.1e-3
-    assert float((ae - be).abs().max()) <= 1e-4
-    assert abs(la - lb) <= 2e-2 * abs(la)
-    assert frac(a2, b2, 2e-4) < 0.05 and float((a2 - b2).abs().max()) <= 4.2e-3
-    moved = frac(a2, a1, 1e-6)
-    assert moved > 0.9 and frac(b2, b1, 1e-6) > 0.9, moved        # the second update was applied in both modes
+    assert torch.equal(a1, b1) and torch.equal(ae, be) and la == lb
+    assert torch.equal(a2, b2)
+    moved = float(((a2 - a1).abs() > 1e-6).float().mean())
+    assert moved > 0.9, moved                                      # the second update was applied
 
 
 def test_ema_network_forward_follows_the_optimizer(cuda):

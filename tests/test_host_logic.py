@@ -243,9 +243,43 @@ def test_lpips_module_layout_matches_reference_and_loads_torchvision_features():
     with pytest.raises(FileNotFoundError):                            # 'lpips' never silently becomes another loss
         get_perceptual_loss('lpips', 'cpu', weights='/nonexistent/lpips_vgg.pt')
     with pytest.warns(UserWarning):
+        get_perceptual_loss('vgg_ssl', 'cpu', weights='/nonexistent/simclr.pt', allow_random=True)
+    with pytest.raises(FileNotFoundError):                            # the default: no silent random trunk
         get_perceptual_loss('vgg_ssl', 'cpu', weights='/nonexistent/simclr.pt')
-    with pytest.raises(FileNotFoundError):
-        get_perceptual_loss('vgg_ssl', 'cpu', weights='/nonexistent/simclr.pt', allow_random=False)
+
+
+def test_lpips_checkpoint_needs_a_trunk(tmp_path):
+    """lpips_vgg_v0.1.pt holds the lin layers ONLY (the reference takes the trunk from torchvision): loading it must
+    not leave a random trunk behind silently (round-2 ADVICE)."""
+    from gangealing_amd.losses import LPIPS, get_perceptual_loss
+    ref = LPIPS(net='vgg', pnet_rand=True, pretrained=False)
+    lin_only = {k: v for k, v in ref.state_dict().items() if k.startswith('lin') and not k.startswith('lins.')}
+    assert sorted(lin_only) == [f'lin{k}.model.1.weight' for k in range(5)]
+    path = tmp_path / 'lpips_vgg_v0.1.pt'
+    torch.save(lin_only, path)
+    with pytest.raises(FileNotFoundError, match='trunk'):
+        get_perceptual_loss('lpips', 'cpu', weights=str(path))
+    with pytest.warns(UserWarning, match='RANDOMLY'):
+        net = get_perceptual_loss('lpips', 'cpu', weights=str(path), allow_random=True)
+    assert net.lins_loaded and not net.net.weights_loaded
+    # with a torchvision-layout `features` file for the trunk
+    feats = {}
+    for si in range(1, 6):
+        for idx, mod in getattr(ref.net, f'slice{si}').named_children():
+            if isinstance(mod, torch.nn.Conv2d):
+                feats[f'{idx}.weight'] = torch.full_like(mod.weight, 0.25)
+                feats[f'{idx}.bias'] = torch.zeros_like(mod.bias)
+    tpath = tmp_path / 'vgg16_features.pt'
+    torch.save(feats, tpath)
+    net = get_perceptual_loss('lpips', 'cpu', weights=str(path), trunk_weights=str(tpath))
+    assert net.net.weights_loaded and float(net.net.slice1[0].weight.min()) == 0.25
+    # a full LPIPS state_dict (trunk + lins) needs nothing else
+    full = tmp_path / 'full.pt'
+    torch.save({k: v for k, v in ref.state_dict().items() if not k.startswith('lins.')}, full)
+    assert get_perceptual_loss('lpips', 'cpu', weights=str(full)).net.weights_loaded
+    torch.save({'lin0.model.1.weight': lin_only['lin0.model.1.weight']}, path)
+    with pytest.raises(RuntimeError, match='not an LPIPS checkpoint'):
+        get_perceptual_loss('lpips', 'cpu', weights=str(path))
 
 
 def test_torch_library_ops_are_registered_with_fake_kernels():
