@@ -299,17 +299,21 @@ class vgg16(nn.Module):
         self.weights_loaded = True
         return result
 
-    def forward(self, x, tap=None):
+    def forward(self, x, tap=None, observe=None):
         """tap: optional callable (slice index, features) -> (features, value); when given the trunk returns the list
-        of values instead of the list of feature maps (LPIPS' fused per-tap distance)."""
+        of values instead of the list of feature maps (LPIPS' fused per-tap distance).
+        observe: optional callable (torchvision `features` index of a convolution, its ReLU output) - diagnostics
+        (tests/test_gpu_lpips_masks.py inspects / pins the branch decisions through it)."""
         feats = []
         for si in range(5):
-            for mod in getattr(self, f'slice{si + 1}'):
+            for name, mod in getattr(self, f'slice{si + 1}').named_children():
                 if isinstance(mod, nn.Conv2d):
                     if x.shape[1] % 32 == 0:     # conv + bias + ReLU in one kernel (alpha 0, gain 1)
                         x = conv_mfma.conv3x3_bias_act(x, mod.weight, mod.bias, 0.0, 1.0)
                     else:                        # 3-channel stem: fp32 kernel + separate ReLU
                         x = F.relu(conv_mfma.conv2d(x, mod.weight, mod.bias, stride=1, padding=1))
+                    if observe is not None:
+                        observe(int(name), x)
                 elif isinstance(mod, nn.MaxPool2d):
                     x = max_pool2x2(x)
                 # nn.ReLU: applied in the convolution above
@@ -394,11 +398,12 @@ class LPIPS(nn.Module):
                 raise NotImplementedError('LPIPS lin layers with active dropout (training mode) are not fused')
             return self.lins[kk].model[-1].weight
 
+        observe = self.__dict__.get('observe')            # diagnostics hook, see vgg16.forward
         if x.dtype == torch.float32 and not ({'lpips_tail', 'lpips_tap'} & conv_mfma.DISABLED):
-            res = [v.view(n, 1, 1, 1) for v in self.net(x, tap=lambda kk, f: lpips_tap(f, lin_of(kk)))]
+            res = [v.view(n, 1, 1, 1) for v in self.net(x, tap=lambda kk, f: lpips_tap(f, lin_of(kk)), observe=observe)]
             feats = []
         else:
-            feats = self.net(x)
+            feats = self.net(x, observe=observe)
             res = []
         for kk, f in enumerate(feats):
             lin = lin_of(kk)

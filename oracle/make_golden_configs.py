@@ -1,7 +1,7 @@
 """Golden vectors at BASELINE.json's own configurations, produced by the REFERENCE on CPU.
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py); authoring container only (needs /root/reference).
 
-    python oracle/make_golden_configs.py [c2_generator c2_stn c1 c2 c2t c4 c5 lpips]      # ~15 min on 8 cores for all
+    python oracle/make_golden_configs.py [c2_generator c2_stn c1 c2 c2t c4 c5 lpips lpips_masks]      # ~15 min on 8 cores for all
 
 Writes tests/golden/{c2_generator,c2_stn,cfg_c1,cfg_c2,cfg_c2t,cfg_c4,cfg_c5,lpips}.npz.  The reference runs unmodified: its
 modules are imported exactly as oracle/make_golden.py does, plus a local VGG16 `features` stack placed where
@@ -163,12 +163,65 @@ def gen_lpips(api):
     save('lpips', cases)
 
 
+def pool_winner_codes(x):
+    """Which input of every 2x2 / stride-2 window ATen's max_pool2d picks (row-major scan, a later element replaces the
+    maximum only if strictly greater): 0..3 = (dy * 2 + dx)."""
+    c = [x[..., dy::2, dx::2] for dy in (0, 1) for dx in (0, 1)]
+    best, code = c[0], torch.zeros_like(c[0], dtype=torch.uint8)
+    for k in (1, 2, 3):
+        upd = c[k] > best
+        code = torch.where(upd, torch.full_like(code, k), code)
+        best = torch.where(upd, c[k], best)
+    return code
+
+
+def gen_lpips_masks(api):
+    """The branch decisions of the reference's float32 LPIPS run behind tests/golden/lpips.npz: one bit per ReLU unit
+    (output > 0) of the 13 VGG16 convolutions and two bits per 2x2 max-pool window (the winner), for both images of
+    every pair (batch order: in0 then in1).  The trunk and the inputs are the same in both lpips.npz cases, so one set
+    serves both.  tests/test_gpu_lpips_masks.py replays the HIP backward with these decisions forced."""
+    net = api.LPIPS(net='vgg', lpips=False, pnet_rand=True, pretrained=False, verbose=False)
+    torch.nn.Module.load_state_dict(net, cc.det_lpips_state_dict(net), strict=False)
+    net.eval()
+    in0 = rnd('lpips.in0', (3, 3, 64, 64), 0.5)
+    in1 = rnd('lpips.in1', (3, 3, 64, 64), 0.5)
+    relu, pool, hooks = {}, {}, []
+    for si in range(1, 6):
+        for name, mod in getattr(net.net, f'slice{si}').named_children():
+            idx = int(name)
+            if isinstance(mod, nn.ReLU):            # features[idx - 1] is its convolution
+                hooks.append(mod.register_forward_hook(
+                    lambda m, i, o, idx=idx: relu.setdefault(idx - 1, []).append((o > 0).clone())))
+            elif isinstance(mod, nn.MaxPool2d):
+                hooks.append(mod.register_forward_hook(
+                    lambda m, i, o, idx=idx: pool.setdefault(idx, []).append(pool_winner_codes(i[0]))))
+    with torch.no_grad():
+        val = net(in0, in1)
+    for h in hooks:
+        h.remove()
+    ref = np.load(os.path.join(REPO, 'tests', 'golden', 'lpips.npz'))
+    assert np.array_equal(val.numpy(), ref['case00/val']), 'not the run stored in lpips.npz'
+    case, shapes = {}, {}
+    for idx, parts in sorted(relu.items()):
+        m = torch.cat(parts, 0).numpy()              # (6, C, H, W): in0's three images, then in1's
+        shapes[f'relu{idx}'] = list(m.shape)
+        case[f'relu{idx}'] = np.packbits(m.reshape(-1))
+    for idx, parts in sorted(pool.items()):
+        c = torch.cat(parts, 0).numpy().reshape(-1)
+        shapes[f'pool{idx}'] = list(torch.cat(parts, 0).shape)
+        c = np.concatenate([c, np.zeros((-c.size) % 4, np.uint8)])
+        case[f'pool{idx}'] = (c[0::4] | (c[1::4] << 2) | (c[2::4] << 4) | (c[3::4] << 6)).astype(np.uint8)
+    case['meta'] = dict(shapes=shapes, relu_layers=sorted(relu), pool_layers=sorted(pool),
+                        active_fraction={str(k): float(torch.cat(v, 0).float().mean()) for k, v in relu.items()})
+    save('lpips_masks', [case])
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
     api = reference_api()
     only = sys.argv[1:]
-    jobs = dict(lpips=lambda: gen_lpips(api), c2_generator=lambda: gen_c2_generator(api), c2_stn=lambda: gen_c2_stn(api),
+    jobs = dict(lpips=lambda: gen_lpips(api), lpips_masks=lambda: gen_lpips_masks(api), c2_generator=lambda: gen_c2_generator(api), c2_stn=lambda: gen_c2_stn(api),
                 c1=lambda: gen_config(api, 'c1'), c5=lambda: gen_config(api, 'c5'), c4=lambda: gen_config(api, 'c4'),
                 c2=lambda: gen_config(api, 'c2'), c2t=lambda: gen_config(api, 'c2t'))
     for name, fn in jobs.items():
