@@ -174,8 +174,16 @@ SYNTHETIC_LR = 1e-4      # the work per step does not depend on the learning rat
                          # 1e4 .. 1e10 in the similarity head), 1e-4 keeps it near its perturbed initial warp
 
 
-def measure(device, wl, precision, graph, steps, warmup, world, gdist, profile=True):
-    """Warm-up, then time exactly `steps` iterations between barrier + synchronize pairs.  -> dict."""
+def measure(device, wl, precision, graph, steps, warmup, world, gdist, profile=True, modconv='shared'):
+    """Warm-up, then time exactly `steps` iterations between barrier + synchronize pairs.  -> dict.
+    modconv='grouped': the generator's modulated convolutions in the reference's own formulation (materialised
+    per-sample weights + grouped convolution through op.conv2d_gradfix: the literal drop-in route)."""
+    from gangealing_amd.stylegan2 import networks
+    with networks.modconv_form(modconv):
+        return _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile)
+
+
+def _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile):
     from gangealing_amd.op import conv_mfma
     from gangealing_amd.train_step import GangealingTrainer
     conv_mfma.set_precision(precision)
@@ -303,15 +311,22 @@ def main():
         # further measurements of the same workload in the same process (each with its own trainer); `value` above
         # stays the eager, parity-preserving run whose dominant kernel was timed with HIP events
         extras = {}
-        for name, prec, graph in (('hipgraph_replay', args.precision, True), ('bf16_eager', 'bf16', False),
-                                  ('bf16_hipgraph_replay', 'bf16', True)):
+        for name, prec, graph, form in (('hipgraph_replay', args.precision, True, 'shared'),
+                                        ('bf16_eager', 'bf16', False, 'shared'),
+                                        ('bf16_hipgraph_replay', 'bf16', True, 'shared'),
+                                        # the literal drop-in route: reference-form generator (per-sample weights +
+                                        # grouped convolutions through op.conv2d_gradfix), same step otherwise
+                                        ('dropin_route', args.precision, False, 'grouped')):
             if name.startswith('bf16') and args.precision == 'bf16':
                 continue
             try:
-                r = measure(device, wl, prec, graph, args.steps, args.warmup, world, gdist, profile=False)
+                r = measure(device, wl, prec, graph, args.steps, args.warmup, world, gdist, profile=False, modconv=form)
                 extras[name] = {'value': round(r['images'] / r['elapsed'], 3),
                                 'ms_per_step': round(1e3 * r['elapsed'] / args.steps, 3), 'dtype': DTYPE[prec],
                                 'launch': 'hipGraph replay' if r['graphed'] else 'eager'}
+                if form == 'grouped':
+                    extras[name]['generator'] = ('reference formulation: materialised (N*Cout, Cin, k, k) weights, '
+                                                 'conv2d / conv_transpose2d with groups = N')
             except Exception as e:             # noqa: BLE001 - an extra must never take the headline line down
                 extras[name] = {'error': str(e)[:200]}
         out['extras'] = extras

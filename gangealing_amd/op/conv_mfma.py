@@ -192,9 +192,13 @@ def mark_trainable_packs_current():
 def packed(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0):
     """PackedWeight for `weight`; weights that do not require grad (frozen VGG / generator) keep their
     packs across steps, keyed by storage + version so an in-place update invalidates them."""
+    if groups > 1 and not isinstance(weight, torch.nn.Parameter):
+        # per-sample weights of the reference-form modulated convolution (groups = batch): a fresh (N*Cout, Cin, k, k)
+        # tensor per call - nothing to cache (a cache entry would pin 151 MB per layer and pass)
+        return PackedWeight(weight.detach(), groups, cout_g, cin_g, k, transpose_io, flip, scale)
     if weight.requires_grad:
         reg = TRAINABLE_PACKS
-        if reg is None or 'pack_registry' in DISABLED:
+        if reg is None or 'pack_registry' in DISABLED or not weight.is_leaf:
             return PackedWeight(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale)
         key = (weight.data_ptr(), groups, cout_g, cin_g, k, int(transpose_io), int(flip), float(scale))
         ent = reg.entries.get(key)

@@ -27,6 +27,31 @@ from ..op.upfirdn2d import blur_noise_act, blur_noise_act_ok, upfirdn2d_add
 from ..op import conv_mfma
 
 
+# How ModulatedConv2d executes:
+#   'shared'  (default) one dense convolution with shared weights; style and demodulation ride in the gather / epilogue
+#   'grouped' the reference's own operator sequence (networks.py:233-282): per-sample weights scale * W * style
+#             (* demod) materialised as an (N * Cout, Cin, k, k) tensor and a per-sample GROUPED convolution issued
+#             through op.conv2d_gradfix (conv2d / conv_transpose2d with groups = N) - what an unmodified reference
+#             networks.py runs on these operators (`python -m gangealing_amd.launch .../train.py`).
+#             No fusion across layers applies in this form; it exists so that the literal drop-in route is tested and
+#             timed (tests/test_gpu_dropin.py, bench.py extras.dropin_route).
+import contextlib as _contextlib
+import os as _os
+MODCONV_FORM = _os.environ.get('GANGEALING_MODCONV', 'shared')
+
+
+@_contextlib.contextmanager
+def modconv_form(form):
+    global MODCONV_FORM
+    if form not in ('shared', 'grouped'):
+        raise ValueError(f'modconv form {form!r}: shared | grouped')
+    old, MODCONV_FORM = MODCONV_FORM, form
+    try:
+        yield
+    finally:
+        MODCONV_FORM = old
+
+
 class PixelNorm(nn.Module):
     def forward(self, input):
         return input * torch.rsqrt(torch.mean(input ** 2, dim=1, keepdim=True) + 1e-8)
@@ -202,10 +227,33 @@ class ModulatedConv2d(nn.Module):
         return (slot, mod.weight.detach(), None if mod.bias is None else mod.bias.detach(), mod.scale, mod.lr_mul,
                 wsq if self.demodulate else None, self.eps)
 
+    def forward_grouped(self, input, style):
+        """The reference's formulation (networks.py:233-282) on the drop-in operators: per-sample weights, one grouped
+        convolution with groups = batch."""
+        from ..op import conv2d_gradfix
+        n, cin, h, w = input.shape
+        k, cout = self.kernel_size, self.out_channel
+        weight = (self.scale * self.weight) * self.modulation(style).view(n, 1, cin, 1, 1)
+        if self.demodulate:
+            demod = torch.rsqrt(weight.pow(2).sum([2, 3, 4]) + self.eps)
+            weight = weight * demod.view(n, cout, 1, 1, 1)
+        if self.upsample:
+            per_sample = weight.transpose(1, 2).reshape(n * cin, cout, k, k)
+            out = conv2d_gradfix.conv_transpose2d(input.reshape(1, n * cin, h, w), per_sample, padding=0, stride=2,
+                                                  groups=n)
+            return self.blur(out.view(n, cout, out.shape[-2], out.shape[-1]))
+        out = conv2d_gradfix.conv2d(input.reshape(1, n * cin, h, w), weight.view(n * cout, cin, k, k),
+                                    padding=self.padding, groups=n)
+        return out.view(n, cout, out.shape[-2], out.shape[-1])
+
     def forward(self, input, style, act=None, pre=None, bias=None):
         """act = (noise, noise_weight, bias, negative_slope, scale): fuse StyledConv's NoiseInjection +
         FusedLeakyReLU into the convolution (callers check `can_fuse_act` first).  pre = (style vector, demodulation)
         already computed for this layer (Generator's style bank); bias: frozen per-channel bias for the epilogue."""
+        if MODCONV_FORM == 'grouped':
+            if act is not None or pre is not None or bias is not None:
+                raise RuntimeError('grouped (reference-form) modulated convolution: the fused paths do not apply')
+            return self.forward_grouped(input, style)
         wmat_fwd, wmat_bwd, wsq = self._weights()
         if pre is not None:
             style, demod = pre
@@ -227,7 +275,8 @@ class ModulatedConv2d(nn.Module):
     def can_fuse_act(self, input, style, *frozen):
         """The one-kernel StyledConv applies to 3x3 layers without upsampling when neither the style (i.e. the
         latent and the modulation layer) nor the activation parameters need a gradient."""
-        if self.kernel_size != 3 or input.dtype != torch.float32 or 'fuse_act' in conv_mfma.DISABLED:
+        if (self.kernel_size != 3 or input.dtype != torch.float32 or 'fuse_act' in conv_mfma.DISABLED
+                or MODCONV_FORM == 'grouped'):
             return False
         if self.upsample:
             h, w = 2 * input.shape[-2] + 1, 2 * input.shape[-1] + 1           # transposed-conv output
@@ -287,7 +336,7 @@ class StyledConv(nn.Module):
                                                 self.activate.negative_slope, self.activate.scale), pre=pre)
         out = self.conv(input, style, pre=pre)
         n, _, h, w = out.shape
-        if out.dtype == torch.float32 and (h * w) % 4 == 0:
+        if out.dtype == torch.float32 and (h * w) % 4 == 0 and MODCONV_FORM != 'grouped':
             # NoiseInjection + FusedLeakyReLU in one pass over the activation (csrc/fused_bias_act.hip)
             if noise is None:
                 noise = out.new_empty(n, 1, h, w).normal_()
@@ -304,7 +353,8 @@ def styled_conv_with_rgb(styled, to_rgb, input, style, rgb_latent, noise=None, p
     (conv_mfma._StyledConvToRGB); returns (activation, raw rgb) or None when the pair cannot be fused (a style that
     needs a gradient, trainable generator weights, shapes off the fused path)."""
     conv, rgb_conv = styled.conv, to_rgb.conv
-    if 'torgb_fuse' in conv_mfma.DISABLED or not torch.is_grad_enabled() or not input.requires_grad:
+    if ('torgb_fuse' in conv_mfma.DISABLED or not torch.is_grad_enabled() or not input.requires_grad
+            or MODCONV_FORM == 'grouped'):
         return None
     if not conv.can_fuse_act(input, style, styled.noise.weight, styled.activate.bias) or conv.upsample:
         return None
@@ -337,7 +387,8 @@ class ToRGB(nn.Module):
     def epilogue_bias(self):
         """The bias as a (3,) vector for the 1x1 convolution's epilogue, or None when it needs a gradient (then
         finish() adds it as the reference does) or the fusion is switched off."""
-        if 'torgb_bias' in conv_mfma.DISABLED or (self.bias.requires_grad and torch.is_grad_enabled()):
+        if ('torgb_bias' in conv_mfma.DISABLED or (self.bias.requires_grad and torch.is_grad_enabled())
+                or MODCONV_FORM == 'grouped'):
             return None
         return self.bias.detach().reshape(-1)
 
@@ -351,7 +402,8 @@ class ToRGB(nn.Module):
         out = rgb if bias_done else rgb + self.bias.type(rgb.dtype)
         if skip is not None:
             up = self.upsample
-            if out.dtype == torch.float32 and skip.dtype == torch.float32 and 'torgb_bias' not in conv_mfma.DISABLED:
+            if (out.dtype == torch.float32 and skip.dtype == torch.float32 and 'torgb_bias' not in conv_mfma.DISABLED
+                    and MODCONV_FORM != 'grouped'):
                 out = upfirdn2d_add(skip, up.kernel, out, up=up.factor, down=1, pad=up.pad)
             else:
                 out = out.float() + up(skip)
@@ -518,7 +570,7 @@ class Generator(nn.Module):
         """Modulation + demodulation vectors of every layer whose W+ slot needs no gradient (slot >= first_free), in
         two launches (conv_mfma.StyleBank) instead of two per layer.  {} when the bank does not apply."""
         if ('style_bank' in conv_mfma.DISABLED or 'style_demod' in conv_mfma.DISABLED or latent.dtype != torch.float32
-                or not latent.is_cuda or latent.dim() != 3 or first_free >= self.n_latent):
+                or not latent.is_cuda or latent.dim() != 3 or first_free >= self.n_latent or MODCONV_FORM == 'grouped'):
             return {}
         layers = [(m, slot) for m, slot in self._layer_slots() if slot >= first_free]
         frozen = all(not (m.modulation.weight.requires_grad or m.weight.requires_grad or
