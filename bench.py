@@ -24,10 +24,23 @@ WORKLOADS = {
     # BASELINE.json configs[1]: LSUN Cats 256x256, similarity+flow STN (flow_size=128), batch 16 per GPU
     'c2': dict(gen_size=256, flow_size=128, batch=16, transform=('similarity', 'flow'), num_heads=1, flips=False,
                inject=5, ndirs=1, padding_mode='reflection', sample_from_full_res=False),
+    # configs[3]: CelebA-HQ 512x512 flags (scripts/training/celeba.sh:4-6): BilinearDownsample(4) to the 128^2 STN,
+    # border padding, full-resolution sampling source, inject 6, ndirs 512 (high-res upfirdn2d stress); per-GPU batch 4
+    'c4': dict(gen_size=512, flow_size=128, batch=4, transform=('similarity', 'flow'), num_heads=1, flips=False,
+               inject=6, ndirs=512, padding_mode='border', sample_from_full_res=True, tv_weight=2500.0),
+    # configs[4]: LSUN Cars clustering (scripts/training/lsun_cars.sh:4-7): K = 4 heads with flips (the STN and the
+    # perceptual loss see 8x the batch), full-resolution sampling, inject 6, ndirs 5; per-GPU batch 4
+    'c5': dict(gen_size=256, flow_size=128, batch=4, transform=('similarity', 'flow'), num_heads=4, flips=True,
+               inject=6, ndirs=5, padding_mode='reflection', sample_from_full_res=True, tv_weight=2500.0),
     # configs[0]: plumbing (64x64, similarity only)
     'c1': dict(gen_size=64, flow_size=64, batch=4, transform=('similarity',), num_heads=1, flips=False, inject=5,
                ndirs=1, padding_mode='reflection', sample_from_full_res=False, tv_weight=0.0, flow_identity_weight=0.0),
 }
+
+METRIC = {'c2': 'train-step images/sec, LSUN-Cats 256^2 STN+StyleGAN2',
+          'c1': 'train-step images/sec, LSUN-Cats 64^2 similarity STN+StyleGAN2 (plumbing configuration)',
+          'c4': 'train-step images/sec, CelebA-HQ 512^2 STN+StyleGAN2 (BASELINE configs[3] flags)',
+          'c5': 'train-step images/sec, LSUN-Cars 256^2 K=4 clustering STN+StyleGAN2 (BASELINE configs[4] flags)'}
 
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks
 MFMA_PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0, 'bf16x6': 2500.0}
@@ -45,17 +58,32 @@ KERNEL_NAME = {
 MFMA_PRODUCTS = {'fp32': 1, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}
 
 
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the convolution kernel source and the shared headers: identifies the code a
+    profile was taken with."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ('gangealing_amd/csrc/conv_mfma.hip', 'gangealing_amd/csrc/gg_common.h', 'include/gangealing_hip.h'):
+        with open(os.path.join(REPO, rel), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(precision, workload, batch):
     """HBM bytes per launch of the dominant kernel, measured offline with rocprofv3 --pmc on this same command
-    (scripts/final_measure.sh) and committed under profiles/; None for configurations that were not profiled."""
+    (scripts/measure_r03.sh) and committed under profiles/.  None for configurations that were not profiled AND
+    whenever the recorded kernel-source hash differs from the tree's (a profile of another version of the kernel says
+    nothing about this one)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             with open(os.path.join(here, 'profiles', name)) as f:
                 rec = json.load(f)
         except (OSError, ValueError):
             continue
         if (rec.get('precision'), rec.get('workload'), rec.get('batch')) == (precision, workload, batch):
+            if rec.get('kernel_source_sha16') != kernel_source_hash():
+                return None
             return rec.get('hbm_bytes_per_launch')
     return None
 
@@ -203,21 +231,42 @@ def _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile)
     prof = conv_mfma.LaunchProfiler()
     if profile and not graphed:
         conv_mfma.PROFILER = prof        # HIP events around the dominant kernel's launches inside the timed region
+    if world > 1:
+        trainer.comm_events = []
     t0 = time.perf_counter()
     for _ in range(steps):
         parts = trainer.step(psi=0.5)
     trainer.flush()                      # a deferred (pipelined) optimizer step belongs to the timed region
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0       # this rank's own time, before waiting for the others
     barrier()
     elapsed = time.perf_counter() - t0
     conv_mfma.PROFILER = None
+    dist_info = None
     if world > 1:
+        import torch.distributed as dist
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what the collective library itself saw: an all-reduce of ones counts the ranks that took part
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        per_rank = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([own], device=device, dtype=torch.float64))
+        exposed = [a.elapsed_time(b) for a, b in trainer.comm_events]
+        ex = torch.tensor([sum(exposed) / max(len(exposed), 1)], device=device, dtype=torch.float64)
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        ms = [1e3 * float(v.item()) / steps for v in per_rank]
+        dist_info = dict(backend=dist.get_backend(), world_size=dist.get_world_size(),
+                         ranks_counted_by_all_reduce=int(round(float(ones.item()))),
+                         ms_per_step_rank_min=round(min(ms), 3), ms_per_step_rank_max=round(max(ms), 3),
+                         allreduce_exposed_ms_per_step_max_rank=round(float(ex.item()), 4),
+                         allreduce_bytes=int(trainer.stn_arena.numel * 4), pipelined_update=bool(trainer.pipeline_update),
+                         devices=sorted({torch.cuda.current_device()}))
     loss = float(parts['p'])
     assert loss == loss and abs(loss) != float('inf'), 'non-finite loss'
     res = dict(elapsed=elapsed, loss=loss, graphed=graphed, prof=prof.summary() if (profile and not graphed) else None,
-               images=world * wl['batch'] * steps)
+               images=world * wl['batch'] * steps, dist=dist_info)
     del trainer
     torch.cuda.empty_cache()
     return res
@@ -268,7 +317,7 @@ def main():
         psum = main_run['prof']
         elapsed = main_run['elapsed']
         out = {
-            'metric': 'train-step images/sec, LSUN-Cats 256^2 STN+StyleGAN2',
+            'metric': METRIC.get(args.workload, METRIC['c2']),
             'value': round(main_run['images'] / elapsed, 3),
             'unit': 'images/sec',
             'n_gpus': world,
@@ -287,6 +336,8 @@ def main():
                        'launch': 'hipGraph replay of the whole iteration' if main_run['graphed'] else 'eager launches',
                        'loss': main_run['loss']},
         }
+        if main_run.get('dist'):
+            out['distributed'] = main_run['dist']
         if psum is not None:
             achieved = psum['total_flops'] / (psum['total_ms'] * 1e-3) / 1e12 if psum['total_ms'] > 0 else 0.0
             peak = MFMA_PEAK_TFLOPS[args.precision]

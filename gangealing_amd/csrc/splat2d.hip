@@ -6,10 +6,14 @@
 //   accumulated with atomics; the host glue then divides by (alpha [clamped >= 1] + 1e-8).
 //
 // MI355X mapping: the reference runs one THREAD per point (32-thread blocks, a serial loop over
-// the ~7x7 footprint).  Here one 64-lane WAVE owns a point at a time and the lanes fan out over
+// the ~7x7 footprint).  Here a 16-lane quarter of a 64-lane wave owns a point and its lanes fan out over
 // the footprint pixels, so a footprint row becomes a run of consecutive addresses for the L2
-// atomic units (global_atomic_add_f32 via unsafeAtomicAdd - no CAS loop), and point parameters
-// are wave-uniform (scalar loads).
+// atomic units (global_atomic_add_f32 via unsafeAtomicAdd - no CAS loop).  Sixteen lanes suit both
+// ends of the range the applications use: sigma = 0.3 touches <= 3x3 pixels (one pass, 9 of 16 lanes;
+// a whole wave per point would idle 55 of 64), sigma = 1.3 touches 7x7 (four passes, 49 of 64 lane slots).
+// The accumulation order of overlapping points is the arrival order of the atomics: results vary in
+// the last bits from run to run, exactly as the reference kernel's do (inference-side operator; not on
+// the training path).
 #include "../../include/gangealing_hip.h"
 #include "gg_common.h"
 
@@ -19,12 +23,13 @@ __global__ __launch_bounds__(256) void splat_forward_kernel(
     const float* __restrict__ coords, const float* __restrict__ values, const float* __restrict__ sigma,
     float* __restrict__ alpha_splats, float* __restrict__ output, int num_points, int channels, int height,
     int width, int top_count) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  constexpr int G = 16;                                   // lanes per point
+  const int sub = threadIdx.x & (G - 1);
+  const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const long long ngroups = ((long long)gridDim.x * blockDim.x) / G;
   const size_t hw = (size_t)height * width;
-  for (int index = wave; index < top_count; index += nwaves) {
-    const int n = index / num_points;
+  for (long long index = group; index < top_count; index += ngroups) {
+    const int n = (int)(index / num_points);
     const float xc = coords[2 * (size_t)index];
     const float yc = coords[2 * (size_t)index + 1];
     const float stdev = sigma[n];
@@ -41,7 +46,7 @@ __global__ __launch_bounds__(256) void splat_forward_kernel(
     const float* val = values + (size_t)index * channels;
     float* a_img = alpha_splats + (size_t)n * hw;
     float* o_img = output + (size_t)n * channels * hw;
-    for (int p = lane; p < area; p += 64) {
+    for (int p = sub; p < area; p += G) {
       const int dy = p / bw, dx = p - dy * bw;
       const int lh = t + dy, lw = l + dx;
       const float fx = (float)lw - xc, fy = (float)lh - yc;
@@ -74,7 +79,7 @@ extern "C" int gg_splat_forward_f32(const float* coords, const float* values, co
   if (top_count <= 0) return 0;
   if (!coords || !values || !sigma || !alpha_splats || !output || num_points <= 0)
     return gg::fail(-2, "splat_forward: bad arguments");
-  const long long threads = (long long)top_count * 64;
+  const long long threads = (long long)top_count * 16;
   splat_forward_kernel<<<gg::stream_grid(threads, 256), 256, 0, gg::as_stream(stream)>>>(
       coords, values, sigma, alpha_splats, output, num_points, channels, height, width, top_count);
   return gg::launch_status("splat_forward");

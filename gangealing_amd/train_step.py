@@ -173,6 +173,10 @@ class GangealingTrainer:
         FileNotFoundError instead of silently optimising a meaningless objective."""
         self.device = device
         self._pending = None
+        # optional timing of the gradient exchange (bench.py --gpus N): list of (event before, event after) pairs
+        # recorded on the compute stream around the point where it waits for the collective - the time the all-reduce
+        # is EXPOSED to the step (zero when it finished behind the next iteration's generator passes)
+        self.comm_events = None
         self.batch = batch
         self.dim_latent = dim_latent
         self.num_heads = num_heads
@@ -325,7 +329,10 @@ class GangealingTrainer:
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.ll_arena.grad, op=dist.ReduceOp.SUM)
+            ev = self._comm_mark() if not self.pipeline_update else None
             work = dist.all_reduce(self.stn_arena.grad, op=dist.ReduceOp.SUM, async_op=self.pipeline_update)
+            if ev is not None:
+                self._comm_mark(ev)
         else:
             work = None
         stn_lr = self.stn_lr if stn_lr is None else stn_lr
@@ -407,13 +414,24 @@ class GangealingTrainer:
         adam_ema_step(self.stn_arena, lr, self.ema_arena, self.ema_decay, grad_scale=scale)
         conv_mfma.repack_trainable()         # all STN weight packs (forward + data-gradient layouts) in one launch
 
+    def _comm_mark(self, start=None):
+        if self.comm_events is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if start is not None:
+            self.comm_events.append((start, ev))
+        return ev
+
     def flush(self):
         """Apply a deferred STN update (no-op when nothing is pending)."""
         if self._pending is not None:
             work, scale, lr = self._pending
             self._pending = None
             if work is not None:
+                ev = self._comm_mark()
                 work.wait()                      # the compute stream waits for the collective; the host does not
+                self._comm_mark(ev)
             self._apply_stn_update(scale, lr)
             self.stn_arena.zero_grad()
 
