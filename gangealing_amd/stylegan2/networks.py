@@ -437,6 +437,16 @@ class ConvLayer(nn.Sequential):
             conv, act = self[0], self[1]
             return conv_mfma.conv3x3_bias_act(input, conv.weight, act.bias, act.negative_slope, act.scale,
                                               weight_scale=conv.scale)
+        # Blur followed by a 1x1 / stride-2 convolution (ResBlock.skip, networks.py:383-386): the convolution reads only
+        # every second blurred pixel, so the blur is evaluated at those positions only (upfirdn2d with down = 2: the
+        # same taps on the same inputs, a quarter of the outputs and of the intermediate tensor) and the 1x1
+        # convolution becomes a dense stride-1 one
+        if (len(self) == 2 and isinstance(self[0], Blur) and isinstance(self[1], EqualConv2d) and
+                self[1].weight.shape[-1] == 1 and self[1].stride == 2 and self[1].padding == 0 and
+                input.dtype == torch.float32 and input.is_cuda and 'skip_down' not in conv_mfma.DISABLED):
+            blur, conv = self[0], self[1]
+            x = upfirdn2d(input, blur.kernel, up=1, down=2, pad=blur.pad)
+            return conv_mfma.conv2d(x, conv.weight, bias=conv.bias, stride=1, padding=0, weight_scale=conv.scale)
         return super().forward(input)
 
 
