@@ -23,6 +23,7 @@ _PROTOS = {
     'gg_fused_bias_act_f16': 'ppppiiffqqis',
     'gg_fused_lrelu_bwd_f32': 'ppppffiiqs',
     'gg_fused_lrelu_bwd_f64': 'ppppddiiqs',
+    'gg_fused_lrelu_bwd_acc_f32': 'ppppffiiqis',
     'gg_fused_lrelu_bwd_f16': 'ppppffiiqs',
     'gg_noise_bias_act_f32': 'pppppffiiqs',
     'gg_upfirdn2d_f32': 'pppiiiiiiiiiiiiis',
@@ -65,6 +66,7 @@ _PROTOS = {
     'gg_maxpool2x2_bwd_f32': 'pppqiis',
     'gg_torgb_dgrad_add_f32': 'ppppfiiqs',
     'gg_plane_dot_f32': 'pppiqs',
+    'gg_modconv_style_grad_f32': 'ppppppiiis',
     'gg_adam_ema_f32': 'pppppqffffiffs',
     'gg_adam_ema_dev_f32': 'pppppqpffffs',
     'gg_upfirdn2d_add_f32': 'ppppiiiiiiiiiiiiis',

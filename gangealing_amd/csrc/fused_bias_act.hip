@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void fused_bias_act_kernel(
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void fused_lrelu_bwd_kernel(
     T* __restrict__ gin, T* __restrict__ gbias, const T* __restrict__ gout, const T* __restrict__ outv,
-    T alpha, T scale, int n, int c, long long hw, long long chunk, T* part, unsigned* ticket) {
+    T alpha, T scale, int n, int c, long long hw, long long chunk, T* part, unsigned* ticket, int accumulate) {
   __shared__ T red[4];
   const int ch = blockIdx.y;
   const long long lo = (long long)blockIdx.x * chunk;
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void fused_lrelu_bwd_kernel(
   }
   if (gbias) {
     T v[1] = {gg::block_sum_256<T>(acc, red)};
-    if (gg::ordered_grid_sum<T, 1>(v, part, ticket, ch, blockIdx.x, gridDim.x, red)) gbias[ch] = v[0];
+    if (gg::ordered_grid_sum<T, 1>(v, part, ticket, ch, blockIdx.x, gridDim.x, red))
+      gbias[ch] = (accumulate ? gbias[ch] : T(0)) + v[0];
   }
 }
 
@@ -193,7 +194,7 @@ int fused_bias_act_impl(T* out, const T* x, const T* bias, const T* ref, int act
 
 template <typename T>
 int fused_lrelu_bwd_impl(T* gin, T* gbias, const T* gout, const T* outv, T alpha, T scale, int n, int c,
-                         long long hw, void* stream) {
+                         long long hw, void* stream, int accumulate = 0) {
   if (n <= 0 || c <= 0 || hw <= 0) return 0;
   if (!gin || !gout || !outv) return gg::fail(-2, "fused_lrelu_bwd: null pointer");
   if (c > 65535) return gg::fail(-2, "fused_lrelu_bwd: more than 65535 channels");
@@ -219,9 +220,11 @@ int fused_lrelu_bwd_impl(T* gin, T* gbias, const T* gout, const T* outv, T alpha
   }
   dim3 grid((unsigned)splits, (unsigned)c);
   if (vec)
-    fused_lrelu_bwd_kernel<T, 4><<<grid, 256, 0, st>>>(gin, gbias, gout, outv, alpha, scale, n, c, hw, chunk, part, ticket);
+    fused_lrelu_bwd_kernel<T, 4><<<grid, 256, 0, st>>>(gin, gbias, gout, outv, alpha, scale, n, c, hw, chunk, part, ticket,
+                                                       accumulate);
   else
-    fused_lrelu_bwd_kernel<T, 1><<<grid, 256, 0, st>>>(gin, gbias, gout, outv, alpha, scale, n, c, hw, chunk, part, ticket);
+    fused_lrelu_bwd_kernel<T, 1><<<grid, 256, 0, st>>>(gin, gbias, gout, outv, alpha, scale, n, c, hw, chunk, part, ticket,
+                                                       accumulate);
   return gg::launch_status("fused_lrelu_bwd");
 }
 
@@ -302,6 +305,11 @@ extern "C" int gg_noise_bias_act_f32(float* out, const float* x, const float* no
 extern "C" int gg_fused_lrelu_bwd_f32(float* grad_in, float* grad_bias, const float* grad_out, const float* out,
                                       float alpha, float scale, int n, int c, long long hw, void* stream) {
   return fused_lrelu_bwd_impl<float>(grad_in, grad_bias, grad_out, out, alpha, scale, n, c, hw, stream);
+}
+extern "C" int gg_fused_lrelu_bwd_acc_f32(float* grad_in, float* grad_bias, const float* grad_out, const float* out,
+                                          float alpha, float scale, int n, int c, long long hw, int accumulate,
+                                          void* stream) {
+  return fused_lrelu_bwd_impl<float>(grad_in, grad_bias, grad_out, out, alpha, scale, n, c, hw, stream, accumulate);
 }
 extern "C" int gg_fused_lrelu_bwd_f64(double* grad_in, double* grad_bias, const double* grad_out, const double* out,
                                       double alpha, double scale, int n, int c, long long hw, void* stream) {

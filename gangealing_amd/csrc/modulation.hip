@@ -241,6 +241,41 @@ extern "C" int gg_style_bank_f32(float* out_base, const float* latent, long long
   return gg::launch_status("style_bank (demodulation)");
 }
 
+namespace {
+// dstyle[n, ci] = dot_x[n, ci] + 2 style[n, ci] * sum_co t[n, co] * wsq[co, ci],  t = -0.5 * dot_y * demod^2
+// (the style gradient of the shared-weight modulated convolution: dot_x = <d(style-scaled input), x> per plane, and
+//  the demodulation branch d demod / d style = -demod^3 * style * wsq).  grid = (ceil(cin / 256), n)
+constexpr int STYLE_GRAD_MAX_COUT = 1024;
+__global__ __launch_bounds__(256) void style_grad_kernel(float* __restrict__ dstyle, const float* __restrict__ dot_x,
+                                                         const float* __restrict__ dot_y,
+                                                         const float* __restrict__ demod,
+                                                         const float* __restrict__ style,
+                                                         const float* __restrict__ wsq, int cin, int cout) {
+  __shared__ float t[STYLE_GRAD_MAX_COUT];
+  const int n = blockIdx.y, ci = blockIdx.x * 256 + threadIdx.x;
+  for (int co = threadIdx.x; co < cout; co += 256) {
+    const float d = demod[(size_t)n * cout + co];
+    t[co] = -0.5f * dot_y[(size_t)n * cout + co] * d * d;
+  }
+  __syncthreads();
+  if (ci >= cin) return;
+  float acc = 0.f;
+  for (int co = 0; co < cout; ++co) acc += t[co] * wsq[(size_t)co * cin + ci];
+  dstyle[(size_t)n * cin + ci] = dot_x[(size_t)n * cin + ci] + 2.f * style[(size_t)n * cin + ci] * acc;
+}
+}  // namespace
+
+extern "C" int gg_modconv_style_grad_f32(float* dstyle, const float* dot_x, const float* dot_y, const float* demod,
+                                         const float* style, const float* wsq, int n, int cin, int cout,
+                                         void* stream) {
+  if (n <= 0 || cin <= 0) return 0;
+  if (!dstyle || !dot_x || !dot_y || !demod || !style || !wsq || cout <= 0 || cout > STYLE_GRAD_MAX_COUT || n > 65535)
+    return gg::fail(-2, "modconv_style_grad: bad arguments (cout <= %d)", STYLE_GRAD_MAX_COUT);
+  style_grad_kernel<<<dim3((unsigned)((cin + 255) / 256), (unsigned)n), 256, 0, gg::as_stream(stream)>>>(
+      dstyle, dot_x, dot_y, demod, style, wsq, cin, cout);
+  return gg::launch_status("modconv_style_grad");
+}
+
 extern "C" int gg_style_demod_f32(float* style, float* demod, const float* latent, long long lat_stride,
                                   const float* w, const float* b, const float* wsq, int n, int style_dim, int cin,
                                   int cout, float w_scale, float b_scale, float eps, void* stream) {

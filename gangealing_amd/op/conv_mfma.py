@@ -460,6 +460,7 @@ class _Conv3x3BiasAct(Function):
                          act=(None, None, None if bias is None else bias.contiguous(), alpha, gain))
         ctx.save_for_backward(x, weight, y)
         ctx.conf = (alpha, gain, wscale, bias is not None)
+        ctx.bias_ref = bias          # (the parameter itself: looked up in the gradient-slot registry in backward)
         return y
 
     @staticmethod
@@ -494,8 +495,13 @@ class _Conv3x3BiasAct(Function):
                 if rc == 0:
                     return dx, (None if slot is not None else dw), db, None, None, None
         g = torch.empty_like(dy)
-        db = torch.empty(cout, dtype=torch.float32, device=dy.device) if need_db else None
-        _lib.call('gg_fused_lrelu_bwd_f32', g, db, dy, y, alpha, gain, n, cout, h * w)
+        bslot = _slot_for(ctx.bias_ref) if (need_db and ctx.bias_ref is not None) else None
+        if bslot is not None:      # the bias gradient is added straight into its arena slot (no temporary, no add)
+            _lib.call('gg_fused_lrelu_bwd_acc_f32', g, bslot, dy, y, alpha, gain, n, cout, h * w, 1)
+            db = None
+        else:
+            db = torch.empty(cout, dtype=torch.float32, device=dy.device) if need_db else None
+            _lib.call('gg_fused_lrelu_bwd_f32', g, db, dy, y, alpha, gain, n, cout, h * w)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             wm = packed(weight, 1, cin, cout, 3, 1, 1, wscale)
@@ -598,9 +604,17 @@ class _ModulatedConv(Function):
             if need_style:
                 dstyle = plane_dot(dxt, x)
                 if demodulate:
-                    ddemod = plane_dot(dy, y) / demod                       # d loss / d demod
-                    dsq = ddemod * (-0.5) * demod * demod * demod           # through rsqrt
-                    dstyle = dstyle + 2.0 * style * (dsq @ wsq)
+                    # + the demodulation branch: d demod / d style = -demod^3 * style * wsq, with d loss / d demod =
+                    # <dy, y> / demod - one launch (csrc/modulation.hip) instead of nine tiny torch kernels per layer
+                    dot_y = plane_dot(dy, y)
+                    if 'style_grad' in DISABLED or cout > 1024:
+                        dsq = (dot_y / demod) * (-0.5) * demod * demod * demod
+                        dstyle = dstyle + 2.0 * style * (dsq @ wsq)
+                    else:
+                        dot_x = dstyle
+                        dstyle = torch.empty_like(dot_x)
+                        _lib.call('gg_modconv_style_grad_f32', dstyle, dot_x, dot_y, demod.contiguous(), style,
+                                  wsq.contiguous(), n, cin, cout)
                 dx = dxt * style.view(n, cin, 1, 1) if ctx.needs_input_grad[0] else None
             else:
                 dx = dxt

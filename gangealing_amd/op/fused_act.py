@@ -62,6 +62,7 @@ class FusedLeakyReLUFunction(Function):
         ctx.save_for_backward(out)
         ctx.negative_slope = negative_slope
         ctx.scale = scale
+        ctx.bias_ref = bias          # the parameter itself: looked up in the gradient-slot registry in backward
         return out
 
     @staticmethod
@@ -75,6 +76,18 @@ class FusedLeakyReLUFunction(Function):
             _lib.call('gg_fused_lrelu_bwd_' + _SUFFIX[out.dtype], grad_input, None, grad_output, out,
                       ctx.negative_slope, ctx.scale, n, c, out.numel() // max(n * c, 1))
             return grad_input, None, None, None
+        if ctx.needs_input_grad[1] and not torch.is_grad_enabled() and out.dtype == torch.float32:
+            # inside the trainer's backward (conv_mfma.grad_slots): the bias gradient is added straight into the
+            # parameter's slot of the flat gradient arena - no temporary and no AccumulateGrad add
+            from . import conv_mfma
+            slot = conv_mfma._slot_for(ctx.bias_ref) if ctx.bias_ref is not None else None
+            if slot is not None:
+                grad_output = grad_output.contiguous()
+                n, c = out.shape[0], out.shape[1]
+                grad_input = torch.empty_like(grad_output)
+                _lib.call('gg_fused_lrelu_bwd_acc_f32', grad_input, slot, grad_output, out, ctx.negative_slope,
+                          ctx.scale, n, c, out.numel() // max(n * c, 1), 1)
+                return grad_input, None, None, None
         grad_input, grad_bias = FusedLeakyReLUFunctionBackward.apply(grad_output, out, ctx.negative_slope, ctx.scale)
         return grad_input, grad_bias, None, None
 

@@ -45,8 +45,9 @@ class FlatArena:
                 self.param[off:off + n].copy_(p.reshape(-1))
                 p.data = self.param[off:off + n].view(p.shape)
                 p.grad = self.grad[off:off + n].view(p.shape)
-                if p.dim() == 4 and p.requires_grad:
-                    # trainable conv weights: inside `with conv_mfma.grad_slots():` the backward adds straight into the arena
+                if p.dim() in (1, 4) and p.requires_grad:
+                    # trainable conv weights and activation biases: inside `with conv_mfma.grad_slots():` the backward
+                    # adds straight into the arena
                     conv_mfma.register_grad_slot(p, p.grad)
                 off += n
         self.params = params
@@ -73,7 +74,7 @@ class FlatArena:
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + n].view(p.shape)
-                if p.dim() == 4 and p.requires_grad:
+                if p.dim() in (1, 4) and p.requires_grad:
                     conv_mfma.register_grad_slot(p, p.grad)
             off += n
 

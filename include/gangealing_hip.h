@@ -69,6 +69,9 @@ int gg_fused_bias_act_f16(unsigned short* out, const unsigned short* x, const un
  * overwritten.  grad_bias may be NULL to skip the reduction. */
 int gg_fused_lrelu_bwd_f32(float* grad_in, float* grad_bias, const float* grad_out, const float* out,
                            float alpha, float scale, int n, int c, long long hw, void* stream);
+/* as gg_fused_lrelu_bwd_f32; accumulate != 0: grad_bias[c] += the sum (gradient arenas: no temporary, no extra add) */
+int gg_fused_lrelu_bwd_acc_f32(float* grad_in, float* grad_bias, const float* grad_out, const float* out,
+                               float alpha, float scale, int n, int c, long long hw, int accumulate, void* stream);
 int gg_fused_lrelu_bwd_f64(double* grad_in, double* grad_bias, const double* grad_out, const double* out,
                            double alpha, double scale, int n, int c, long long hw, void* stream);
 /* binary16 tensors; grad_bias is an fp32 buffer of c entries (sum of the ROUNDED grad_in values, as the
@@ -372,6 +375,12 @@ int gg_maxpool2x2_bwd_f32(float* dx, const float* dy, const unsigned char* code,
  * the running sum and the ToRGB branch is added in one read-modify-write pass. */
 int gg_torgb_dgrad_add_f32(float* g, const float* grad_rgb, const float* w, const float* style, float wscale, int n,
                            int c, long long hw, void* stream);
+/* Style gradient of the shared-weight modulated convolution from its per-plane dot products, one launch:
+ *   dstyle[n,ci] = dot_x[n,ci] + 2 style[n,ci] * sum_co (-0.5 dot_y[n,co] demod[n,co]^2) wsq[co,ci]
+ * dot_x = <d(style-scaled input), input> (n, cin), dot_y = <d output, output> (n, cout); cout <= 1024.
+ * (the autograd of networks.py:243-249 w.r.t. `style`, which the reference obtains through the per-sample weights) */
+int gg_modconv_style_grad_f32(float* dstyle, const float* dot_x, const float* dot_y, const float* demod,
+                              const float* style, const float* wsq, int n, int cin, int cout, void* stream);
 /* Per-(n,c) dot products over the spatial plane: out[n*c] = sum_hw a*b (style / demod gradients). */
 int gg_plane_dot_f32(float* out, const float* a, const float* b, int planes, long long hw, void* stream);
 
