@@ -2585,6 +2585,98 @@ int launch_conv1x1_fewout(const ConvArgs& a, hipStream_t st) {
   return gg::launch_status("conv1x1_fewout");
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with <= 4 output channels: the data gradient of the perceptual trunk's RGB stem
+// (64 -> 3 @128^2 over 32 images: 0.40 ms on the 32-wide MFMA tile, whose other 29 output columns are padding) and the
+// flow head's last layer (512 -> 2).  A streaming VALU reduction like conv1x1_fewout_kernel: a lane owns 4 consecutive
+// pixels of one image row (W % 4 == 0), reads per input channel the three rows around them (one aligned float4 plus
+// the two neighbouring pixels each; rows / columns outside the image read as zero) and applies the 9 taps; the four
+// waves of a block split the input channels and meet in LDS.  HBM-bound: 4 * Cin bytes per pixel in.
+// wmat: [(ci, ky, kx)][co] (fp32 GEMM layout of pack_weight_kernel).
+// ------------------------------------------------------------------------------------------------
+template <int NCO>
+__global__ __launch_bounds__(256) void conv3x3_fewout_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                             const float* __restrict__ wmat,
+                                                             const float* __restrict__ in_scale,
+                                                             const float* __restrict__ out_scale,
+                                                             const float* __restrict__ bias, int cin, int h, int w) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];                     // cin * 9 * NCO style-scaled weights
+  __shared__ float4 red[4][NCO][64];
+  const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  const long long hw = (long long)h * w;
+  for (int i = tid; i < cin * 9 * NCO; i += 256) {
+    const int ci = i / (9 * NCO);
+    sw[i] = wmat[i] * (in_scale ? in_scale[(size_t)n * cin + ci] : 1.f);
+  }
+  __syncthreads();
+  const long long p = (long long)blockIdx.x * 256 + lane * 4;
+  const bool ok = p < hw;
+  float4 acc[NCO];
+#pragma unroll
+  for (int j = 0; j < NCO; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    const int py = (int)(p / w), px = (int)(p - (long long)py * w);
+    const int per = (cin + 3) / 4, k0 = g * per, k1 = (k0 + per < cin) ? k0 + per : cin;
+    const bool left = px > 0, right = px + 4 < w;
+    for (int k = k0; k < k1; ++k) {
+      const float* plane = x + ((size_t)n * cin + k) * hw;
+      const float* wk = sw + (size_t)k * 9 * NCO;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int yy = py + dy - 1;
+        if ((unsigned)yy >= (unsigned)h) continue;
+        const float* row = plane + (size_t)yy * w + px;
+        const float4 c = *reinterpret_cast<const float4*>(row);
+        const float l = left ? row[-1] : 0.f, r = right ? row[4] : 0.f;
+        const float v[6] = {l, c.x, c.y, c.z, c.w, r};
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+          for (int j = 0; j < NCO; ++j) {
+            const float wj = wk[(dy * 3 + dx) * NCO + j];
+            acc[j].x += v[dx] * wj; acc[j].y += v[dx + 1] * wj; acc[j].z += v[dx + 2] * wj; acc[j].w += v[dx + 3] * wj;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NCO; ++j) red[g][j][lane] = acc[j];
+  __syncthreads();
+  if (g < NCO && ok) {                                      // wave j finishes output channel j
+    const int j = g;
+    float4 r = red[0][j][lane];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      const float4 t = red[q][j][lane];
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    const float sc = out_scale ? out_scale[(size_t)n * NCO + j] : 1.f, bi = bias ? bias[j] : 0.f;
+    r.x = r.x * sc + bi; r.y = r.y * sc + bi; r.z = r.z * sc + bi; r.w = r.w * sc + bi;
+    *reinterpret_cast<float4*>(y + ((size_t)n * NCO + j) * hw + p) = r;
+  }
+}
+
+bool fewout3_serves(const ConvArgs& a, int stride, int pad, int mode) {
+  static const bool off = getenv("GG_NO_FEWOUT") != nullptr;      // measurement switch
+  return !off && mode == 0 && stride == 1 && pad == 1 && a.groups == 1 && a.cout_g >= 1 && a.cout_g <= 4 && a.wmat &&
+         a.cin_g * 9 * a.cout_g <= 16384 && a.cin_g <= FEWOUT_MAX_CIN && a.w % 4 == 0 && !a.act && !a.mask_ref &&
+         a.batch <= 65535 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
+}
+
+int launch_conv3x3_fewout(const ConvArgs& a, hipStream_t st) {
+  const long long hw = (long long)a.h * a.w;
+  dim3 grid((unsigned)((hw + 255) / 256), (unsigned)a.batch);
+  const size_t smem = sizeof(float) * (size_t)a.cin_g * 9 * a.cout_g;
+  switch (a.cout_g) {
+    case 1: conv3x3_fewout_kernel<1><<<grid, 256, smem, st>>>(a.y, a.x, a.wmat, a.in_scale, a.out_scale, a.bias, a.cin_g, a.h, a.w); break;
+    case 2: conv3x3_fewout_kernel<2><<<grid, 256, smem, st>>>(a.y, a.x, a.wmat, a.in_scale, a.out_scale, a.bias, a.cin_g, a.h, a.w); break;
+    case 3: conv3x3_fewout_kernel<3><<<grid, 256, smem, st>>>(a.y, a.x, a.wmat, a.in_scale, a.out_scale, a.bias, a.cin_g, a.h, a.w); break;
+    default: conv3x3_fewout_kernel<4><<<grid, 256, smem, st>>>(a.y, a.x, a.wmat, a.in_scale, a.out_scale, a.bias, a.cin_g, a.h, a.w); break;
+  }
+  return gg::launch_status("conv3x3_fewout");
+}
+
 constexpr int kNotFused = GG_NOT_SERVED;      // masked-input request that no kernel serves: nothing was launched
 
 template <int KS>
@@ -2599,6 +2691,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     return kNotFused;
   }
   if (KS == 1 && limbs == 0 && fewout_serves(a, stride, pad, mode)) return launch_conv1x1_fewout(a, st);
+  if (KS == 3 && limbs == 0 && fewout3_serves(a, stride, pad, mode)) return launch_conv3x3_fewout(a, st);
   if (!a.act && limbs && KS == 3 && mode == 1 && pad <= 1 && a.w >= 4 && (a.w & (a.w - 1)) == 0 &&
       (long long)a.cin_g * a.h * a.w * 4 < (1LL << 31) && (long long)a.cout_g * a.oh * a.ow * 4 < (1LL << 31))
     return launch_convT_patch(a, limbs, pad, st);
