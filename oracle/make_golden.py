@@ -470,6 +470,69 @@ def gen_stn_inference():
     save('stn_inference', cases)
 
 
+def gen_applications():
+    """The per-batch body of the mixed-reality loop (applications/mixed_reality.py:147-218) run with the REFERENCE's
+    own functions on CPU: applications.determine_flips + STN.uncongeal_points + un-mirroring + crop offsets, and the
+    congealed frames, for (0) a composed STN without classifier on non-square frames ('unimodal': flips inferred by
+    forward_with_flip), (1) a K = 2 clustering STN with its classifier, one frame at a time ('predict_cluster').  The
+    splat overlay itself needs the GPU kernel and is pinned elsewhere (tests/golden/splat2d.npz, point_transfer.npz).
+    ('fixed_cluster' creates its tensors with device='cuda' in the reference and cannot run on the CPU.)"""
+    import types as _types
+    import applications as ref_app
+    from models.spatial_transformers.spatial_transformer import get_stn, SpatialTransformer
+    from models.cluster_classifier import ResnetClassifier
+    from prepare_data import nchw_center_crop
+    rules = (('warp_head.linear', 0.01), ('flow_out.2', 0.05), ('mask_out', 0.5))
+    cases = []
+    for ci, heads in enumerate((1, 2)):
+        args = _types.SimpleNamespace(transform=['similarity', 'flow'], flow_size=64, stn_channel_multiplier=0.5,
+                                      num_heads=heads, real_size=128, iters=1 if heads > 1 else 2,
+                                      padding_mode='border', no_flip_inference=False)
+        t = get_stn(args.transform, flow_size=64, supersize=128, channel_multiplier=0.5, num_heads=heads)
+        torch.nn.Module.load_state_dict(t, det_state_dict(t, rules), strict=False)
+        t.eval()
+        classifier = None
+        if heads > 1:
+            classifier = ResnetClassifier(64, channel_multiplier=0.5, num_heads=2 * heads, supersize=128)
+            torch.nn.Module.load_state_dict(classifier, det_state_dict(classifier, (('to_logits', 0.05),)), strict=False)
+            classifier.eval()
+        nframes = 3
+        frames = rnd(f'app.frames{ci}', (nframes, 3, 128, 160 if heads == 1 else 128), 0.5)
+        pts_px = [torch.from_numpy(np.abs(det_array(f'app.points{ci}.{k}', (1, 7, 2), 36.0)) + 12.0).clamp(0, 127)
+                  for k in range(heads)]
+        pts_norm = [SpatialTransformer.normalize(p, 128, 128) for p in pts_px]
+        out_pts, out_flip, out_cluster, out_cong = [], [], [], []
+        with torch.no_grad():
+            batches = [frames] if heads == 1 else [frames[i:i + 1] for i in range(nframes)]
+            for batch in batches:
+                n = batch.size(0)
+                original = batch
+                y0 = x0 = 0
+                if batch.size(2) != batch.size(3):
+                    batch, (y0, x0) = nchw_center_crop(batch)
+                flipped, flip_idx, policy, active = ref_app.determine_flips(args, t, classifier, batch, cluster=None,
+                                                                            return_cluster_assignments=True)
+                pin = pts_norm[active.item()] if heads > 1 else pts_norm[0].repeat(n, 1, 1)
+                prop = t.uncongeal_points(flipped, pin, normalize_input_points=False, warp_policy=policy,
+                                          padding_mode=args.padding_mode, iters=args.iters)
+                prop[:, :, 0] = torch.where(flip_idx.view(-1, 1), args.real_size - 1 - prop[:, :, 0], prop[:, :, 0])
+                prop[:, :, 0] += x0
+                prop[:, :, 1] += y0
+                if heads > 1:
+                    flipped, policy = classifier.run_flip_cartesian(batch)
+                cong = t(flipped, output_resolution=args.real_size, warp_policy=policy, unfold=heads > 1,
+                         padding_mode=args.padding_mode, iters=args.iters)
+                out_pts.append(prop)
+                out_flip.append(flip_idx.reshape(-1))
+                out_cluster.append(active.reshape(-1))
+                out_cong.append(cong if heads > 1 else cong.unsqueeze(1))
+        cases.append(dict(frames=frames, points_norm=torch.cat(pts_norm, 0), points=torch.cat(out_pts, 0),
+                          flip=torch.cat(out_flip, 0), clusters=torch.cat(out_cluster, 0), congealed=torch.cat(out_cong, 0),
+                          meta=dict(num_heads=heads, args={k: v for k, v in vars(args).items()},
+                                    stn_rules=[list(r) for r in rules])))
+    save('applications', cases)
+
+
 # ---------------------------------------------------------------------------------------------
 # integer by-products of the anti-aliased sampling ("bit-exact warp grid indices")
 
@@ -693,7 +756,7 @@ if __name__ == '__main__':
                 misc=gen_misc, modconv=gen_modconv, generator=gen_generator, stn=gen_stn,
                 train_step=gen_train_step, cluster_classifier=gen_cluster_classifier,
                 point_transfer=gen_point_transfer, warp_indices=gen_warp_indices, annealing=gen_annealing, stn_inference=gen_stn_inference,
-                half_ops=gen_half_ops)
+                half_ops=gen_half_ops, applications=gen_applications)
     for name, fn in gens.items():
         if only and name not in only:
             continue
