@@ -244,24 +244,39 @@ extern "C" int gg_style_bank_f32(float* out_base, const float* latent, long long
 namespace {
 // dstyle[n, ci] = dot_x[n, ci] + 2 style[n, ci] * sum_co t[n, co] * wsq[co, ci],  t = -0.5 * dot_y * demod^2
 // (the style gradient of the shared-weight modulated convolution: dot_x = <d(style-scaled input), x> per plane, and
-//  the demodulation branch d demod / d style = -demod^3 * style * wsq).  grid = (ceil(cin / 256), n)
+//  the demodulation branch d demod / d style = -demod^3 * style * wsq).
 constexpr int STYLE_GRAD_MAX_COUT = 1024;
+// block = 64 input channels x 4 waves; wave g sums the output channels co = g, g + 4, ... (eight independent partial sums
+// per lane so that the wsq loads - one L2 round trip each - overlap), the waves meet in LDS.  grid = (ceil(cin / 64), n)
 __global__ __launch_bounds__(256) void style_grad_kernel(float* __restrict__ dstyle, const float* __restrict__ dot_x,
                                                          const float* __restrict__ dot_y,
                                                          const float* __restrict__ demod,
                                                          const float* __restrict__ style,
                                                          const float* __restrict__ wsq, int cin, int cout) {
   __shared__ float t[STYLE_GRAD_MAX_COUT];
-  const int n = blockIdx.y, ci = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[4][64];
+  const int n = blockIdx.y, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int ci = blockIdx.x * 64 + lane;
   for (int co = threadIdx.x; co < cout; co += 256) {
     const float d = demod[(size_t)n * cout + co];
     t[co] = -0.5f * dot_y[(size_t)n * cout + co] * d * d;
   }
   __syncthreads();
-  if (ci >= cin) return;
-  float acc = 0.f;
-  for (int co = 0; co < cout; ++co) acc += t[co] * wsq[(size_t)co * cin + ci];
-  dstyle[(size_t)n * cin + ci] = dot_x[(size_t)n * cin + ci] + 2.f * style[(size_t)n * cin + ci] * acc;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (ci < cin) {
+    int co = g;
+    for (; co + 28 < cout; co += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += t[co + 4 * u] * wsq[(size_t)(co + 4 * u) * cin + ci];
+    }
+    for (; co < cout; co += 4) acc[0] += t[co] * wsq[(size_t)co * cin + ci];
+  }
+  red[g][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (g == 0 && ci < cin) {
+    const float sum = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    dstyle[(size_t)n * cin + ci] = dot_x[(size_t)n * cin + ci] + 2.f * style[(size_t)n * cin + ci] * sum;
+  }
 }
 }  // namespace
 
@@ -271,7 +286,7 @@ extern "C" int gg_modconv_style_grad_f32(float* dstyle, const float* dot_x, cons
   if (n <= 0 || cin <= 0) return 0;
   if (!dstyle || !dot_x || !dot_y || !demod || !style || !wsq || cout <= 0 || cout > STYLE_GRAD_MAX_COUT || n > 65535)
     return gg::fail(-2, "modconv_style_grad: bad arguments (cout <= %d)", STYLE_GRAD_MAX_COUT);
-  style_grad_kernel<<<dim3((unsigned)((cin + 255) / 256), (unsigned)n), 256, 0, gg::as_stream(stream)>>>(
+  style_grad_kernel<<<dim3((unsigned)((cin + 63) / 64), (unsigned)n), 256, 0, gg::as_stream(stream)>>>(
       dstyle, dot_x, dot_y, demod, style, wsq, cin, cout);
   return gg::launch_status("modconv_style_grad");
 }
