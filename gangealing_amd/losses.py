@@ -167,6 +167,9 @@ class _LpipsTap(torch.autograd.Function):
         _lib.call('gg_lpips_tail_fwd_f32', out, feats, lin, n2 // 2, c, h * w, eps)
         ctx.save_for_backward(feats, lin if lin is not None else feats.new_empty(0))
         ctx.eps = eps
+        # the last tap's features feed nothing else: without this autograd would hand backward() a full-size zero
+        # tensor for them (a memset plus a read-modify-write of the 512-channel map)
+        ctx.set_materialize_grads(False)
         return feats, out
 
     @staticmethod
@@ -178,7 +181,11 @@ class _LpipsTap(torch.autograd.Function):
         if g_feats is None:
             df, acc = torch.empty_like(feats), 0
         else:
-            df, acc = g_feats.contiguous(), 1              # produced for this node only: updated in place
+            # Updated IN PLACE.  Invariant this relies on: the incoming gradient was produced for this node alone - it is
+            # the data gradient written by the next stage's first convolution (a fresh tensor of _Conv3x3BiasAct /
+            # _MaxPool2x2.backward).  No backward in this package hands one gradient tensor to two consumers that mutate
+            # (conv_mfma._AddScale returns one tensor twice, to consumers that only read it).
+            df, acc = g_feats.contiguous(), 1
         _lib.call('gg_lpips_tail_bwd_f32', df, feats, lin if lin.numel() else None, g_out.contiguous().float(),
                   n2 // 2, c, h * w, ctx.eps, acc)
         return df, None, None

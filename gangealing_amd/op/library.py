@@ -7,7 +7,8 @@ fake (meta) implementations for shape inference / torch.compile tracing and auto
     y = torch.ops.gangealing.upfirdn2d(x, k, 2, 1, 2, 1)
 
 The module-level functions (op/upfirdn2d.py, op/fused_act.py, splat2d_cuda/functional.py, antialiased_sampling.py)
-remain the drop-in API with the reference's signatures; these ops are thin aliases of the same kernels."""
+remain the drop-in API with the reference's signatures; these ops are aliases of the same kernels (all of them
+differentiable where the reference's operator is; splat2d's backward raises, as the reference's does)."""
 import torch
 
 import importlib
@@ -109,6 +110,38 @@ def _warp_impl(inputs, grid, max_level, min_level, padding_mode, antialias):
         return _MipmapWarpFn.apply(inputs, grid, max_level, min_level, padding_mode, antialias)
 
 
+def _warp_setup(ctx, inputs, output):
+    img, grid, max_level, min_level, padding_mode, antialias = inputs
+    ctx.save_for_backward(img, grid)
+    ctx.conf = (max_level, min_level, padding_mode, antialias)
+
+
+def _warp_backward(ctx, grad_out, _grad_levels):
+    """Gradients w.r.t. the image and the sampling grid: the formula of _MipmapWarpFn (the op's forward ran without a
+    graph, so the Function is re-applied here - the alias operator pays one extra forward; the module-level MipmapWarp
+    is the training path)."""
+    from ..spatial_transformers.antialiased_sampling import _MipmapWarpFn
+    img, grid = ctx.saved_tensors
+    need = ctx.needs_input_grad[:2]
+    with torch.enable_grad():
+        a = img.detach().requires_grad_(need[0])
+        b = grid.detach().requires_grad_(need[1])
+        out, _ = _MipmapWarpFn.apply(a, b, *ctx.conf)
+        wanted = [t for t, n in ((a, need[0]), (b, need[1])) if n]
+        grads = list(torch.autograd.grad(out, wanted, grad_out)) if wanted else []
+    g_img = grads.pop(0) if need[0] else None
+    g_grid = grads.pop(0) if need[1] else None
+    return g_img, g_grid, None, None, None, None
+
+
+def _splat_setup(ctx, inputs, output):
+    pass
+
+
+def _splat_backward(ctx, grad):
+    raise NotImplementedError('splat2d has no backward (as the reference: utils/splat2d_cuda/functional.py:66-68)')
+
+
 def _warp_fake(inputs, grid, max_level, min_level, padding_mode, antialias):
     n, c = inputs.shape[:2]
     ho, wo = grid.shape[1:3]
@@ -196,6 +229,10 @@ def _register():
         torch.library.register_autograd('gangealing::upfirdn2d', _upfirdn2d_backward, setup_context=_upfirdn2d_setup,
                                         lib=_lib_def)
         torch.library.register_autograd('gangealing::fused_leaky_relu', _flr_backward, setup_context=_flr_setup,
+                                        lib=_lib_def)
+        torch.library.register_autograd('gangealing::mipmap_warp', _warp_backward, setup_context=_warp_setup,
+                                        lib=_lib_def)
+        torch.library.register_autograd('gangealing::splat2d', _splat_backward, setup_context=_splat_setup,
                                         lib=_lib_def)
     except RuntimeError:
         pass
