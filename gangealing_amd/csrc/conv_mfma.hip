@@ -3064,7 +3064,9 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
   }
   int rc = gg::launch_status("conv2d_wgrad");
   if (rc || !a.part) return rc;
-  if (splits >= 32 && count <= (1LL << 22))     // many partials of a small tile: one wave per element
+  if (splits >= 32 && count <= 16384)           // many partials of few elements: one wave per element (otherwise a
+                                                // thread per element: coalesced across elements, 512 x 512 1x1 weights
+                                                // took 28 us with 262144 waves reading 4-byte pieces)
     partial_sum_kernel<<<(unsigned)((count + 3) / 4), 256, 0, st>>>(dw, a.part, (int)splits, (int)count, scale,
                                                                     accumulate ? 1 : 0);
   else

@@ -78,15 +78,16 @@ GRAD_FACTOR = 4.0                        # HIP-path error allowed as a multiple 
 # lucky (2e-6); the HIP path is not required to match that luck.  The kernels themselves are compared with float64
 # convolutions at the same shapes, where nothing can flip, in tests/test_gpu_c2_layer_ops.py.
 # Round 3: the library has no float atomics any more, so these errors are exactly reproducible run to run; the floors
-# were re-measured (profiles/parity_r03.json: worst flow-stage / latent / generator gradient 1.5e-3 fp32, 2.3e-3
+# were re-measured (profiles/parity_r03.json: worst flow-stage / latent / generator gradient 9.7e-4 fp32, 3.3e-3
 # bf16x3; perceptual-loss input gradient 1.8e-3 / 3.9e-3) and tightened from 5e-3 / 2e-2 to 3e-3 / 6e-3.
 GRAD_FLOOR = {'fp32': (3e-3, 3e-3), 'bf16x3': (6e-3, 6e-3)}
 # the similarity stage additionally receives gradient through MipmapWarp's level selection, where a similarity warp
 # makes the four neighbour distances EXACTLY tied in real arithmetic: arg-max (and with it the sub-gradient) is decided
 # by last-ulp noise of the grid in every implementation, the reference's float32 and float64 runs included
-# (measured worst case, c2_stn[1]: 2.0e-2 fp32 / 1.6e-2 bf16x3 against the reference's own 4.3e-3)
+# (measured worst case, c2_stn[1]: 7.9e-3 fp32 / 1.8e-2 bf16x3 against the reference's own 4.3e-3)
 SIM_FACTOR = 8.0
-SIM_FLOOR_SCALE = 2.0                    # similarity-stage floors: 6e-3 / 1.2e-2 (round 2: 1.5e-2 / 6e-2)
+SIM_FLOOR_SCALE = 2.5                    # similarity-stage floors: 7.5e-3 / 1.5e-2 (round 2: 1.5e-2 / 6e-2; measured worst
+                                         # outside c2_stn[1]: 3.2e-3 fp32, 1.17e-2 bf16x3 on cfg_c1)
 GRAD_MAX_ELEM = 5e-2                     # single entries, relative to the largest entry (measured worst: 3.0e-2)
 
 
