@@ -43,19 +43,22 @@ METRIC = {'c2': 'train-step images/sec, LSUN-Cats 256^2 STN+StyleGAN2',
           'c5': 'train-step images/sec, LSUN-Cars 256^2 K=4 clustering STN+StyleGAN2 (BASELINE configs[4] flags)'}
 
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks
-MFMA_PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0, 'bf16x6': 2500.0}
+MFMA_PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0, 'bf16x6': 2500.0, 'fp16x3': 2500.0}
 KERNEL_NAME = {
     'fp32': 'conv_igemm_kernel<3,0,2,2,2,2,*> (3x3 correlation, 128co x 128pix tile, v_mfma_f32_32x32x2_f32)',
     'bf16x3': 'conv3x3_patch_kernel<2, true, 256, 2, false, 1> (3x3 stride-1 modulated conv + fused noise/bias/lrelu epilogue, '
               '128co x 256pix tile, input patch staged once per 32-channel chunk, double-buffered weight slab with a '
               'software-pipelined tap loop, v_mfma_f32_32x32x16_bf16, 2 bf16 limbs per fp32 operand = 3 MFMA products per '
               'algorithmic product)',
+    'fp16x3': 'conv3x3_patch_kernel<2, true, 256, 2, false, 1, true> (the bf16x3 tile with binary16 limbs: '
+              'v_mfma_f32_32x32x16_f16, 2 limbs per fp32 operand = 3 MFMA products per algorithmic product, weights '
+              'pre-scaled by 2^8 in the pack; gradient convolutions keep bf16 limbs)',
     'bf16': 'conv3x3_patch_kernel<1, true, 256, 2, false, 3> (same tile as bf16x3, one bf16 limb per operand = one MFMA '
             'product per algorithmic product, fp32 accumulate; three tap slabs staged per barrier interval)',
     'bf16x6': 'conv3x3_patch_kernel<3, true, 128, 2, false, 1> (same layers, 128co x 128pix tile, 3 bf16 limbs per fp32 operand '
               '= 6 MFMA products per algorithmic product)',
 }
-MFMA_PRODUCTS = {'fp32': 1, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}
+MFMA_PRODUCTS = {'fp32': 1, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6, 'fp16x3': 3}
 
 
 def kernel_source_hash():
@@ -89,7 +92,9 @@ def pmc_traffic(precision, workload, batch):
 
 
 DTYPE = {'fp32': 'f32', 'bf16': 'bf16 (convolution operands rounded to bf16, fp32 accumulate, fp32 activations)', 'bf16x3': 'bf16x3 (fp32 operands split into 2 bf16 limbs, fp32 accumulate)',
-         'bf16x6': 'bf16x6 (fp32 operands split into 3 bf16 limbs, fp32 accumulate)'}
+         'bf16x6': 'bf16x6 (fp32 operands split into 3 bf16 limbs, fp32 accumulate)',
+         'fp16x3': 'fp16x3 (fp32 operands split into 2 sixteen-bit limbs, 3 MFMA products, fp32 accumulate: binary16 limbs on '
+                   'the forward convolutions, bf16 limbs on the gradient convolutions)'}
 
 
 def _reference_step_fn(wl):
@@ -280,7 +285,7 @@ def main():
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
     ap.add_argument('--precision', default=os.environ.get('GANGEALING_CONV_PRECISION', 'bf16x3'),
-                    choices=['fp32', 'bf16', 'bf16x3', 'bf16x6'],
+                    choices=['fp32', 'bf16', 'bf16x3', 'bf16x6', 'fp16x3'],
                     help='arithmetic of the implicit-GEMM convolutions (fp32 = exact fp32 MFMA parity mode)')
     ap.add_argument('--graph', action='store_true',
                     help='time hipGraph replays of the whole iteration instead of eager launches (single GPU; no '

@@ -78,6 +78,8 @@ struct ConvArgs {
   // bitwise reproducible (float atomics onto y would combine the splits in arrival order).
   float* part;
   long long part_stride;
+  int f16;                        // split-precision limbs are binary16 (forward convolutions), see Limb<>
+  float acc_scale;                // accumulators are multiplied by this first (1 / kF16WeightScale with f16 limbs)
 };
 
 // k -> (ci, ky, kx, dy, dx).  MODE 0: correlation taps; MODE 1: taps of one parity class.
@@ -344,8 +346,52 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 __device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
-template <int KS, int MODE, int LIMBS, bool IN_SCALE, int TPIX>
+// Limb format of the split-precision kernels.  F16 = false: bf16 limbs (8-bit mantissa, fp32's exponent range - any
+// operand, in particular gradients of arbitrary magnitude).  F16 = true: IEEE binary16 limbs (11-bit mantissa): two
+// limbs carry 22 bits, so the same THREE MFMA products (x0 w0 + x0 w1 + x1 w0) leave ~2^-21 per product instead of
+// ~2^-17 - fp32-class results at the two-limb price - but binary16 spans only 6e-8 .. 65504, so this format is used
+// where the operand range is known: the FORWARD convolutions (activations of O(1); weights are pre-scaled by
+// kF16WeightScale in the pack and the accumulators multiplied by its inverse, so that the low weight limb stays a
+// normal number).  Values beyond +-65504 saturate instead of becoming inf.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float kF16WeightScale = 256.f;
+template <bool F16>
+struct Limb;
+template <>
+struct Limb<false> {
+  static __device__ __forceinline__ unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
+  static __device__ __forceinline__ float lo(unsigned p) { return bf16_lo(p); }
+  static __device__ __forceinline__ float hi(unsigned p) { return bf16_hi(p); }
+  static __device__ __forceinline__ unsigned short one(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+  static __device__ __forceinline__ float back(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+  static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Limb<true> {
+  static __device__ __forceinline__ _Float16 sat(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
+  static __device__ __forceinline__ unsigned pack2(float a, float b) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    f16x2 v;
+    v[0] = sat(a);
+    v[1] = sat(b);
+    return __builtin_bit_cast(unsigned, v);
+  }
+  static __device__ __forceinline__ float lo(unsigned p) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu));
+  }
+  static __device__ __forceinline__ float hi(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
+  static __device__ __forceinline__ unsigned short one(float v) { return __builtin_bit_cast(unsigned short, sat(v)); }
+  static __device__ __forceinline__ float back(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+  static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <int KS, int MODE, int LIMBS, bool IN_SCALE, int TPIX, bool F16 = false>
 __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs a) {
+  using L = Limb<F16>;
   constexpr int TCO = 128, MI = 2, NJ = 2, PWAVES = TPIX / 64;
   __shared__ __attribute__((aligned(16))) unsigned char sW[LIMBS][TCO * ROWB];
   __shared__ __attribute__((aligned(16))) unsigned char sX[LIMBS][TPIX * ROWB];
@@ -439,10 +485,10 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
       unsigned pk[EPT / 2];
 #pragma unroll
       for (int j = 0; j < EPT / 2; ++j) {
-        pk[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+        pk[j] = L::pack2(v[2 * j], v[2 * j + 1]);
         if (l + 1 < LIMBS) {                       // residual for the next limb
-          v[2 * j] -= bf16_lo(pk[j]);
-          v[2 * j + 1] -= bf16_hi(pk[j]);
+          v[2 * j] -= L::lo(pk[j]);
+          v[2 * j + 1] -= L::hi(pk[j]);
         }
       }
       U4* dst = reinterpret_cast<U4*>(&sX[l][pcol * ROWB + khalf * EPT * 2]);
@@ -493,7 +539,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
             for (int i = 0; i < MI; ++i)
 #pragma unroll
               for (int j = 0; j < NJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la][i], fb[lb][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = L::mfma(fa[la][i], fb[lb][j], acc[i][j]);
           }
       }
       __syncthreads();
@@ -523,6 +569,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
         const int co = co0 + (wco * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (co >= a.cout_g) continue;
         float v = acc[i][j][r];
+        if (!partial) v *= a.acc_scale;
         if (osc) v *= osc[co];
         if (bia) v += bia[co];
         yp[(size_t)co * ohw] = v;
@@ -549,8 +596,10 @@ constexpr int patch_pixels(int tpix) { return (tpix / 64 + 2) * 66; }    // (TH+
 // TPI = tap slabs staged per barrier interval.  With two or three limbs a tap already carries 24 / 48 MFMAs per wave
 // between its two barriers; with ONE limb (plain bf16) it carries 8, and the barrier pair costs about as much as the
 // MFMAs - so the single-limb instantiations stage a whole row of taps (ky fixed, kx = 0..2) per interval.
-template <int LIMBS, bool IN_SCALE, int TPIX, int MI = 2, bool MASK = false, int TPI = (LIMBS == 1 ? 3 : 1)>
+template <int LIMBS, bool IN_SCALE, int TPIX, int MI = 2, bool MASK = false, int TPI = (LIMBS == 1 ? 3 : 1),
+          bool F16 = false>
 __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvArgs a, int tw_log2) {
+  using L = Limb<F16>;
   constexpr int TCO = MI * 64, NJ = 2, NT = TPIX * 2, PWAVES = TPIX / 64;
   static_assert(9 % TPI == 0, "TPI must divide the 9 taps");
   // PIPE: the 8-wave tile (alone on its CU) double-buffers the weight slab and software-pipelines the tap loop - see
@@ -662,10 +711,10 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int j = 8 * q + 2 * e;
-            pk[e] = pack_bf16x2(xa[j], xa[j + 1]);
+            pk[e] = L::pack2(xa[j], xa[j + 1]);
             if (l + 1 < LIMBS) {
-              xa[j] -= bf16_lo(pk[e]);
-              xa[j + 1] -= bf16_hi(pk[e]);
+              xa[j] -= L::lo(pk[e]);
+              xa[j + 1] -= L::hi(pk[e]);
             }
           }
           dst[q] = U4{pk[0], pk[1], pk[2], pk[3]};
@@ -677,9 +726,9 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       if (IN_SCALE) v *= sg[chunk * BKS + lci];
 #pragma unroll
       for (int l = 0; l < LIMBS; ++l) {
-        const __bf16 hb = (__bf16)v;
-        *reinterpret_cast<__bf16*>(&sP[l][lpp * ROWB + lci * 2]) = hb;
-        v -= (float)hb;
+        const unsigned short hb = L::one(v);
+        *reinterpret_cast<unsigned short*>(&sP[l][lpp * ROWB + lci * 2]) = hb;
+        v -= L::back(hb);
       }
     }
   };
@@ -764,7 +813,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
             for (int i = 0; i < MI; ++i)
 #pragma unroll
               for (int j = 0; j < NJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la][i], fb[lb][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = L::mfma(fa[la][i], fb[lb][j], acc[i][j]);
           }
       };
       for (int chunk = chunk0; chunk < chunk1; ++chunk) {
@@ -840,7 +889,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                   for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[la][i], fb[lb][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = L::mfma(fa[la][i], fb[lb][j], acc[i][j]);
               }
           }
         }
@@ -897,7 +946,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int co = co0 + (wco * MI + i) * 32 + row;
-        float v = acc[i][j][r];
+        float v = acc[i][j][r] * a.acc_scale;
         if (co < a.cout_g) {
           if (osc) v *= osc[co];
           if (bia) v += bia[co];
@@ -948,9 +997,10 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
 // The q-grid has one more row / column than the input; the extra row is an ordinary tile row, the extra
 // column is covered by "edge" tiles of shape TQ x 1.
 // ------------------------------------------------------------------------------------------------
-template <int LIMBS, bool IN_SCALE, int TQ>
+template <int LIMBS, bool IN_SCALE, int TQ, bool F16 = false>
 __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvArgs a, int tw_log2_in, int tiles_y,
                                                                      int edge_tiles, int pad) {
+  using L = Limb<F16>;
   constexpr int TCO = 128, NJ = 2, NT = TQ * 4, PWAVES = TQ / 64;
   constexpr int PATCH_MAX = 2 * TQ + 2;
   // weight slabs staged per barrier interval: the 8-wave variant (alone on its CU) takes a whole row of taps
@@ -1050,10 +1100,10 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int j = 8 * q + 2 * e;
-            pk[e] = pack_bf16x2(xa[j], xa[j + 1]);
+            pk[e] = L::pack2(xa[j], xa[j + 1]);
             if (l + 1 < LIMBS) {
-              xa[j] -= bf16_lo(pk[e]);
-              xa[j + 1] -= bf16_hi(pk[e]);
+              xa[j] -= L::lo(pk[e]);
+              xa[j + 1] -= L::hi(pk[e]);
             }
           }
           dst[q] = U4{pk[0], pk[1], pk[2], pk[3]};
@@ -1065,9 +1115,9 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
       if (IN_SCALE) v *= sg[chunk * BKS + lci];
 #pragma unroll
       for (int l = 0; l < LIMBS; ++l) {
-        const __bf16 hb = (__bf16)v;
-        *reinterpret_cast<__bf16*>(&sP[l][lpp * ROWB + lci * 2]) = hb;
-        v -= (float)hb;
+        const unsigned short hb = L::one(v);
+        *reinterpret_cast<unsigned short*>(&sP[l][lpp * ROWB + lci * 2]) = hb;
+        v -= L::back(hb);
       }
     }
   };
@@ -1162,7 +1212,7 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
               const int lb = sum - la;
 #pragma unroll
               for (int j = 0; j < NJ; ++j)
-                acc[cls][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][la], fb[slot][lb][j], acc[cls][j], 0, 0, 0);
+                acc[cls][j] = L::mfma(fa[slot][la], fb[slot][lb][j], acc[cls][j]);
             }
           if (PF) __builtin_amdgcn_sched_barrier(0);
         }
@@ -1225,9 +1275,9 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
         const int r = q4 * 4 + rr;
         const int lrow = rr + 4 * (lane >> 5);
         const int co = co0 + wco * 32 + lrow + 8 * q4;
-        float sc = 1.f, bi = 0.f;
+        float sc = a.acc_scale, bi = 0.f;
         if (co < a.cout_g) {
-          if (osc) sc = osc[co];
+          if (osc) sc *= osc[co];
           if (bia) bi = bia[co];
         }
 #pragma unroll
@@ -1294,6 +1344,15 @@ __device__ __forceinline__ void pack_weight_split_body(unsigned short* __restric
     const size_t src = transpose_io ? (((size_t)g * cin_g + r) * cout_g + c) * kk + ky * kw + kx
                                     : (((size_t)g * cout_g + c) * cin_g + r) * kk + ky * kw + kx;
     float v = w[src] * scale;
+    if (limbs & 16) {                    // binary16 limbs (forward packs of the fp16x3 mode), see Limb<true>
+      v *= kF16WeightScale;
+      for (int l = 0; l < (limbs & 15); ++l) {
+        const unsigned short h = Limb<true>::one(v);
+        wl[(size_t)l * limb_stride + o] = h;
+        v -= Limb<true>::back(h);
+      }
+      continue;
+    }
     for (int l = 0; l < limbs; ++l) {
       const __bf16 h = (__bf16)v;
       wl[(size_t)l * limb_stride + o] = __builtin_bit_cast(unsigned short, h);
@@ -1319,7 +1378,7 @@ struct PackJob {
   long long total;
   long long limb_stride;
   int cout_g, cin_g, kh, kw, transpose_io, flip;
-  int limbs;            // 0: fp32 GEMM layout (pack_weight_kernel); 2 | 3: bf16 limb planes
+  int limbs;            // 0: fp32 GEMM layout (pack_weight_kernel); 1 | 2 | 3: bf16 limb planes; 18: two binary16 limbs
   float scale;
 };
 constexpr int PACK_MANY_BLOCKS = 512;        // grid-stride workers per job (small jobs: most exit at once)
@@ -1346,6 +1405,15 @@ __device__ __forceinline__ bool pack_tiled_ok(const PackJob& j) {
 }
 
 __device__ __forceinline__ void store_limbs(unsigned short* __restrict__ dst, long long limb_stride, int limbs, float v) {
+  if (limbs & 16) {                      // binary16 limbs, pre-scaled (see pack_weight_split_body)
+    v *= kF16WeightScale;
+    for (int l = 0; l < (limbs & 15); ++l) {
+      const unsigned short h = Limb<true>::one(v);
+      dst[(size_t)l * limb_stride] = h;
+      v -= Limb<true>::back(h);
+    }
+    return;
+  }
   for (int l = 0; l < limbs; ++l) {
     const __bf16 h = (__bf16)v;
     dst[(size_t)l * limb_stride] = __builtin_bit_cast(unsigned short, h);
@@ -1356,6 +1424,17 @@ __device__ __forceinline__ void store_limbs(unsigned short* __restrict__ dst, lo
 // even limb_stride)
 __device__ __forceinline__ void store_limbs2(unsigned short* __restrict__ dst, long long limb_stride, int limbs, float a,
                                              float b) {
+  if (limbs & 16) {
+    a *= kF16WeightScale;
+    b *= kF16WeightScale;
+    for (int l = 0; l < (limbs & 15); ++l) {
+      const unsigned pk = Limb<true>::pack2(a, b);
+      *reinterpret_cast<unsigned*>(dst + (size_t)l * limb_stride) = pk;
+      a -= Limb<true>::lo(pk);
+      b -= Limb<true>::hi(pk);
+    }
+    return;
+  }
   for (int l = 0; l < limbs; ++l) {
     const unsigned pk = pack_bf16x2(a, b);
     *reinterpret_cast<unsigned*>(dst + (size_t)l * limb_stride) = pk;
@@ -2212,9 +2291,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ 
     }
     const long long plane = e / ohw;
     const int c = (int)(plane % C);
-    const float sc = a.out_scale ? a.out_scale[plane] : 1.f, bi = a.bias ? a.bias[c] : 0.f;
+    const float sc = a.acc_scale * (a.out_scale ? a.out_scale[plane] : 1.f), bi = a.bias ? a.bias[c] : 0.f;
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) v[q] = a.out_scale ? v[q] * sc + bi : v[q] + bi;
+    for (int q = 0; q < VEC; ++q) v[q] = v[q] * sc + bi;
     if (a.act) {
       const long long n = plane / C, p = e - plane * ohw;
       const float ab = a.act_bias ? a.act_bias[c] : 0.f;
@@ -2329,7 +2408,15 @@ int launch_conv_split(const ConvArgs& a, int limbs, hipStream_t st) {
   if ((long long)a.tiles_pix * a.tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
-  if (limbs <= 2 && a.tile_pixels == 256) {
+  if (a.f16) {          // two binary16 limbs (forward convolutions of the fp16x3 mode)
+    if (a.tile_pixels == 256) {
+      if (sc) conv_split_kernel<KS, MODE, 2, true, 256, true><<<grid, 512, 0, st>>>(a);
+      else conv_split_kernel<KS, MODE, 2, false, 256, true><<<grid, 512, 0, st>>>(a);
+    } else {
+      if (sc) conv_split_kernel<KS, MODE, 2, true, 128, true><<<grid, 256, 0, st>>>(a);
+      else conv_split_kernel<KS, MODE, 2, false, 128, true><<<grid, 256, 0, st>>>(a);
+    }
+  } else if (limbs <= 2 && a.tile_pixels == 256) {
     if (sc) LIMBS12(limbs, conv_split_kernel<KS, MODE, L, true, 256><<<grid, 512, 0, st>>>(a));
     else LIMBS12(limbs, conv_split_kernel<KS, MODE, L, false, 256><<<grid, 512, 0, st>>>(a));
   } else if (limbs <= 2) {
@@ -2428,6 +2515,20 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
       if (sc) LIMBS12(limbs, conv3x3_patch_kernel<L, true, 128, 2, true><<<grid, 256, 0, st>>>(a, tw_log2));
       else LIMBS12(limbs, conv3x3_patch_kernel<L, false, 128, 2, true><<<grid, 256, 0, st>>>(a, tw_log2));
     }
+  } else if (a.f16) {        // two binary16 limbs: the same four tile shapes
+    if (narrow && tpix == 256) {
+      if (sc) conv3x3_patch_kernel<2, true, 256, 1, false, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 256, 1, false, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+    } else if (narrow) {
+      if (sc) conv3x3_patch_kernel<2, true, 128, 1, false, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 128, 1, false, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+    } else if (tpix == 256) {
+      if (sc) conv3x3_patch_kernel<2, true, 256, 2, false, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 256, 2, false, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+    } else {
+      if (sc) conv3x3_patch_kernel<2, true, 128, 2, false, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 128, 2, false, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+    }
   } else if (narrow && tpix == 256) {
     if (sc) LIMBS12(limbs, conv3x3_patch_kernel<L, true, 256, 1><<<grid, 512, 0, st>>>(a, tw_log2));
     else LIMBS12(limbs, conv3x3_patch_kernel<L, false, 256, 1><<<grid, 512, 0, st>>>(a, tw_log2));
@@ -2493,7 +2594,15 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   }
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
-  if (limbs <= 2 && tq == 128) {
+  if (a.f16) {
+    if (tq == 128) {
+      if (sc) convT3x3s2_patch_kernel<2, true, 128, true><<<grid, 512, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
+      else convT3x3s2_patch_kernel<2, false, 128, true><<<grid, 512, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
+    } else {
+      if (sc) convT3x3s2_patch_kernel<2, true, 64, true><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
+      else convT3x3s2_patch_kernel<2, false, 64, true><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
+    }
+  } else if (limbs <= 2 && tq == 128) {
     if (sc) LIMBS12(limbs, convT3x3s2_patch_kernel<L, true, 128><<<grid, 512, 0, st>>>(a, tw_log2, tiles_y, edge, pad));
     else LIMBS12(limbs, convT3x3s2_patch_kernel<L, false, 128><<<grid, 512, 0, st>>>(a, tw_log2, tiles_y, edge, pad));
   } else if (limbs <= 2) {
@@ -2684,7 +2793,7 @@ template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {
   if (a.mask_ref) {
     int tw_log2;
-    if (!((limbs == 1 || limbs == 2) && KS == 3 && mode == 0 && stride == 1 && pad == 1)) return kNotFused;
+    if (a.f16 || !((limbs == 1 || limbs == 2) && KS == 3 && mode == 0 && stride == 1 && pad == 1)) return kNotFused;
     const long long tiles256 = (long long)a.batch * a.oh * a.ow / 256 * ((a.cout_g + 127) / 128) * a.groups;
     if (tiles256 >= 2 * gg::kNumCu && a.cin_g > patch256_min_cin() && patch_geometry(a, 256, tw_log2))
       return launch_conv_patch(a, limbs, tw_log2, 256, st);
@@ -2811,8 +2920,11 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   if (mode == 0 && (stride < 1 || stride > 2)) return gg::fail(-2, "conv2d: stride must be 1 or 2");
   if (mode == 1 && stride != 2)
     return gg::fail(-2, "conv2d: transposed mode is implemented for stride 2 (stride 1 = mode 0 with flipped taps)");
+  const bool f16 = (limbs & 16) != 0;      // format code: bit 4 = binary16 limbs (see Limb<>), low bits = limb count
+  if (f16 && (limbs != 18 || mask.ref)) return gg::fail(-2, "conv2d_split: binary16 limbs come in pairs (code 18), forward only");
+  limbs &= 15;
   if (limbs) {
-    if (limbs < 1 || limbs > 3) return gg::fail(-2, "conv2d_split: limbs must be 1, 2 or 3");
+    if (limbs < 1 || limbs > 3) return gg::fail(-2, "conv2d_split: limbs must be 1, 2, 3 or 18");
     if (cin_g % BKS != 0) return gg::fail(-2, "conv2d_split: cin per group must be a multiple of %d", BKS);
     if (in_scale && (reinterpret_cast<uintptr_t>(in_scale) & 15)) return gg::fail(-2, "conv2d_split: in_scale must be 16-byte aligned");
     if (reinterpret_cast<uintptr_t>(wsplit) & 15) return gg::fail(-2, "conv2d_split: weights must be 16-byte aligned");
@@ -2822,6 +2934,8 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   a.y = y; a.x = x; a.wmat = wmat; a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
   a.wsplit = wsplit; a.wsplit_stride = wsplit_stride;
   a.part = nullptr; a.part_stride = 0;
+  a.f16 = f16 ? 1 : 0;
+  a.acc_scale = f16 ? 1.f / kF16WeightScale : 1.f;
   a.mask_ref = mask.ref; a.mask_alpha = mask.alpha; a.mask_gain = mask.gain;
   a.act = act.on; a.act_noise = act.noise; a.act_noise_w = act.noise_w; a.act_bias = act.bias;
   a.act_alpha = act.alpha; a.act_gain = act.gain;
@@ -2900,7 +3014,8 @@ extern "C" int gg_conv_pack_weight_split(unsigned short* wsplit, const float* w,
                                          void* stream) {
   const long long total = (long long)groups * cout_g * cin_g * kh * kw;
   if (total <= 0) return 0;
-  if (!wsplit || !w || limbs < 1 || limbs > 3) return gg::fail(-2, "conv_pack_weight_split: bad arguments");
+  if (!wsplit || !w || (limbs & 15) < 1 || (limbs & 15) > 3 || (limbs & ~31) || ((limbs & 16) && (limbs & 15) != 2))
+    return gg::fail(-2, "conv_pack_weight_split: limbs must be 1, 2, 3 (bf16) or 18 (two binary16 limbs)");
   pack_weight_split_kernel<<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(
       wsplit, w, total, total, cout_g, cin_g, kh, kw, transpose_io, flip, scale, limbs);
   return gg::launch_status("conv_pack_weight_split");

@@ -37,9 +37,23 @@ PROFILER = None
 #   'bf16'   one bf16 limb per operand (one MFMA per tile step, fp32 accumulation, fp32 activations in HBM): plain
 #            bf16 matrix arithmetic, ~2^-9 relative error per product - the arithmetic BASELINE.json's benchmark
 #            configuration names ("bf16").  Not a parity mode: activations agree with the reference to ~1e-2.
+#   'fp16x3' two 16-bit limbs per operand and 3 MFMA products like bf16x3, but the limbs of the FORWARD convolutions are
+#            IEEE binary16 (11-bit mantissa: two limbs carry 22 bits, ~2^-21 per product - fp32-class activations at the
+#            bf16x3 price; binary16's narrow exponent is safe there because activations are O(1) and the weights are
+#            pre-scaled in the pack), while every gradient convolution keeps bf16 limbs (fp32's exponent range: gradients
+#            of any magnitude).  CPU emulation on the reference STN (scripts/study_bf16x3_stn.py): warped-output error
+#            2.6e-5 (bf16x3: 3.3e-4, bf16x6: 2.5e-5, the reference's own fp32 vs fp64: 1.7e-5).
 import os as _os
 PRECISION = _os.environ.get('GANGEALING_CONV_PRECISION', 'fp32')
-_LIMBS = {'fp32': 0, 'bf16': 1, 'bf16x3': 2, 'bf16x6': 3}
+_LIMBS = {'fp32': 0, 'bf16': 1, 'bf16x3': 2, 'bf16x6': 3, 'fp16x3': 2}
+_F16_FORWARD = frozenset(['fp16x3'])
+
+
+def limb_code(grad=False):
+    """Format code of the split-precision entry points for the current mode: limb count, + 16 when the limbs are
+    binary16 (forward launches of the fp16x3 mode; `grad` = the launch is a gradient convolution)."""
+    limbs = _LIMBS[PRECISION]
+    return limbs | 16 if (PRECISION in _F16_FORWARD and not grad) else limbs
 
 
 def set_precision(mode):
@@ -106,9 +120,10 @@ class PackedWeight:
         return self.cin_g % 32 == 0 and self.cout_g > 32
 
     def split(self, limbs):
+        """limbs: format code (limb_code): 1 | 2 | 3 bf16 limbs, 18 = two binary16 limbs (pre-scaled weights)."""
         if limbs not in self._split:
             n = self.groups * self.cout_g * self.cin_g * self.k * self.k
-            buf = torch.empty((limbs, n), dtype=torch.int16, device=self.weight.device)
+            buf = torch.empty((limbs & 15, n), dtype=torch.int16, device=self.weight.device)
             _lib.call('gg_conv_pack_weight_split', buf, self.weight.contiguous(), self.groups, self.cout_g,
                       self.cin_g, self.k, self.k, self.transpose_io, self.flip, self.scale, limbs)
             self._split[limbs] = (buf, n)
@@ -225,10 +240,11 @@ def pack_weight(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0)
 
 
 def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in_scale=None, out_scale=None,
-                 bias=None, out_hw=None, act=None):
+                 bias=None, out_hw=None, act=None, grad=False):
     """act = (noise (N,1,OH,OW), noise_weight (1,), act_bias (Cout,), alpha, gain): the StyledConv tail
     lrelu(y + noise_weight*noise + act_bias)*gain fused behind a 3x3/stride-1/pad-1 convolution
-    (gg_modconv3x3_act_f32)."""
+    (gg_modconv3x3_act_f32).  grad: this launch is a gradient convolution (data gradient): bf16 limbs in every
+    split-precision mode."""
     h, w = x.shape[-2], x.shape[-1]
     if mode == 0:
         oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
@@ -238,7 +254,8 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             oh, ow = out_hw
     y = torch.empty((batch, groups * cout_g, oh, ow), dtype=torch.float32, device=x.device)
     if y.numel():
-        limbs = _LIMBS[PRECISION]
+        code = limb_code(grad)
+        limbs = code & 15
         use_split = limbs > 0 and isinstance(wmat, PackedWeight) and wmat.split_ok()
         prof = None
         if PROFILER is not None and k == 3 and mode == 0 and cout_g > 64:
@@ -263,13 +280,13 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             if (k, stride, pad, mode, groups) != (3, 1, 1, 0, 1) or bias is not None or (oh * ow) % 4:
                 raise NotImplementedError('conv_forward: the fused activation needs a 3x3 stride-1 pad-1 single-group conv')
             noise, noise_weight, act_bias, alpha, gain = act       # noise / noise_weight / act_bias may be None
-            wbuf, stride_l = wmat.split(limbs) if use_split else (None, 0)
+            wbuf, stride_l = wmat.split(code) if use_split else (None, 0)
             wm = None if use_split else (wmat.fp32() if isinstance(wmat, PackedWeight) else wmat)
-            _lib.call('gg_modconv3x3_act_f32', y, x, wm, wbuf, stride_l, limbs if use_split else 0, in_scale, out_scale,
+            _lib.call('gg_modconv3x3_act_f32', y, x, wm, wbuf, stride_l, code if use_split else 0, in_scale, out_scale,
                       noise, noise_weight, act_bias, alpha, gain, batch, cin_g, cout_g, h, w)
         elif use_split:
-            wbuf, stride_l = wmat.split(limbs)
-            _lib.call('gg_conv2d_split_f32', y, x, wbuf, stride_l, limbs, in_scale, out_scale, bias, batch, groups,
+            wbuf, stride_l = wmat.split(code)
+            _lib.call('gg_conv2d_split_f32', y, x, wbuf, stride_l, code, in_scale, out_scale, bias, batch, groups,
                       cin_g, cout_g, h, w, k, stride, pad, mode, oh if mode == 1 else 0, ow if mode == 1 else 0)
         else:
             wm = wmat.fp32() if isinstance(wmat, PackedWeight) else wmat
@@ -419,17 +436,17 @@ def conv2d_backward(x, weight, dy, conf, needs):
         if not transposed:
             if stride == 1:
                 wm = packed(weight, groups, cin_g, cout_g, k, 1, 1, wscale)
-                dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, k - 1 - padding, 0)
+                dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, k - 1 - padding, 0, grad=True)
             else:
                 wm = packed(weight, groups, cin_g, cout_g, k, 1, 0, wscale)
-                dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 1, out_hw=(h, w))
+                dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 1, out_hw=(h, w), grad=True)
         else:
             if stride == 1:
                 wm = packed(weight, groups, cin_g, cout_g, k, 0, 0, wscale)
-                dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, padding, 0)
+                dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 1, padding, 0, grad=True)
             else:
                 wm = packed(weight, groups, cin_g, cout_g, k, 0, 0, wscale)
-                dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 0)
+                dx = conv_forward(dy, wm, batch, groups, cout_g, cin_g, k, 2, padding, 0, grad=True)
                 dx = dx[..., :h, :w].contiguous() if dx.shape[-2:] != (h, w) else dx
     if needs[1]:
         slot = _slot_for(weight)
@@ -505,7 +522,7 @@ class _Conv3x3BiasAct(Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             wm = packed(weight, 1, cin, cout, 3, 1, 1, wscale)
-            dx = conv_forward(g, wm, n, 1, cout, cin, 3, 1, 1, 0)
+            dx = conv_forward(g, wm, n, 1, cout, cin, 3, 1, 1, 0, grad=True)
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(x, g, n, 1, cin, cout, 3, 1, 1, wscale, into=slot)
         return dx, dw, db, None, None, None
@@ -595,12 +612,12 @@ class _ModulatedConv(Function):
             # un-scaled for the per-plane dot product; otherwise the style scale rides in the epilogue.
             osc = None if need_style else style
             if upsample:
-                dxt = conv_forward(dy, wmat_bwd, n, 1, cout, cin, k, 2, 0, 0, in_scale=dscale, out_scale=osc)
+                dxt = conv_forward(dy, wmat_bwd, n, 1, cout, cin, k, 2, 0, 0, in_scale=dscale, out_scale=osc, grad=True)
                 if dxt.shape[-2:] != (h, w):
                     dxt = dxt[..., :h, :w].contiguous()
             else:
                 dxt = conv_forward(dy, wmat_bwd, n, 1, cout, cin, k, 1, k - 1 - k // 2, 0, in_scale=dscale,
-                                   out_scale=osc)
+                                   out_scale=osc, grad=True)
             if need_style:
                 dstyle = plane_dot(dxt, x)
                 if demodulate:
@@ -672,7 +689,7 @@ class _ModulatedConvAct(Function):
             g = torch.empty_like(dy)
             _lib.call('gg_fused_lrelu_bwd_f32', g, None, dy, y, alpha, gain, n, cout, h * w)
             dx = conv_forward(g, ctx.wmat_bwd, n, 1, cout, cin, 3, 1, 1, 0, in_scale=demod if demodulate else None,
-                              out_scale=style)
+                              out_scale=style, grad=True)
         return (dx,) + (None,) * 11
 
 
@@ -720,7 +737,7 @@ class _StyledConvToRGB(Function):
             gm = torch.empty_like(g)
             _lib.call('gg_fused_lrelu_bwd_f32', gm, None, g, y, alpha, gain, n, cout, h * w)
             dx = conv_forward(gm, ctx.wmat_bwd, n, 1, cout, cin, 3, 1, 1, 0, in_scale=demod if demodulate else None,
-                              out_scale=style)
+                              out_scale=style, grad=True)
         return (dx,) + (None,) * 16
 
 

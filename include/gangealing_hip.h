@@ -295,8 +295,8 @@ int gg_conv2d_split_f32(float* y, const float* x, const unsigned short* wsplit, 
  * FusedLeakyReLU):  y = lrelu(out_scale[n,co] * conv3x3(W, in_scale[n,ci] * x) + noise_weight[0] * noise[n,0] +
  * act_bias[co], alpha) * gain.  3x3 / stride 1 / pad 1, one group.  limbs = 0: fp32 MFMA kernel with `wmat`
  * (gg_conv_pack_weight_f32); limbs = 2|3: split-precision kernel with `wsplit` (gg_conv_pack_weight_split).
- * The activation rides in the convolution's epilogue when the launch needs no split-K; otherwise the library runs
- * gg_noise_bias_act_f32 in place afterwards - the result is the same either way.  H*W % 4 == 0.
+ * The activation rides in the convolution's epilogue when the launch needs no split-K; otherwise in the pass that
+ * adds the split-K partial sums - the result is the same either way.  H*W % 4 == 0.
  * noise = NULL drops the noise term and in_scale / out_scale / act_bias may be NULL too, which makes this the plain
  * "3x3 convolution + bias + leaky ReLU" of the STN trunk (EqualConv2d + FusedLeakyReLU, networks.py:602-640) and,
  * with alpha = 0 and gain = 1, the conv + bias + ReLU of the VGG16 backbone (lpips_backbones.py:98-140). */
@@ -304,7 +304,8 @@ int gg_modconv3x3_act_f32(float* y, const float* x, const float* wmat, const uns
                           long long limb_stride, int limbs, const float* in_scale, const float* out_scale,
                           const float* noise, const float* noise_weight, const float* act_bias, float alpha,
                           float gain, int batch, int cin, int cout, int h, int w, void* stream);
-/* Weight gradient: dw (groups, cout_g, cin_g, k, k) torch layout, overwritten.
+/* Weight gradient: dw (groups, cout_g, cin_g, k, k) torch layout, overwritten.  (All weight-gradient entry points:
+ * the K-splits' partial tiles go to the library's scratch and are added in split order.)
  *   dw[g,co,ci,ky,kx] = sum_{n,oy,ox} dy[n,g*cout_g+co,oy,ox] * x[n,g*cin_g+ci, oy*stride+ky-pad, ox*stride+kx-pad] */
 int gg_conv2d_wgrad_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g, int cout_g,
                         int h, int w, int ksize, int stride, int pad, float scale, void* stream);
@@ -319,11 +320,13 @@ int gg_conv2d_wgrad_split_f32(float* dw, const float* x, const float* dy, int ba
 int gg_conv2d_wgrad_acc_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g,
                             int cout_g, int h, int w, int ksize, int stride, int pad, float scale, int limbs,
                             void* stream);
-/* Weight gradient with a caller-provided workspace.  With limbs != 0, a 3x3 / stride-1 / pad-1 convolution and
- * W % 32 == 0 the row-streaming kernel runs: each block walks down a 32-pixel-wide strip keeping a rolling 3-row
- * window of x in LDS, writes its partial (co, ci, tap) tile to `workspace`, and a second kernel sums the partials
- * (dw = or += depending on `accumulate`).  Workspace need: blocks * 147,456 bytes (at most ~1,100 blocks); when it
- * is NULL / too small, or for any other shape, this is gg_conv2d_wgrad(_split / _acc)_f32. */
+/* Weight gradient, kernel chosen by shape; K-split partial tiles are summed in a fixed order (no float atomics).
+ * With limbs != 0, a 3x3 / stride-1 / pad-1 convolution and W % 32 == 0 (or W == 16) the row-streaming kernel runs:
+ * each block walks down a 32-pixel-wide strip keeping a rolling 3-row window of x in LDS and writes its partial
+ * (co, ci, tap) tile to the workspace, a second kernel sums the partials (dw = or += depending on `accumulate`); 1x1
+ * convolutions with <= 4 input channels use a streaming reduction; any other shape is gg_conv2d_wgrad(_split / _acc)_f32.
+ * `workspace` may be NULL (or too small): the library's per-stream scratch is used instead.  Caller-provided need:
+ * blocks * 147,456 bytes (at most ~1,100 blocks). */
 int gg_conv2d_wgrad_ws_f32(float* dw, const float* x, const float* dy, int batch, int groups, int cin_g, int cout_g,
                            int h, int w, int ksize, int stride, int pad, float scale, int limbs, int accumulate,
                            float* workspace, long long workspace_bytes, void* stream);

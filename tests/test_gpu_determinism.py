@@ -43,7 +43,7 @@ def run(cuda, kw, steps, precision):
         conv_mfma.set_precision(old)
 
 
-@pytest.mark.parametrize('precision', ['bf16x3', 'fp32'])
+@pytest.mark.parametrize('precision', ['bf16x3', 'fp16x3', 'fp32'])
 @pytest.mark.parametrize('name', sorted(CONFIGS))
 def test_train_iterations_are_bitwise_reproducible(name, precision, cuda):
     steps = 2

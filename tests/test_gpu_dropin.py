@@ -19,7 +19,7 @@ from test_gpu_c2_layer_ops import MODULATED, N, check, reference_modulated, rnd
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=['fp32', 'bf16x3'])
+@pytest.fixture(params=['fp32', 'bf16x3', 'fp16x3'])
 def mode(request):
     from gangealing_amd.op import conv_mfma
     old = conv_mfma.PRECISION
