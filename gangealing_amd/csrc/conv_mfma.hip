@@ -357,12 +357,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float kF16WeightScale = 256.f;
 template <bool F16>
 struct Limb;
+// pack2 / one: `first` = this is limb 0 of the value (the others hold residuals, which are small)
 template <>
 struct Limb<false> {
-  static __device__ __forceinline__ unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
+  static __device__ __forceinline__ unsigned pack2(float a, float b, bool) { return pack_bf16x2(a, b); }
   static __device__ __forceinline__ float lo(unsigned p) { return bf16_lo(p); }
   static __device__ __forceinline__ float hi(unsigned p) { return bf16_hi(p); }
-  static __device__ __forceinline__ unsigned short one(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+  static __device__ __forceinline__ unsigned short one(float v, bool) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
   static __device__ __forceinline__ float back(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
   static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -370,24 +371,34 @@ struct Limb<false> {
 };
 template <>
 struct Limb<true> {
-  static __device__ __forceinline__ _Float16 sat(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
-  static __device__ __forceinline__ unsigned pack2(float a, float b) {
+  // Limb 0 is converted with round-toward-zero (v_cvt_pkrtz_f16_f32: one instruction per pair, and under that rounding
+  // an overflow yields +-65504 instead of inf - saturation for free); its residual (< one binary16 ulp of the value,
+  // exactly representable in fp32) goes to limb 1 with round-to-nearest, so what is finally dropped is <= 2^-22 |x|
+  // and unbiased, exactly as with two nearest roundings.
+  static __device__ __forceinline__ unsigned pack2(float a, float b, bool first) {
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    if (first) return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
     f16x2 v;
-    v[0] = sat(a);
-    v[1] = sat(b);
+    v[0] = (_Float16)a;
+    v[1] = (_Float16)b;
     return __builtin_bit_cast(unsigned, v);
   }
   static __device__ __forceinline__ float lo(unsigned p) {
     return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu));
   }
   static __device__ __forceinline__ float hi(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
-  static __device__ __forceinline__ unsigned short one(float v) { return __builtin_bit_cast(unsigned short, sat(v)); }
+  static __device__ __forceinline__ unsigned short one(float v, bool first) {
+    return (unsigned short)(pack2(v, 0.f, first) & 0xffffu);
+  }
   static __device__ __forceinline__ float back(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
   static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
 };
+// host-side-exact variant for the weight packs (run once per weight version): nearest rounding with explicit saturation
+__device__ __forceinline__ unsigned short f16_limb_rn(float v) {
+  return __builtin_bit_cast(unsigned short, (_Float16)fminf(fmaxf(v, -65504.f), 65504.f));
+}
 
 template <int KS, int MODE, int LIMBS, bool IN_SCALE, int TPIX, bool F16 = false>
 __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs a) {
@@ -485,7 +496,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
       unsigned pk[EPT / 2];
 #pragma unroll
       for (int j = 0; j < EPT / 2; ++j) {
-        pk[j] = L::pack2(v[2 * j], v[2 * j + 1]);
+        pk[j] = L::pack2(v[2 * j], v[2 * j + 1], l == 0);
         if (l + 1 < LIMBS) {                       // residual for the next limb
           v[2 * j] -= L::lo(pk[j]);
           v[2 * j + 1] -= L::hi(pk[j]);
@@ -711,7 +722,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int j = 8 * q + 2 * e;
-            pk[e] = L::pack2(xa[j], xa[j + 1]);
+            pk[e] = L::pack2(xa[j], xa[j + 1], l == 0);
             if (l + 1 < LIMBS) {
               xa[j] -= L::lo(pk[e]);
               xa[j + 1] -= L::hi(pk[e]);
@@ -726,7 +737,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       if (IN_SCALE) v *= sg[chunk * BKS + lci];
 #pragma unroll
       for (int l = 0; l < LIMBS; ++l) {
-        const unsigned short hb = L::one(v);
+        const unsigned short hb = L::one(v, l == 0);
         *reinterpret_cast<unsigned short*>(&sP[l][lpp * ROWB + lci * 2]) = hb;
         v -= L::back(hb);
       }
@@ -1100,7 +1111,7 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int j = 8 * q + 2 * e;
-            pk[e] = L::pack2(xa[j], xa[j + 1]);
+            pk[e] = L::pack2(xa[j], xa[j + 1], l == 0);
             if (l + 1 < LIMBS) {
               xa[j] -= L::lo(pk[e]);
               xa[j + 1] -= L::hi(pk[e]);
@@ -1115,7 +1126,7 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
       if (IN_SCALE) v *= sg[chunk * BKS + lci];
 #pragma unroll
       for (int l = 0; l < LIMBS; ++l) {
-        const unsigned short hb = L::one(v);
+        const unsigned short hb = L::one(v, l == 0);
         *reinterpret_cast<unsigned short*>(&sP[l][lpp * ROWB + lci * 2]) = hb;
         v -= L::back(hb);
       }
@@ -1347,7 +1358,7 @@ __device__ __forceinline__ void pack_weight_split_body(unsigned short* __restric
     if (limbs & 16) {                    // binary16 limbs (forward packs of the fp16x3 mode), see Limb<true>
       v *= kF16WeightScale;
       for (int l = 0; l < (limbs & 15); ++l) {
-        const unsigned short h = Limb<true>::one(v);
+        const unsigned short h = f16_limb_rn(v);
         wl[(size_t)l * limb_stride + o] = h;
         v -= Limb<true>::back(h);
       }
@@ -1408,7 +1419,7 @@ __device__ __forceinline__ void store_limbs(unsigned short* __restrict__ dst, lo
   if (limbs & 16) {                      // binary16 limbs, pre-scaled (see pack_weight_split_body)
     v *= kF16WeightScale;
     for (int l = 0; l < (limbs & 15); ++l) {
-      const unsigned short h = Limb<true>::one(v);
+      const unsigned short h = f16_limb_rn(v);
       dst[(size_t)l * limb_stride] = h;
       v -= Limb<true>::back(h);
     }
@@ -1428,7 +1439,7 @@ __device__ __forceinline__ void store_limbs2(unsigned short* __restrict__ dst, l
     a *= kF16WeightScale;
     b *= kF16WeightScale;
     for (int l = 0; l < (limbs & 15); ++l) {
-      const unsigned pk = Limb<true>::pack2(a, b);
+      const unsigned pk = (unsigned)f16_limb_rn(a) | ((unsigned)f16_limb_rn(b) << 16);
       *reinterpret_cast<unsigned*>(dst + (size_t)l * limb_stride) = pk;
       a -= Limb<true>::lo(pk);
       b -= Limb<true>::hi(pk);
