@@ -284,9 +284,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
-    ap.add_argument('--precision', default=os.environ.get('GANGEALING_CONV_PRECISION', 'bf16x3'),
+    ap.add_argument('--precision', default=os.environ.get('GANGEALING_CONV_PRECISION', 'fp16x3'),
                     choices=['fp32', 'bf16', 'bf16x3', 'bf16x6', 'fp16x3'],
-                    help='arithmetic of the implicit-GEMM convolutions (fp32 = exact fp32 MFMA parity mode)')
+                    help='arithmetic of the implicit-GEMM convolutions: fp16x3 (default) / bf16x3 = two 16-bit limbs per fp32 '
+                         'operand, 3 MFMA products (binary16 limbs on the forward convolutions / bf16 limbs everywhere); '
+                         'fp32 = exact-product fp32 MFMA')
     ap.add_argument('--graph', action='store_true',
                     help='time hipGraph replays of the whole iteration instead of eager launches (single GPU; no '
                          'roofline entry: HIP events cannot be recorded inside a replayed graph)')
@@ -368,12 +370,13 @@ def main():
         # stays the eager, parity-preserving run whose dominant kernel was timed with HIP events
         extras = {}
         for name, prec, graph, form in (('hipgraph_replay', args.precision, True, 'shared'),
+                                        ('bf16x3_eager', 'bf16x3', False, 'shared'),
                                         ('bf16_eager', 'bf16', False, 'shared'),
                                         ('bf16_hipgraph_replay', 'bf16', True, 'shared'),
                                         # the literal drop-in route: reference-form generator (per-sample weights +
                                         # grouped convolutions through op.conv2d_gradfix), same step otherwise
                                         ('dropin_route', args.precision, False, 'grouped')):
-            if name.startswith('bf16') and args.precision == 'bf16':
+            if (name.startswith('bf16_') and args.precision == 'bf16') or (name == 'bf16x3_eager' and args.precision == 'bf16x3'):
                 continue
             try:
                 r = measure(device, wl, prec, graph, args.steps, args.warmup, world, gdist, profile=False, modconv=form)

@@ -43,12 +43,12 @@ def stamped(src, dst, header=''):
         f.write(STAMP + header + open(os.path.join(O, src)).read())
 
 
-for src, dst in (('parity_r03.json', 'parity_r03.json'), ('bench_bf16x3.json', 'bench_r03_bf16x3.json'),
+for src, dst in (('parity_r03.json', 'parity_r03.json'), ('bench_fp16x3.json', 'bench_r03_fp16x3.json'), ('bench_bf16x3.json', 'bench_r03_bf16x3.json'),
                  ('bench_fp32.json', 'bench_r03_fp32.json'), ('bench_bf16.json', 'bench_r03_bf16.json'),
-                 ('bench_bf16x3_batch5.json', 'bench_r03_bf16x3_batch5.json'),
-                 ('bench_bf16x3_batch32.json', 'bench_r03_bf16x3_batch32.json'),
+                 ('bench_fp16x3_batch5.json', 'bench_r03_fp16x3_batch5.json'),
+                 ('bench_fp16x3_batch32.json', 'bench_r03_fp16x3_batch32.json'),
                  ('bench_c4.json', 'bench_r03_c4.json'), ('bench_c5.json', 'bench_r03_c5.json'),
-                 ('bench_c2_under_rocprofv3.json', 'bench_r03_bf16x3_under_rocprofv3.json'),
+                 ('bench_c2_under_rocprofv3.json', 'bench_r03_fp16x3_under_rocprofv3.json'),
                  ('splat_bench.json', 'r03_splat_bench.json')):
     if os.path.exists(os.path.join(O, src)):
         shutil.copy(os.path.join(O, src), os.path.join(P, dst))
@@ -60,14 +60,16 @@ dom_avg = float(dom_line.split()[2])
 stamped('kernel_stats_c2.txt', 'r03_a_kernel_stats.txt',
         '# rocprofv3 --kernel-trace --output-format rocpd -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline '
         '--no-extras   (13 steps traced; per-step = total/13)\n'
-        f'# bench line printed by the same run: profiles/bench_r03_bf16x3_under_rocprofv3.json '
+        f'# bench line printed by the same run: profiles/bench_r03_fp16x3_under_rocprofv3.json '
         f'(roofline.avg_launch_ms {under["roofline"]["avg_launch_ms"]} vs {dom_avg} us below)\n')
 for w in ('c4', 'c5'):
     stamped(f'kernel_stats_{w}.txt', f'r03_a_kernel_stats_{w}.txt',
             f'# rocprofv3 --kernel-trace -- python bench.py --workload {w} --steps 10 --warmup 3 --no-cpu-baseline '
             f'--no-extras (per-GPU batch 4; 13 steps traced)\n')
 stamped('blur_bench.txt', 'r03_d_blur_bench.txt')
-stamped('conv_layers.txt', 'r03_f_conv_layers.txt', '# scripts/conv_bench.py, bf16x3, batch 16, ITERS=20\n')
+stamped('conv_layers.txt', 'r03_f_conv_layers.txt', '# scripts/conv_bench.py, fp16x3 (forward launches: binary16 limbs; the wgrad column: bf16 limbs), batch 16, ITERS=20\n')
+if os.path.exists(os.path.join(O, 'conv_layers_bf16x3.txt')):
+    stamped('conv_layers_bf16x3.txt', 'r03_f_conv_layers_bf16x3.txt', '# scripts/conv_bench.py "G ", bf16x3, batch 16, ITERS=20\n')
 stamped('determinism.txt', 'r03_determinism.txt',
         '# scripts/check_determinism.py: two runs of two training iterations from the same seeds, compared bit for bit\n')
 stamped('pytest_gpu.txt', 'r03_pytest_gpu.txt', '# python -m pytest tests -m gpu -q (tail)\n')
@@ -98,7 +100,7 @@ wn, wv = find(write, DOM, 'WRITE_SIZE')
 scale_f = 512 * 1024 / cal_f
 fetch_b, write_b = int(fv * 1024 * round(scale_f)), int(wv * 1024)
 json.dump({
-    'kernel': 'conv3x3_patch_kernel<2, true, 256, 2, false, 1>', 'precision': 'bf16x3', 'workload': 'c2', 'batch': 16,
+    'kernel': 'conv3x3_patch_kernel<2, true, 256, 2, false, 1, true>', 'precision': 'fp16x3', 'workload': 'c2', 'batch': 16,
     'kernel_source_sha16': sha, 'commit': commit,
     'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python bench.py --steps 2 '
                '--warmup 1 --no-cpu-baseline --no-extras',

@@ -19,16 +19,18 @@ PY
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/pytest_gpu.txt
 cp gpurun_out/parity_report.json $O/parity_r03.json 2>/dev/null
 ( for cfg in small cluster c2; do for prec in bf16x3 fp32; do timeout 300 python scripts/check_determinism.py $cfg $prec 2>&1 | tail -1; done; done ) > $O/determinism.txt 2>&1
-python bench.py --steps 30 --warmup 5 > $O/bench_bf16x3.json 2> $O/bench_bf16x3.err
+python bench.py --steps 30 --warmup 5 > $O/bench_fp16x3.json 2> $O/bench_fp16x3.err
+python bench.py --steps 30 --warmup 5 --precision bf16x3 --no-cpu-baseline --no-extras > $O/bench_bf16x3.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --precision fp32 --no-cpu-baseline --no-extras > $O/bench_fp32.json 2>/dev/null
 python bench.py --steps 30 --warmup 5 --precision bf16 --no-cpu-baseline --no-extras > $O/bench_bf16.json 2>/dev/null
-python bench.py --steps 30 --warmup 5 --batch 5 --no-cpu-baseline --no-extras > $O/bench_bf16x3_batch5.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 --batch 32 --no-cpu-baseline --no-extras > $O/bench_bf16x3_batch32.json 2>/dev/null
+python bench.py --steps 30 --warmup 5 --batch 5 --no-cpu-baseline --no-extras > $O/bench_fp16x3_batch5.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --batch 32 --no-cpu-baseline --no-extras > $O/bench_fp16x3_batch32.json 2>/dev/null
 python bench.py --workload c4 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_c4.json 2>/dev/null
 python bench.py --workload c5 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_c5.json 2>/dev/null
 python scripts/blur_bench.py > $O/blur_bench.txt 2>&1
 python scripts/splat_bench.py $O/splat_bench.json > $O/splat_bench.txt 2>&1
-GANGEALING_CONV_PRECISION=bf16x3 ITERS=20 python scripts/conv_bench.py > $O/conv_layers.txt 2>&1
+GANGEALING_CONV_PRECISION=fp16x3 ITERS=20 python scripts/conv_bench.py > $O/conv_layers.txt 2>&1
+GANGEALING_CONV_PRECISION=bf16x3 ITERS=20 python scripts/conv_bench.py "G " > $O/conv_layers_bf16x3.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 for w in c2 c4 c5; do
   CMD="python $R/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-extras"
@@ -54,4 +56,4 @@ for d in splat_fetch splat_write; do
   python scripts/pmc_kernel.py $O/$d "splat" > $O/$d.txt 2>&1
   rm -rf $O/$d
 done
-ls -la $O; cat $O/pytest_gpu.txt; cat $O/determinism.txt; head -c 700 $O/bench_bf16x3.json; echo; head -8 $O/kernel_stats_c2.txt | cut -c1-170
+ls -la $O; cat $O/pytest_gpu.txt; cat $O/determinism.txt; head -c 700 $O/bench_fp16x3.json; echo; head -8 $O/kernel_stats_c2.txt | cut -c1-170

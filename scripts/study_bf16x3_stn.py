@@ -28,7 +28,38 @@ def limbs_of(t, n):
     return out
 
 
+def rtz16(x):
+    """float32 -> binary16 with round-toward-zero and saturation (v_cvt_pkrtz_f16_f32), returned as float32."""
+    x = x.clamp(-65504.0, 65504.0)
+    h = x.to(torch.float16)
+    over = h.float().abs() > x.abs()                 # nearest rounded away from zero: step the magnitude back
+    bits = h.view(torch.int16).clone()
+    bits[over] = bits[over] - 1
+    return bits.view(torch.float16).float()
+
+
+def f16_limbs_act(t):
+    """Activation limbs of the fp16x3 mode: limb 0 round-toward-zero, limb 1 = nearest of the (exact) residual."""
+    h0 = rtz16(t)
+    return [h0, (t - h0).to(torch.float16).float()]
+
+
+def f16_limbs_weight(t, scale=256.0):
+    """Weight limbs of the fp16x3 packs: pre-scaled by 2^8, both limbs nearest with saturation."""
+    out, r = [], t * scale
+    for _ in range(2):
+        h = r.clamp(-65504.0, 65504.0).to(torch.float16).float()
+        out.append(h)
+        r = r - h
+    return out
+
+
 def emulated_conv(x, w, bias, limbs, **kw):
+    if limbs == 16:                                  # fp16x3: binary16 limbs, three products, accumulators / 2^8
+        xs, ws = f16_limbs_act(x), f16_limbs_weight(w)
+        acc = REAL_CONV(xs[1], ws[0], None, **kw) + REAL_CONV(xs[0], ws[1], None, **kw)
+        acc = (acc + REAL_CONV(xs[0], ws[0], None, **kw)) / 256.0
+        return acc if bias is None else acc + bias.view(1, -1, 1, 1)
     xs, ws = limbs_of(x, limbs), limbs_of(w, limbs)
     acc = None
     for s in range(limbs - 1, -1, -1):          # smallest terms first, as the kernels do
@@ -105,6 +136,8 @@ if __name__ == '__main__':
             'sim stage >= 64^2 layers bf16x6': lambda i, xs, ws: 3 if (i < nsim and xs[-1] >= 63) else 2,
             'sim stage fp32 exact, flow stage bf16x3': lambda i, xs, ws: 0 if i < nsim else 2,
             'all bf16x6': lambda i, xs, ws: 3,
+            'all fp16x3 (binary16 limbs, 3 products)': lambda i, xs, ws: 16,
+            'sim stage fp16x3, flow stage bf16x3': lambda i, xs, ws: 16 if i < nsim else 2,
         }
         for name, fn in policies.items():
             out, flow, sim, _ = run(fn, ci)
