@@ -37,7 +37,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize('mode_name,tol', [('bf16x3', 3e-5), ('bf16x6', 1e-5)])
+@pytest.mark.parametrize('mode_name,tol', [('bf16x3', 3e-5), ('bf16x6', 1e-5), ('fp16x3', 1e-5)])
 @pytest.mark.parametrize('spec', CASES, ids=lambda s: 'x'.join(map(str, s)))
 def test_split_conv_matches_fp32_kernel(spec, mode_name, tol, cuda, precision):
     from gangealing_amd.op import conv_mfma as cm
@@ -234,3 +234,27 @@ def test_pointwise_small_cin_wgrad(spec, mode_name, cuda, precision):
     cm.conv_wgrad(x.to(cuda), dy.to(cuda), n, 1, cin, cout, 1, 1, 0, 0.25, into=slot)
     np.testing.assert_allclose(slot.cpu().numpy().reshape(cout, cin) - 2.0, ref.numpy(), rtol=2e-5,
                                atol=2e-5 * float(ref.abs().max()))
+
+
+def test_fp16_limbs_saturate_and_keep_small_values(cuda, precision):
+    """The fp16x3 mode's binary16 limbs: operands beyond +-65504 saturate (finite, wrong - never inf / NaN), tiny
+    activations survive as subnormals to ~1e-7 absolute, and a gradient convolution (grad=True) keeps bf16 limbs, whose
+    exponent range is fp32's."""
+    from gangealing_amd.op import conv_mfma as cm
+    g = torch.Generator(device='cpu').manual_seed(7)
+    n, cin, cout, h = 2, 64, 64, 16
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(cuda)
+    pw = cm.PackedWeight(w, 1, cout, cin, 3, 0, 0, 1.0)
+    x = torch.randn(n, cin, h, h, generator=g).to(cuda)
+    precision('fp32')
+    ref = cm.conv_forward(x, pw, n, 1, cin, cout, 3, 1, 1, 0)
+    precision('fp16x3')
+    big = cm.conv_forward(x * 1e7, pw, n, 1, cin, cout, 3, 1, 1, 0)             # |x| up to ~4e7: saturates
+    assert bool(torch.isfinite(big).all())
+    small = cm.conv_forward(x * 1e-3, pw, n, 1, cin, cout, 3, 1, 1, 0)          # low limb in the subnormal range
+    assert float((small - ref * 1e-3).abs().max()) <= 5e-7
+    tiny_grad = cm.conv_forward(x * 1e-12, pw, n, 1, cin, cout, 3, 1, 1, 0, grad=True)     # bf16 limbs: full range
+    rel = float((tiny_grad - ref * 1e-12).abs().max() / (ref.abs().max() * 1e-12))
+    assert rel <= 3e-5, rel
+    as_fwd = cm.conv_forward(x * 1e-12, pw, n, 1, cin, cout, 3, 1, 1, 0)                   # binary16 would flush this
+    assert float(as_fwd.abs().max()) <= float(tiny_grad.abs().max())
