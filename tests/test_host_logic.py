@@ -309,7 +309,7 @@ def test_committed_bench_line_follows_the_contract():
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = json.loads(open(os.path.join(root, 'profiles', 'bench_r02_bf16x3.json')).read().strip().splitlines()[-1])
+    line = json.loads(open(os.path.join(root, 'profiles', 'bench_r03_fp16x3.json')).read().strip().splitlines()[-1])
     base = json.load(open(os.path.join(root, 'BASELINE.json')))
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
