@@ -268,6 +268,13 @@ int gg_conv2d_f32(float* y, const float* x, const float* wmat, const float* in_s
 /* Split-precision variant of gg_conv2d_f32 on the bf16 matrix pipe (16x the fp32 MFMA rate): every fp32
  * operand is split into `limbs` bf16 limbs and the product is assembled from the limb pairs (i,j), i+j <
  * limbs, accumulated in fp32.  limbs = 2: 3 MFMAs, error ~2^-16 per product; limbs = 3: 6 MFMAs, fp32-class.
+ * limbs = 18 (= 16 + 2; ABI 2): two BINARY16 limbs (11 + 11 significand bits, v_mfma_f32_32x32x16_f16), 3 MFMAs,
+ * error ~2^-22 per product.  For FORWARD convolutions only: binary16 has no exponent range to spare, so the pack
+ * multiplies the weights by 2^8 (the kernels' epilogues divide the fp32 accumulator by 2^8 - exact), the leading
+ * limb of an operand is rounded toward zero and saturates at +-65504 (|x| up to ~1.3e5 is still represented exactly
+ * by the limb pair; beyond that the result is finite and wrong), and activations below ~1e-7 vanish.  Gradient
+ * tensors span more than that: pass limbs = 2 for them (gg_conv3x3_masked_dgrad_f32 and the weight-gradient entry
+ * points do not take 18).  A weight pack made with limbs = 18 must be used with limbs = 18 and vice versa.
  * Weights come pre-split from gg_conv_pack_weight_split: bf16 planes wsplit[limb][g][co][k], K ordered
  * (tap, ci) with ci fastest, limb planes `limb_stride` elements apart (= groups*cout_g*cin_g*kh*kw).
  * Requires cin_g % 32 == 0; every other argument as gg_conv2d_f32. */

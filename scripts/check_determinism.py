@@ -35,7 +35,7 @@ def run(kw, steps):
 
 def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else 'small'
-    prec = sys.argv[2] if len(sys.argv) > 2 else 'bf16x3'
+    prec = sys.argv[2] if len(sys.argv) > 2 else 'fp16x3'
     conv_mfma.set_precision(prec)
     names, a = run(CFG[cfg], 2)
     _, b = run(CFG[cfg], 2)

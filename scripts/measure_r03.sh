@@ -18,7 +18,7 @@ print(bench.kernel_source_hash())
 PY
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/pytest_gpu.txt
 cp gpurun_out/parity_report.json $O/parity_r03.json 2>/dev/null
-( for cfg in small cluster c2; do for prec in bf16x3 fp32; do timeout 300 python scripts/check_determinism.py $cfg $prec 2>&1 | tail -1; done; done ) > $O/determinism.txt 2>&1
+( for cfg in small cluster c2; do for prec in fp16x3 bf16x3 fp32; do timeout 300 python scripts/check_determinism.py $cfg $prec 2>&1 | tail -1; done; done ) > $O/determinism.txt 2>&1
 python bench.py --steps 30 --warmup 5 > $O/bench_fp16x3.json 2> $O/bench_fp16x3.err
 python bench.py --steps 30 --warmup 5 --precision bf16x3 --no-cpu-baseline --no-extras > $O/bench_bf16x3.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --precision fp32 --no-cpu-baseline --no-extras > $O/bench_fp32.json 2>/dev/null
