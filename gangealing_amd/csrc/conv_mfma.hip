@@ -330,6 +330,14 @@ __device__ __forceinline__ void buffer_store_f32(float v, __amdgpu_buffer_rsrc_t
 }
 // orders one wave's LDS writes before its own later LDS reads (and vice versa) when the lanes exchange data through a
 // region no other wave touches: DS operations of a wave execute in order, so only the compiler has to be held back
+#ifdef GG_EXP_STAGGER            // measurement build: de-phase the first wave of blocks by (block % 8) / 8 of `cycles`
+__device__ __forceinline__ void exp_stagger(unsigned block, long long ref_ticks) {
+  if (block >= 256u) return;
+  const long long t0 = wall_clock64();
+  const long long wait = ref_ticks * (long long)(block & 7u) / 8;
+  while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+}
+#endif
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -622,8 +630,11 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   constexpr int PATCH_MAX = LIMBS == 3 ? 6 * 34 : patch_pixels(TPIX);
   // one LDS arena: [limb][patch rows] then [limb][weight rows]; reused as the epilogue staging buffer (32 x 64
   // floats per wave - with a single limb that is the larger of the two uses)
+  // (the epilogue also keeps the tile's per-channel scale / bias / activation bias and per-pixel noise in LDS: EPI_BYTES)
   constexpr int MAIN_BYTES = LIMBS * (PATCH_MAX + WBUF * TPI * TCO) * ROWB, STAGE_BYTES = (NT / 64) * 32 * 64 * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES];
+  constexpr int EPI_BYTES = (3 * TCO + TPIX) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char
+      smem[MAIN_BYTES > STAGE_BYTES + EPI_BYTES ? MAIN_BYTES : STAGE_BYTES + EPI_BYTES];
   unsigned char (*sP)[PATCH_MAX * ROWB] = reinterpret_cast<unsigned char (*)[PATCH_MAX * ROWB]>(smem);
   unsigned char (*sW)[TCO * ROWB] = reinterpret_cast<unsigned char (*)[TCO * ROWB]>(smem + LIMBS * PATCH_MAX * ROWB);
 
@@ -642,6 +653,9 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   const int trem = tile_pix - pn * tiles_x * tiles_y;
   const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
+#ifdef GG_EXP_STAGGER
+  exp_stagger(blockIdx.x, (long long)a.slabs_per_split * 600);
+#endif
 
   const int chan0 = (pn * a.groups + g) * a.cin_g;
   const float* sg = IN_SCALE ? a.in_scale + chan0 : nullptr;
@@ -949,23 +963,38 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   // sub-tile through LDS and store 16 B per lane: every store instruction writes 4 full 256 B pixel runs.
   __syncthreads();                                          // sP / sW are dead from here on
   float* stage = reinterpret_cast<float*>(smem) + wid * (32 * 64);
+  // Everything the epilogue reads from global memory goes to LDS FIRST: VMEM loads and stores share one in-order
+  // counter (vmcnt), so a load issued after a store can only be waited for together with that store's
+  // acknowledgement - with the per-channel / per-pixel loads inside the store loop every pass paid a store round
+  // trip (16 of them per tile; r03 session I: the epilogue was 15 - 29 % of the large layers' launches).
+  float* ep_scale = reinterpret_cast<float*>(smem + STAGE_BYTES);        // acc_scale * out_scale[co]
+  float* ep_bias = ep_scale + TCO;                                       // bias[co]
+  float* ep_abias = ep_bias + TCO;                                       // activation bias[co]
+  float* ep_noise = ep_abias + TCO;                                      // noise at the tile's pixels
+  for (int c = tid; c < TCO; c += NT) {
+    const int co = co0 + c;
+    const bool ok = co < a.cout_g;
+    ep_scale[c] = (osc && ok) ? a.acc_scale * osc[co] : a.acc_scale;
+    ep_bias[c] = (bia && ok) ? bia[co] : 0.f;
+    ep_abias[c] = (a.act && a.act_bias && ok) ? a.act_bias[g * a.cout_g + co] : 0.f;
+  }
+  for (int p = tid; p < TPIX; p += NT) {
+    const int oy = y0 + (p >> tw_log2), ox = x0 + (p & (TW - 1));
+    ep_noise[p] = (a.act && a.act_noise) ? a.act_noise[(size_t)pn * hw + (size_t)oy * a.w + ox] : 0.f;
+  }
+  const float anw = (a.act && a.act_noise) ? a.act_noise_w[0] : 0.f;
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int c = (wco * MI + i) * 32 + row;
+      const float sc = ep_scale[c], bi = ep_bias[c];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int co = co0 + (wco * MI + i) * 32 + row;
-        float v = acc[i][j][r] * a.acc_scale;
-        if (co < a.cout_g) {
-          if (osc) v *= osc[co];
-          if (bia) v += bia[co];
-        }
-        stage[row * 64 + j * 32 + (lane & 31)] = v;
-      }
+      for (int j = 0; j < NJ; ++j) stage[row * 64 + j * 32 + (lane & 31)] = acc[i][j][r] * sc + bi;
+    }
     wave_lds_sync();                // the staging rows are this wave's own
-    const float anw = (a.act && a.act_noise) ? a.act_noise_w[0] : 0.f;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int idx = it * 64 + lane;
@@ -976,9 +1005,8 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       if (co < a.cout_g) {
         float4 v4 = *reinterpret_cast<const float4*>(stage + row * 64 + c4 * 4);
         if (a.act) {             // (NoiseInjection +) bias + leaky ReLU (networks.py:291-298, 344-350; fused_act.py:74-97)
-          const float4 nz = a.act_noise ? *reinterpret_cast<const float4*>(a.act_noise + (size_t)pn * hw + (size_t)oy * a.w + ox)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-          const float ab = a.act_bias ? a.act_bias[g * a.cout_g + co] : 0.f;
+          const float4 nz = *reinterpret_cast<const float4*>(ep_noise + p);
+          const float ab = ep_abias[(wco * MI + i) * 32 + row];
           float t;
           t = v4.x + anw * nz.x + ab; v4.x = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
           t = v4.y + anw * nz.y + ab; v4.y = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
@@ -1018,7 +1046,9 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   // (ky fixed, kx = 0..2) so that each interval carries 36 instead of 12 MFMAs per wave
   constexpr int TPI = (TQ == 128) ? 3 : 1;
   constexpr int MAIN_BYTES = LIMBS * (PATCH_MAX + TPI * TCO) * ROWB, STAGE_BYTES = (NT / 64) * 8 * 128 * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES];
+  constexpr int EPI_BYTES = 2 * TCO * 4;          // per-channel scale and bias of the tile (see the epilogue)
+  __shared__ __attribute__((aligned(16))) unsigned char
+      smem[MAIN_BYTES > STAGE_BYTES + EPI_BYTES ? MAIN_BYTES : STAGE_BYTES + EPI_BYTES];
   unsigned char (*sP)[PATCH_MAX * ROWB] = reinterpret_cast<unsigned char (*)[PATCH_MAX * ROWB]>(smem);
   unsigned char (*sW)[TCO * ROWB] = reinterpret_cast<unsigned char (*)[TCO * ROWB]>(smem + LIMBS * PATCH_MAX * ROWB);
 
@@ -1047,6 +1077,9 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
     x0 = a.w;
   }
   const int TW = 1 << tw_log2, TH = TQ >> tw_log2, PW = TW + 1, PP = (TH + 1) * PW;
+#ifdef GG_EXP_STAGGER
+  exp_stagger(blockIdx.x, (long long)a.slabs_per_split * 700);      // 100 MHz ticks: ~7 us per 32-channel chunk
+#endif
 
   const int chan0 = (pn * a.groups + g) * a.cin_g;
   const float* sg = IN_SCALE ? a.in_scale + chan0 : nullptr;
@@ -1091,6 +1124,13 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   U4 wv[TPI][LIMBS][WEPT / 8];
 
   auto load_patch = [&](int chunk) {
+#ifdef GG_EXP_CONVT_NO_PLOAD     // measurement build: no activation loads
+    if (chunk >= 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) xa[j] = 1.f + j;
+      return;
+    }
+#endif
     const int cbase = __builtin_amdgcn_readfirstlane(chunk * BKS * hw * 4);
 #pragma unroll
     for (int j = 0; j < 16; ++j) xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
@@ -1134,6 +1174,17 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   };
   // interval i of a chunk covers taps [i * TPI, i * TPI + TPI)
   auto load_w = [&](int chunk, int interval) {
+#ifdef GG_EXP_CONVT_NO_WLOAD     // measurement build: no weight loads
+    if (chunk >= 0) {
+#pragma unroll
+      for (int u = 0; u < TPI; ++u)
+#pragma unroll
+        for (int l = 0; l < LIMBS; ++l)
+#pragma unroll
+          for (int q = 0; q < WEPT / 8; ++q) wv[u][l][q] = U4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+      return;
+    }
+#endif
 #pragma unroll
     for (int u = 0; u < TPI; ++u) {
       const int soff = __builtin_amdgcn_readfirstlane(((interval * TPI + u) * a.cin_g + chunk * BKS) * 2);
@@ -1246,6 +1297,11 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   }
 #endif
   const int ohw = a.oh * a.ow;
+#ifdef GG_EXP_CONVT_PITCH        // measurement build (results land at wrong addresses): 16-byte aligned output rows
+  const int owp = (a.ow + 3) & ~3, ohwp = a.oh * owp;
+#else
+  const int owp = a.ow, ohwp = ohw;
+#endif
   const int ochan0 = (pn * a.groups + g) * a.cout_g;
   const float* osc = a.out_scale ? a.out_scale + ochan0 : nullptr;
   const float* bia = a.bias ? a.bias + g * a.cout_g : nullptr;
@@ -1275,8 +1331,22 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   // the (2W+1)-wide output start at odd offsets) - 4x fewer store instructions than the per-dword form.
   __syncthreads();                                          // sP / sW are dead from here on
   float* stage = reinterpret_cast<float*>(smem) + wid * (8 * 128);
+  // per-channel scale / bias through LDS, loaded before the first store (a VMEM load issued after a store is waited
+  // for together with that store's acknowledgement - see conv3x3_patch_kernel's epilogue)
+  float* ep_scale = reinterpret_cast<float*>(smem + STAGE_BYTES);
+  float* ep_bias = ep_scale + TCO;
+  for (int c = tid; c < TCO; c += NT) {
+    const int co = co0 + c;
+    const bool ok = co < a.cout_g;
+    ep_scale[c] = (osc && ok) ? a.acc_scale * osc[co] : a.acc_scale;
+    ep_bias[c] = (bia && ok) ? bia[co] : 0.f;
+  }
+  __syncthreads();
   const __amdgpu_buffer_rsrc_t yr = uniform_rsrc(a.y + (size_t)ochan0 * ohw, a.cout_g * ohw * 4);
   const bool vec = tw_log2 > 0;                             // edge tiles (one q column): scalar stores
+#ifdef GG_EXP_CONVT_EPI_NOLDS
+  float exp_sum = 0.f;
+#endif
 #pragma unroll
   for (int py = 0; py < 2; ++py) {
 #pragma unroll
@@ -1285,12 +1355,10 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
       for (int rr = 0; rr < 4; ++rr) {
         const int r = q4 * 4 + rr;
         const int lrow = rr + 4 * (lane >> 5);
-        const int co = co0 + wco * 32 + lrow + 8 * q4;
-        float sc = a.acc_scale, bi = 0.f;
-        if (co < a.cout_g) {
-          if (osc) sc *= osc[co];
-          if (bia) bi = bia[co];
-        }
+        const float sc = ep_scale[wco * 32 + lrow + 8 * q4], bi = ep_bias[wco * 32 + lrow + 8 * q4];
+#ifdef GG_EXP_CONVT_EPI_NOLDS    // measurement build: no LDS transposition (the stores carry garbage)
+        for (int j = 0; j < NJ; ++j) exp_sum += acc[py * 2 + 0][j][r] * sc + acc[py * 2 + 1][j][r] * sc + bi;
+#else
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           float2 v2;
@@ -1298,19 +1366,30 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
           v2.y = acc[py * 2 + 1][j][r] * sc + bi;
           *reinterpret_cast<float2*>(stage + lrow * 128 + (j * 32 + l31) * 2) = v2;
         }
+#endif
       }
+#ifndef GG_EXP_CONVT_EPI_NOLDS
       wave_lds_sync();
+#endif
       if (vec) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int idx = it * 64 + lane;
           const int lrow = idx >> 5, s = (idx & 31) * 4;
+#ifdef GG_EXP_CONVT_EPI_NOLDS
+          const f32x4 v4 = f32x4{exp_sum, exp_sum, exp_sum, exp_sum};
+#else
           const f32x4 v4 = *reinterpret_cast<const f32x4*>(stage + lrow * 128 + s);
+#endif
           const int p = wpix * 64 + (s >> 1);
           const int oy = 2 * (y0 + (p >> tw_log2)) + py - pad, ox = 2 * (x0 + (p & (TW - 1))) - pad;
           const int co = co0 + wco * 32 + lrow + 8 * q4;
           const bool rowok = co < a.cout_g && (unsigned)oy < (unsigned)a.oh;
-          const unsigned off = (unsigned)(co * ohw + oy * a.ow + ox) * 4u;
+          const unsigned off = (unsigned)(co * ohwp + oy * owp + ox) * 4u;
+#ifdef GG_EXP_CONVT_EPI_NOSTORE  // measurement build: the LDS transposition without the global stores
+          if (v4[0] == 1234.5678f && v4[1] == 8765.4321f) buffer_store_f32x4(v4, yr, off, 0);
+          continue;
+#endif
           if (rowok && ox >= 0 && ox + 3 < a.ow) {
             buffer_store_f32x4(v4, yr, off, 0);
           } else if (rowok) {
@@ -1320,6 +1399,9 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
           }
         }
       } else {
+#ifdef GG_EXP_CONVT_PITCH
+        if (owp != a.ow) continue;
+#endif
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
           const int idx = it * 64 + lane;

@@ -322,11 +322,21 @@ constexpr int MAX_LDS_TAPS = 1024;
 
 // K = tap / accumulator type: T itself for float and double; float for binary16 tensors (the reference's kernel
 // accumulates in scalar_t, upfirdn2d_kernel.cu:191-201; one rounding at the end is the tighter result)
-template <typename T, typename K = T>
+// Thread -> one output position (oy, ox) of the plane, 32-bit index math (one unsigned division per thread; the round-2
+// form decomposed a 64-bit flat index with two 64-bit divisions per output - several hundred VALU instructions for a
+// 16-tap filter); the tap geometry depends on the position only, so it is computed once and the thread then walks over
+// planes blockIdx.y, blockIdx.y + gridDim.y, ...
+// FAST: 0 = any up / down / taps; 1 = 4x4 taps, up 1, down 2 (the ResBlock skip's blur + stride-2 read-out and the
+// adjoint of the ToRGB up-sampling); 2 = 4x4 taps, up 2, down 1 (ToRGB skip up-sampling, adjoint of the former): the
+// tap loops have constant trip counts there.
+template <typename T, typename K = T, int FAST = 0>
 __global__ __launch_bounds__(256) void upfirdn2d_direct(
     T* __restrict__ out, const T* __restrict__ in, const K* __restrict__ kernel,
-    long long total, int in_h, int in_w, int out_h, int out_w, int kh, int kw,
-    int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_y0, const T* __restrict__ addend = nullptr) {
+    int major, int in_h, int in_w, int out_h, int out_w, int kh_, int kw_,
+    int up_x_, int up_y_, int down_x_, int down_y_, int pad_x0, int pad_y0, const T* __restrict__ addend = nullptr) {
+  const int kh = FAST ? 4 : kh_, kw = FAST ? 4 : kw_;
+  const int up_x = FAST == 1 ? 1 : FAST == 2 ? 2 : up_x_, up_y = FAST == 1 ? 1 : FAST == 2 ? 2 : up_y_;
+  const int down_x = FAST == 1 ? 2 : FAST == 2 ? 1 : down_x_, down_y = FAST == 1 ? 2 : FAST == 2 ? 1 : down_y_;
   __shared__ K sk[MAX_LDS_TAPS];
   const bool lds_taps = kh * kw <= MAX_LDS_TAPS;
   if (lds_taps) {
@@ -336,30 +346,93 @@ __global__ __launch_bounds__(256) void upfirdn2d_direct(
     }
     __syncthreads();
   }
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
-    const int ox = (int)(o % out_w);
-    const long long q = o / out_w;
-    const int oy = (int)(q % out_h);
-    const long long plane = q / out_h;
+  const unsigned per_out = (unsigned)out_h * (unsigned)out_w;
+  const size_t per_in = (size_t)in_h * in_w;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < per_out; idx += gridDim.x * 256u) {
+    const int oy = (int)(idx / (unsigned)out_w);
+    const int ox = (int)(idx - (unsigned)oy * (unsigned)out_w);
     const int mid_x = ox * down_x + up_x - 1 - pad_x0;
     const int mid_y = oy * down_y + up_y - 1 - pad_y0;
     const int ix0 = gg::floor_div(mid_x, up_x), iy0 = gg::floor_div(mid_y, up_y);
     const int tx0 = ix0 * up_x + pad_x0 - ox * down_x;
     const int ty0 = iy0 * up_y + pad_y0 - oy * down_y;
-    const T* src = in + (size_t)plane * in_h * in_w;
-    K acc = K(0);
-    for (int ty = ty0, iy = iy0; ty < kh; ty += up_y, ++iy) {
-      if (iy < 0 || iy >= in_h) continue;
-      for (int tx = tx0, ix = ix0; tx < kw; tx += up_x, ++ix) {
-        if (ix < 0 || ix >= in_w) continue;
-        const K kv = lds_taps ? sk[ty * kw + tx] : kernel[(kh - 1 - ty) * kw + (kw - 1 - tx)];
-        acc += K(src[(size_t)iy * in_w + ix]) * kv;
+    if (FAST) {
+      // constant trip counts: NT taps per axis starting at (tx0, ty0) in {0 .. up - 1}; a tap outside the image reads a
+      // clamped (always valid) address and is replaced by zero - no branches in the plane loop
+      constexpr int NT = FAST == 1 ? 4 : 2, UP = FAST == 1 ? 1 : 2;
+      K kv[NT][NT];
+      int off[NT][NT];
+      unsigned okm = 0;
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+          const int iy = iy0 + a, ix = ix0 + b, ty = ty0 + a * UP, tx = tx0 + b * UP;
+          const bool ok = (unsigned)iy < (unsigned)in_h && (unsigned)ix < (unsigned)in_w && ty < 4 && tx < 4;
+          kv[a][b] = ok ? sk[ty * 4 + tx] : K(0);
+          off[a][b] = ok ? iy * in_w + ix : 0;
+          okm |= (ok ? 1u : 0u) << (a * NT + b);
+        }
+      for (int plane = blockIdx.y; plane < major; plane += gridDim.y) {
+        const T* src = in + (size_t)plane * per_in;
+        // same summation order as the generic loop (rows outer, columns inner), skipped taps add an exact zero
+        K acc = K(0);
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int b = 0; b < NT; ++b) {
+            const K v = K(src[off[a][b]]);
+            acc += ((okm >> (a * NT + b)) & 1u ? v : K(0)) * kv[a][b];
+          }
+        const size_t o = (size_t)plane * per_out + idx;
+        if (addend) acc += K(addend[o]);
+        out[o] = T(acc);
       }
+      continue;
     }
-    if (addend) acc += K(addend[o]);
-    out[o] = T(acc);
+    for (int plane = blockIdx.y; plane < major; plane += gridDim.y) {
+      const T* src = in + (size_t)plane * per_in;
+      K acc = K(0);
+      for (int ty = ty0, iy = iy0; ty < kh; ty += up_y, ++iy) {
+        if (iy < 0 || iy >= in_h) continue;
+        for (int tx = tx0, ix = ix0; tx < kw; tx += up_x, ++ix) {
+          if (ix < 0 || ix >= in_w) continue;
+          const K kv = lds_taps ? sk[ty * kw + tx] : kernel[(kh - 1 - ty) * kw + (kw - 1 - tx)];
+          acc += K(src[(size_t)iy * in_w + ix]) * kv;
+        }
+      }
+      const size_t o = (size_t)plane * per_out + idx;
+      if (addend) acc += K(addend[o]);
+      out[o] = T(acc);
+    }
   }
+}
+
+// grid: x covers one plane's outputs, y strides over planes (<= 64 planes per thread)
+template <typename T, typename K>
+int launch_direct(T* out, const T* in, const K* kernel, const T* addend, int major, int in_h, int in_w, int out_h,
+                  int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_y0,
+                  hipStream_t st, const char* what) {
+  if ((long long)out_h * out_w >= (1LL << 31) || (long long)in_h * in_w >= (1LL << 31))
+    return gg::fail(-2, "upfirdn2d: a single plane has 2^31 or more elements");
+  const unsigned per_out = (unsigned)out_h * (unsigned)out_w;
+  const unsigned gx = (per_out + 255u) / 256u;
+  unsigned gy = (unsigned)major;
+  // enough blocks to fill the chip, but let a thread reuse its tap geometry over several planes when there are many
+  while (gy > 1 && (unsigned long long)gx * gy > 4096ull && gy * 2u > (unsigned)major / 32u) gy = (gy + 1) / 2;
+  if (gy > 65535u) gy = 65535u;
+  const dim3 grid(gx, gy);
+  const bool fir4 = kh == 4 && kw == 4 && up_x == up_y && down_x == down_y;
+  if (fir4 && up_x == 1 && down_x == 2)
+    upfirdn2d_direct<T, K, 1><<<grid, 256, 0, st>>>(out, in, kernel, major, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y,
+                                                     down_x, down_y, pad_x0, pad_y0, addend);
+  else if (fir4 && up_x == 2 && down_x == 1)
+    upfirdn2d_direct<T, K, 2><<<grid, 256, 0, st>>>(out, in, kernel, major, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y,
+                                                     down_x, down_y, pad_x0, pad_y0, addend);
+  else
+    upfirdn2d_direct<T, K, 0><<<grid, 256, 0, st>>>(out, in, kernel, major, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y,
+                                                     down_x, down_y, pad_x0, pad_y0, addend);
+  return gg::launch_status(what);
 }
 
 template <typename T>
@@ -379,9 +452,8 @@ int upfirdn2d_impl(T* out, const T* in, const T* kernel, int major, int in_h, in
     return launch_blur4<false, false>(reinterpret_cast<float*>(out), reinterpret_cast<const float*>(in),
                                       reinterpret_cast<const float*>(kernel), major, in_h, in_w, out_h, out_w, pad_x0,
                                       pad_y0, BlurFuse{}, st);
-  upfirdn2d_direct<T><<<gg::stream_grid(total, 256), 256, 0, st>>>(out, in, kernel, total, in_h, in_w, out_h, out_w,
-                                                                  kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0);
-  return gg::launch_status("upfirdn2d_direct");
+  return launch_direct<T, T>(out, in, kernel, nullptr, major, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y, down_x, down_y,
+                             pad_x0, pad_y0, st, "upfirdn2d_direct");
 }
 
 }  // namespace
@@ -404,11 +476,8 @@ extern "C" int gg_upfirdn2d_add_f32(float* out, const float* in, const float* ke
   const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w + down_x) / down_x;
   if (out_h <= 0 || out_w <= 0 || major == 0) return 0;
   if (!out || !in || !kernel || !addend) return gg::fail(-2, "upfirdn2d_add: null pointer");
-  const long long total = (long long)major * out_h * out_w;
-  upfirdn2d_direct<float><<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(
-      out, in, kernel, total, in_h, in_w, out_h, out_w, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0,
-      addend);
-  return gg::launch_status("upfirdn2d_add");
+  return launch_direct<float, float>(out, in, kernel, addend, major, in_h, in_w, out_h, out_w, kernel_h, kernel_w, up_x,
+                                     up_y, down_x, down_y, pad_x0, pad_y0, gg::as_stream(stream), "upfirdn2d_add");
 }
 
 extern "C" int gg_blur4_fused_f32(float* out, const float* in, const float* kernel, int n, int c, int in_h, int in_w,
@@ -441,11 +510,9 @@ extern "C" int gg_upfirdn2d_f16(unsigned short* out, const unsigned short* in, c
   const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w + down_x) / down_x;
   if (out_h <= 0 || out_w <= 0 || major == 0) return 0;
   if (!out || !in || !kernel) return gg::fail(-2, "upfirdn2d: null pointer");
-  const long long total = (long long)major * out_h * out_w;
-  upfirdn2d_direct<_Float16, float><<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(
-      reinterpret_cast<_Float16*>(out), reinterpret_cast<const _Float16*>(in), kernel, total, in_h, in_w, out_h, out_w,
-      kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0);
-  return gg::launch_status("upfirdn2d_direct");
+  return launch_direct<_Float16, float>(reinterpret_cast<_Float16*>(out), reinterpret_cast<const _Float16*>(in), kernel,
+                                        nullptr, major, in_h, in_w, out_h, out_w, kernel_h, kernel_w, up_x, up_y, down_x,
+                                        down_y, pad_x0, pad_y0, gg::as_stream(stream), "upfirdn2d_direct");
 }
 extern "C" int gg_upfirdn2d_f64(double* out, const double* in, const double* kernel, int major, int in_h, int in_w,
                                 int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0,

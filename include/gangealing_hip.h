@@ -270,9 +270,10 @@ int gg_conv2d_f32(float* y, const float* x, const float* wmat, const float* in_s
  * limbs, accumulated in fp32.  limbs = 2: 3 MFMAs, error ~2^-16 per product; limbs = 3: 6 MFMAs, fp32-class.
  * limbs = 18 (= 16 + 2; ABI 2): two BINARY16 limbs (11 + 11 significand bits, v_mfma_f32_32x32x16_f16), 3 MFMAs,
  * error ~2^-22 per product.  For FORWARD convolutions only: binary16 has no exponent range to spare, so the pack
- * multiplies the weights by 2^8 (the kernels' epilogues divide the fp32 accumulator by 2^8 - exact), the leading
- * limb of an operand is rounded toward zero and saturates at +-65504 (|x| up to ~1.3e5 is still represented exactly
- * by the limb pair; beyond that the result is finite and wrong), and activations below ~1e-7 vanish.  Gradient
+ * multiplies the weights by 2^8 (the kernels' epilogues divide the fp32 accumulator by 2^8 - exact) and the leading
+ * limb of an operand is rounded toward zero, so it saturates at +-65504 instead of overflowing.  Operand range
+ * (activation times in_scale): full precision for |x| <= 65504; 2^-12 up to ~1.3e5; beyond that the LOW limb
+ * overflows and the output is inf / NaN (loud, never silently wrong); activations below ~1e-7 vanish.  Gradient
  * tensors span more than that: pass limbs = 2 for them (gg_conv3x3_masked_dgrad_f32 and the weight-gradient entry
  * points do not take 18).  A weight pack made with limbs = 18 must be used with limbs = 18 and vice versa.
  * Weights come pre-split from gg_conv_pack_weight_split: bf16 planes wsplit[limb][g][co][k], K ordered

@@ -236,10 +236,10 @@ def test_pointwise_small_cin_wgrad(spec, mode_name, cuda, precision):
                                atol=2e-5 * float(ref.abs().max()))
 
 
-def test_fp16_limbs_saturate_and_keep_small_values(cuda, precision):
-    """The fp16x3 mode's binary16 limbs: operands beyond +-65504 saturate (finite, wrong - never inf / NaN), tiny
-    activations survive as subnormals to ~1e-7 absolute, and a gradient convolution (grad=True) keeps bf16 limbs, whose
-    exponent range is fp32's."""
+def test_fp16_limbs_range(cuda, precision):
+    """The fp16x3 mode's binary16 limbs: operands up to +-65504 keep the full 2^-22 pair precision; beyond +-1.3e5 the
+    low limb overflows and the result is inf / NaN (loud, not silently wrong); tiny activations survive as subnormals to
+    ~1e-7 absolute; a gradient convolution (grad=True) keeps bf16 limbs, whose exponent range is fp32's."""
     from gangealing_amd.op import conv_mfma as cm
     g = torch.Generator(device='cpu').manual_seed(7)
     n, cin, cout, h = 2, 64, 64, 16
@@ -249,8 +249,11 @@ def test_fp16_limbs_saturate_and_keep_small_values(cuda, precision):
     precision('fp32')
     ref = cm.conv_forward(x, pw, n, 1, cin, cout, 3, 1, 1, 0)
     precision('fp16x3')
-    big = cm.conv_forward(x * 1e7, pw, n, 1, cin, cout, 3, 1, 1, 0)             # |x| up to ~4e7: saturates
-    assert bool(torch.isfinite(big).all())
+    top = 6.0e4 / float(x.abs().max())
+    large = cm.conv_forward(x * top, pw, n, 1, cin, cout, 3, 1, 1, 0)           # |x| up to 6e4: inside the range
+    assert float((large - ref * top).abs().max() / (ref.abs().max() * top)) <= 1e-5
+    big = cm.conv_forward(x * 1e7, pw, n, 1, cin, cout, 3, 1, 1, 0)             # |x| up to ~4e7: out of range
+    assert not bool(torch.isfinite(big).all())
     small = cm.conv_forward(x * 1e-3, pw, n, 1, cin, cout, 3, 1, 1, 0)          # low limb in the subnormal range
     assert float((small - ref * 1e-3).abs().max()) <= 5e-7
     tiny_grad = cm.conv_forward(x * 1e-12, pw, n, 1, cin, cout, 3, 1, 1, 0, grad=True)     # bf16 limbs: full range
