@@ -1694,16 +1694,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
   float rd[16], rx[16];
   unsigned mask_d = 0, mask_x = 0;
+  // (image, position inside it) of this thread's pixel, advanced by one slab per call (no 64-bit division per slab)
+  int kn;
+  unsigned krem;
+  {
+    const long long k = kbeg + kl;
+    kn = (int)(k / ohw);
+    krem = (unsigned)(k - (long long)kn * ohw);
+  }
   auto load_slab = [&](long long k0) {
     const long long k = k0 + kl;
     const bool ok = k < kend;
     int n = 0, oy = 0, ox = 0;
     if (ok) {
-      n = (int)(k / ohw);
-      const int rem = (int)(k - (long long)n * ohw);
-      oy = rem / a.ow;
-      ox = rem - oy * a.ow;
+      n = kn;
+      oy = (int)(krem / (unsigned)a.ow);
+      ox = (int)(krem - (unsigned)oy * (unsigned)a.ow);
     }
+    krem += WBK;
+    while (krem >= (unsigned)ohw) { krem -= (unsigned)ohw; ++kn; }
     const float* dyp = a.dy + ((size_t)(n * a.groups + g) * a.cout_g) * ohw + (size_t)oy * a.ow + ox;
     const float* xp = a.x + ((size_t)(n * a.groups + g) * a.cin_g) * hw;
     const int by = oy * a.stride, bx = ox * a.stride;
@@ -1831,16 +1840,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradArgs a
   float4 rd[4];
   float rx[4][4];
   unsigned mx = 0;                 // validity bits of rx
+  // (image, position inside the image) of this thread's first pixel, advanced by BKS per slab: the slab loop used to
+  // decompose the 64-bit pixel index with a 64-bit division per slab - more VALU work than the slab's conversions
+  int kn;
+  unsigned krem;
+  {
+    const long long k = kbeg + grp * 4;
+    kn = (int)(k / ohw);
+    krem = (unsigned)(k - (long long)kn * ohw);
+  }
   auto load_slab = [&](long long k0) {
     const long long k = k0 + grp * 4;                 // first of this thread's 4 pixels (same image row)
     const bool ok = k < kend;
     int n = 0, oy = 0, ox = 0;
     if (ok) {
-      n = (int)(k / ohw);
-      const int rem = (int)(k - (long long)n * ohw);
-      oy = rem / a.ow;
-      ox = rem - oy * a.ow;
+      n = kn;
+      oy = (int)(krem / (unsigned)a.ow);
+      ox = (int)(krem - (unsigned)oy * (unsigned)a.ow);
     }
+    krem += BKS;
+    while (krem >= (unsigned)ohw) { krem -= (unsigned)ohw; ++kn; }
     const float* dyp = a.dy + ((size_t)(n * a.groups + g) * a.cout_g) * ohw + (size_t)oy * a.ow + ox;
     const float* xp = a.x + ((size_t)(n * a.groups + g) * a.cin_g) * hw;
     mx = 0;

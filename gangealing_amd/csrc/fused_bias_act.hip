@@ -27,10 +27,12 @@ __global__ __launch_bounds__(256) void fused_bias_act_kernel(
     T* __restrict__ out, const T* __restrict__ x, const T* __restrict__ b, const T* __restrict__ ref,
     int mode, T alpha, T scale, long long n_items, long long step_b, int size_b) {
   const long long stride = (long long)gridDim.x * blockDim.x;
+  const bool small = n_items * VEC < (1LL << 31) && step_b < (1LL << 31);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += stride) {
     const long long e = i * VEC;
     T bias = T(0);
-    if (b) bias = b[(e / step_b) % size_b];
+    // (32-bit index math whenever the tensor allows it: a 64-bit division is ~100 VALU instructions per lane)
+    if (b) bias = small ? b[((unsigned)e / (unsigned)step_b) % (unsigned)size_b] : b[(e / step_b) % size_b];
     if (VEC == 4) {
       Vec4<T> xv = *reinterpret_cast<const Vec4<T>*>(x + e);
       Vec4<T> rv;
@@ -151,12 +153,17 @@ __global__ __launch_bounds__(256) void noise_bias_act_kernel(float* __restrict__
                                                              const float* __restrict__ b, float alpha, float scale,
                                                              long long n_vec, int c, long long hw) {
   const float nw = noise_weight[0];
+  const bool small = n_vec * 4 < (1LL << 31) && hw < (1LL << 31);
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
     const long long e = i * 4;
-    const long long plane = e / hw;                 // n * c + ch
-    const long long pix = e - plane * hw;
-    const long long n = plane / c;
+    long long plane, pix, n;                        // plane = n * c + ch
+    if (small) {
+      const unsigned pl = (unsigned)e / (unsigned)hw;
+      plane = pl; pix = (unsigned)e - pl * (unsigned)hw; n = pl / (unsigned)c;
+    } else {
+      plane = e / hw; pix = e - plane * hw; n = plane / c;
+    }
     const int ch = (int)(plane - n * c);
     const float4 xv = *reinterpret_cast<const float4*>(x + e);
     const float4 nv = *reinterpret_cast<const float4*>(noise + n * hw + pix);
