@@ -706,6 +706,13 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   U4 wv[TPI][LIMBS][EPT / 8];
 
   auto load_patch = [&](int chunk) {
+#ifdef GG_EXP_PATCH_NO_PLOAD     // measurement build: no activation loads
+    if (chunk >= 0) {
+#pragma unroll
+      for (int j = 0; j < BKS; ++j) xa[j] = 1.f + j;
+      return;
+    }
+#endif
     const int cbase = __builtin_amdgcn_readfirstlane(chunk * BKS * hw * 4);
 #pragma unroll
     for (int j = 0; j < BKS; ++j) xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
@@ -714,6 +721,26 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
 #pragma unroll
       for (int j = 0; j < BKS; ++j) xm[MASK ? j : 0] = buffer_load_f32(mr, pvoff, cbase + j * hw * 4);
       xml = buffer_load_f32(mr, lvoff, cbase);
+    }
+  };
+  // The same loads in slices [j0, j1) (+ the left-over element with `tail`): the pipelined tile issues the next chunk's
+  // patch a few channels per tap instead of all 33 loads per lane at the top of the chunk.  A CU keeps only a limited
+  // number of requests in flight, so the burst held every wave in its VMEM issue phase - in front of the chunk's first
+  // MFMA - for 1.4 - 4 thousand cycles per chunk (r03 session O: 7 - 16 % of the launch).
+  auto load_patch_slice = [&](int chunk, int j0, int j1, bool tail) {
+#ifdef GG_EXP_PATCH_NO_PLOAD
+    if (chunk >= 0) return;
+#endif
+    const int cbase = __builtin_amdgcn_readfirstlane(chunk * BKS * hw * 4);
+#pragma unroll
+    for (int j = 0; j < BKS; ++j)
+      if (j >= j0 && j < j1) {
+        xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
+        if (MASK) xm[MASK ? j : 0] = buffer_load_f32(mr, pvoff, cbase + j * hw * 4);
+      }
+    if (tail) {
+      xl = buffer_load_f32(xr, lvoff, cbase);
+      if (MASK) xml = buffer_load_f32(mr, lvoff, cbase);
     }
   };
   auto store_patch = [&](int chunk) {
@@ -760,6 +787,17 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   // interval i of a chunk covers taps [i * TPI, i * TPI + TPI)
   auto load_w = [&](int chunk, int interval) {
     if (!w_thr) return;
+#ifdef GG_EXP_PATCH_NO_WLOAD     // measurement build: no weight loads
+    if (chunk >= 0) {
+#pragma unroll
+      for (int u = 0; u < TPI; ++u)
+#pragma unroll
+        for (int l = 0; l < LIMBS; ++l)
+#pragma unroll
+          for (int q = 0; q < EPT / 8; ++q) wv[u][l][q] = U4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+      return;
+    }
+#endif
 #pragma unroll
     for (int u = 0; u < TPI; ++u) {
       const int soff = __builtin_amdgcn_readfirstlane(((interval * TPI + u) * a.cin_g + chunk * BKS) * 2);
@@ -847,7 +885,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
         store_patch(chunk);
         store_w(0);
         load_w(chunk, 1);
-        if (chunk + 1 < chunk1) load_patch(chunk + 1);
+        const bool more = chunk + 1 < chunk1;
         __syncthreads();
         read_frag(fa0, fb0, 0, 0, 0);
 #pragma unroll
@@ -858,8 +896,10 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
           if (t < 8) {
             store_w(buf ^ 1);                                    // slab t + 1
             if (t + 2 < 9) load_w(chunk, t + 2);
-            else if (chunk + 1 < chunk1) load_w(chunk + 1, 0);
+            else if (more) load_w(chunk + 1, 0);
           }
+          // next chunk's patch: six channels per tap over taps 0 .. 5 (the last ones land three taps before their use)
+          if (more && t < 6) load_patch_slice(chunk + 1, 6 * t, 6 * t + 6 < BKS ? 6 * t + 6 : BKS, t == 5);
           read_frag(fa1, fb1, buf, tapoff, 1);
           // (the scheduler otherwise sinks each fetch down to its first use to shorten the live ranges, which puts
           // the LDS round trip back in front of the MFMAs)
@@ -1013,6 +1053,9 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
           t = v4.z + anw * nz.z + ab; v4.z = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
           t = v4.w + anw * nz.w + ab; v4.w = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
         }
+#ifdef GG_EXP_PATCH_EPI_NOSTORE  // measurement build: the whole epilogue except its global stores
+        if (v4.x == 1234.5678f && v4.y == 8765.4321f)
+#endif
         *reinterpret_cast<float4*>(a.y + (size_t)(ochan0 + co) * hw + (size_t)oy * a.w + ox) = v4;
       }
     }
@@ -1136,6 +1179,17 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
     for (int j = 0; j < 16; ++j) xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
     xl = buffer_load_f32(xr, lvoff, cbase);
   };
+  // sliced form of load_patch (see conv3x3_patch_kernel): channels [j0, j1) of the lane's 16 (+ the left-over element)
+  auto load_patch_slice = [&](int chunk, int j0, int j1, bool tail) {
+#ifdef GG_EXP_CONVT_NO_PLOAD
+    if (chunk >= 0) return;
+#endif
+    const int cbase = __builtin_amdgcn_readfirstlane(chunk * BKS * hw * 4);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j >= j0 && j < j1) xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
+    if (tail) xl = buffer_load_f32(xr, lvoff, cbase);
+  };
   auto store_patch = [&](int chunk) {
     if (pin) {
       if (IN_SCALE) {
@@ -1228,13 +1282,16 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
       __syncthreads();
       store_patch(chunk);
-      if (chunk + 1 < chunk1) load_patch(chunk + 1);
+      const bool more = chunk + 1 < chunk1;
+      // 8-wave tile: the next chunk's patch is issued in slices inside the first two intervals (below); the 4-wave
+      // tile (two blocks per CU, one tap per interval) keeps the single burst
+      if (more && TPI == 1) load_patch(chunk + 1);
 #pragma unroll
       for (int iv = 0; iv < 9 / TPI; ++iv) {
         store_w();
         __syncthreads();
         if (iv + 1 < 9 / TPI) load_w(chunk, iv + 1);
-        else if (chunk + 1 < chunk1) load_w(chunk + 1, 0);
+        else if (more) load_w(chunk + 1, 0);
         // (tap, k-step) units of the interval, software-pipelined: the fragments of unit q + 1 are fetched before the
         // MFMAs of unit q, so that an LDS round trip is covered by 6 (two limbs) MFMAs per wave instead of being
         // waited for in front of them (with 255 registers in use the scheduler otherwise fetches just in time)
@@ -1263,6 +1320,10 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
           const int slot = PF ? (q & 1) : 0;
           if (!PF) fetch(0, q);
           else if (q + 1 < UNITS) fetch(slot ^ 1, q + 1);
+          if (TPI == 3 && more) {            // 2 channels per unit in interval 0, 1 per unit in the first 4 units of interval 1
+            if (iv == 0) load_patch_slice(chunk + 1, 2 * q, 2 * q + 2, false);
+            else if (iv == 1 && q < 4) load_patch_slice(chunk + 1, 12 + q, 13 + q, q == 3);
+          }
           if (PF) __builtin_amdgcn_sched_barrier(0);
           const int t = iv * TPI + q / (BKS / 16);
           const int ky = t / 3, kx = t - ky * 3;
@@ -2582,7 +2643,8 @@ bool patch_geometry(const ConvArgs& a, int tpix, int& tw_log2, int limbs = 2) {
   const int w = a.w, h = a.h;
   if (w < 16 || (w & (w - 1)) != 0) return false;
   if ((long long)a.cin_g * h * w * 4 >= (1LL << 31)) return false;        // buffer-resource addressing
-  const int tw_max = limbs == 3 ? 32 : 64;
+  static const int tw_env = env_int("GG_PATCH_TW", 64);      // measurement override: narrower, taller tiles
+  const int tw_max = limbs == 3 ? 32 : tw_env;
   int tw = w < tw_max ? w : tw_max;
   tw_log2 = 0;
   while ((1 << tw_log2) < tw) ++tw_log2;

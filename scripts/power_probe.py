@@ -37,7 +37,7 @@ def one_limb(t, mode):
 
 
 rows = []
-for mode in ('bf16x3', 'fp16x3', 'bf16'):
+for mode in os.environ.get('PROBE_MODES', 'bf16x3,fp16x3,bf16').split(','):
     cm.set_precision(mode)
     for (cin, cout, h) in ((512, 512, 64), (128, 128, 256)):
         g = torch.Generator(device='cpu').manual_seed(1)
@@ -46,11 +46,14 @@ for mode in ('bf16x3', 'fp16x3', 'bf16'):
         s_in = torch.ones(N, cin, device=dev)
         s_out = torch.ones(N, cout, device=dev)
         flops = 2.0 * N * cin * cout * 9 * h * h
-        for data, x, w in (('random fp32', x0, w0),
-                           ('one-limb values (low limb planes zero)', one_limb(x0, mode), one_limb(w0, mode)),
-                           ('x random, w zero', x0, torch.zeros_like(w0)),
-                           ('x zero, w random', torch.zeros_like(x0), w0),
-                           ('all zero', torch.zeros_like(x0), torch.zeros_like(w0))):
+        cases = (('random fp32', x0, w0),
+                 ('one-limb values (low limb planes zero)', one_limb(x0, mode), one_limb(w0, mode)),
+                 ('x random, w zero', x0, torch.zeros_like(w0)),
+                 ('x zero, w random', torch.zeros_like(x0), w0),
+                 ('all zero', torch.zeros_like(x0), torch.zeros_like(w0)))
+        if os.environ.get('PROBE_CASES'):           # e.g. "0,4" under the counter passes
+            cases = tuple(cases[int(i)] for i in os.environ['PROBE_CASES'].split(','))
+        for data, x, w in cases:
             wm = cm.PackedWeight(w, 1, cout, cin, 3, 0, 0)
             t = timeit(lambda: cm.conv_forward(x, wm, N, 1, cin, cout, 3, 1, 1, 0, in_scale=s_in, out_scale=s_out))
             rows.append(dict(mode=mode, layer=f'{cin}->{cout} @{h}^2', data=data, ms=round(t, 4),
