@@ -1024,17 +1024,36 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   }
   const float anw = (a.act && a.act_noise) ? a.act_noise_w[0] : 0.f;
   __syncthreads();
+  // LDS reads are grouped in front of the LDS writes / global stores that follow them: the parameter arrays and the
+  // staging rows live in the same LDS array, so the compiler orders every read after the preceding write and waits for it
+  // - one LDS round trip per accumulator register and per store in the interleaved form (24 per 32-channel sub-tile)
+  const int pq = wpix * 64 + (lane & 15) * 4;                 // this lane's four pixels in every store of the loop below
+  const float4 nz = *reinterpret_cast<const float4*>(ep_noise + pq);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    float4 sc4[4], bi4[4];
+    float abv[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      sc4[q] = *reinterpret_cast<const float4*>(ep_scale + (wco * MI + i) * 32 + 8 * q + 4 * (lane >> 5));
+      bi4[q] = *reinterpret_cast<const float4*>(ep_bias + (wco * MI + i) * 32 + 8 * q + 4 * (lane >> 5));
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) abv[it] = ep_abias[(wco * MI + i) * 32 + it * 4 + (lane >> 4)];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int c = (wco * MI + i) * 32 + row;
-      const float sc = ep_scale[c], bi = ep_bias[c];
+      const float4 s4 = sc4[r >> 2], b4 = bi4[r >> 2];
+      const float sc = (r & 3) == 0 ? s4.x : (r & 3) == 1 ? s4.y : (r & 3) == 2 ? s4.z : s4.w;
+      const float bi = (r & 3) == 0 ? b4.x : (r & 3) == 1 ? b4.y : (r & 3) == 2 ? b4.z : b4.w;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) stage[row * 64 + j * 32 + (lane & 31)] = acc[i][j][r] * sc + bi;
     }
     wave_lds_sync();                // the staging rows are this wave's own
+    float4 v4s[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+      v4s[it] = *reinterpret_cast<const float4*>(stage + (it * 4 + (lane >> 4)) * 64 + (lane & 15) * 4);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int idx = it * 64 + lane;
@@ -1043,10 +1062,9 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       const int p = wpix * 64 + c4 * 4;
       const int oy = y0 + (p >> tw_log2), ox = x0 + (p & (TW - 1));
       if (co < a.cout_g) {
-        float4 v4 = *reinterpret_cast<const float4*>(stage + row * 64 + c4 * 4);
+        float4 v4 = v4s[it];
         if (a.act) {             // (NoiseInjection +) bias + leaky ReLU (networks.py:291-298, 344-350; fused_act.py:74-97)
-          const float4 nz = *reinterpret_cast<const float4*>(ep_noise + p);
-          const float ab = ep_abias[(wco * MI + i) * 32 + row];
+          const float ab = abv[it];
           float t;
           t = v4.x + anw * nz.x + ab; v4.x = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
           t = v4.y + anw * nz.y + ab; v4.y = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
@@ -1408,6 +1426,14 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
 #ifdef GG_EXP_CONVT_EPI_NOLDS
   float exp_sum = 0.f;
 #endif
+  // the lane's 16 channel scales / biases in registers before the passes (LDS reads interleaved with the staging writes
+  // are ordered after them by the compiler: one round trip each)
+  float4 sc4[4], bi4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sc4[q] = *reinterpret_cast<const float4*>(ep_scale + wco * 32 + 8 * q + 4 * (lane >> 5));
+    bi4[q] = *reinterpret_cast<const float4*>(ep_bias + wco * 32 + 8 * q + 4 * (lane >> 5));
+  }
 #pragma unroll
   for (int py = 0; py < 2; ++py) {
 #pragma unroll
@@ -1416,7 +1442,8 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
       for (int rr = 0; rr < 4; ++rr) {
         const int r = q4 * 4 + rr;
         const int lrow = rr + 4 * (lane >> 5);
-        const float sc = ep_scale[wco * 32 + lrow + 8 * q4], bi = ep_bias[wco * 32 + lrow + 8 * q4];
+        const float sc = rr == 0 ? sc4[q4].x : rr == 1 ? sc4[q4].y : rr == 2 ? sc4[q4].z : sc4[q4].w;
+        const float bi = rr == 0 ? bi4[q4].x : rr == 1 ? bi4[q4].y : rr == 2 ? bi4[q4].z : bi4[q4].w;
 #ifdef GG_EXP_CONVT_EPI_NOLDS    // measurement build: no LDS transposition (the stores carry garbage)
         for (int j = 0; j < NJ; ++j) exp_sum += acc[py * 2 + 0][j][r] * sc + acc[py * 2 + 1][j][r] * sc + bi;
 #else
@@ -1433,15 +1460,22 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
       wave_lds_sync();
 #endif
       if (vec) {
+        // the pass's four LDS reads first, then its four stores (one LDS round trip per pass instead of four)
+        f32x4 v4s[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int idx = it * 64 + lane;
+#ifdef GG_EXP_CONVT_EPI_NOLDS
+          v4s[it] = f32x4{exp_sum, exp_sum, exp_sum, exp_sum};
+#else
+          v4s[it] = *reinterpret_cast<const f32x4*>(stage + (idx >> 5) * 128 + (idx & 31) * 4);
+#endif
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int idx = it * 64 + lane;
           const int lrow = idx >> 5, s = (idx & 31) * 4;
-#ifdef GG_EXP_CONVT_EPI_NOLDS
-          const f32x4 v4 = f32x4{exp_sum, exp_sum, exp_sum, exp_sum};
-#else
-          const f32x4 v4 = *reinterpret_cast<const f32x4*>(stage + lrow * 128 + s);
-#endif
+          const f32x4 v4 = v4s[it];
           const int p = wpix * 64 + (s >> 1);
           const int oy = 2 * (y0 + (p >> tw_log2)) + py - pad, ox = 2 * (x0 + (p & (TW - 1))) - pad;
           const int co = co0 + wco * 32 + lrow + 8 * q4;
