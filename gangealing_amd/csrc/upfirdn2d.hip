@@ -237,12 +237,19 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
     if (PRO) v *= (gg::buffer_load_f32(rsrc, vo, so) > 0.f) ? f.gain : f.gain * f.alpha;
     return v;
   };
-  auto finish = [&](float acc, int oy) {
+  // noise of output row oy at this lane's column (EPI); loaded with the rows, BEFORE the strip's first store: VMEM loads
+  // and stores share the in-order vmcnt, so a load issued after a store is waited for together with the store's
+  // acknowledgement (the round-2 form loaded the noise inside `finish`: one store round trip per output row)
+  auto noise_at = [&](int oy) -> float {
+    const bool row_ok = oy < out_h;
+    return gg::buffer_load_f32(nz, row_ok ? out_off : gg::kOobOffset, row_ok ? oy * out_w * 4 : 0);
+  };
+  auto finish = [&](float acc, int oy, float noise) {
     const bool row_ok = oy < out_h;
     const unsigned vo = row_ok ? out_off : gg::kOobOffset;
     const int so = row_ok ? oy * out_w * 4 : 0;
     if (EPI) {
-      const float t = acc + nw * gg::buffer_load_f32(nz, vo, so) + ab;
+      const float t = acc + nw * noise + ab;
       acc = (t > 0.f ? t : t * f.alpha) * f.gain;
     }
     gg::buffer_store_f32(acc, dst, vo, so);
@@ -252,18 +259,19 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
       const float s1 = wave_shl1(v), s2 = wave_shl1(s1), s3 = wave_shl1(s2);
       return v * kb[0] + s1 * kb[1] + s2 * kb[2] + s3 * kb[3];
     };
-    float h0 = hpass(fetch(iy0)), h1 = hpass(fetch(iy0 + 1)), h2 = hpass(fetch(iy0 + 2));
-    for (int rr = 0; rr < SROWS; rr += 8) {
-      if (oy0 + rr >= out_h) break;
-      float nv[8];
+    // every load of the strip (3 + SROWS input rows, SROWS noise rows) is issued before its first store
+    const float r0 = fetch(iy0), r1 = fetch(iy0 + 1), r2 = fetch(iy0 + 2);
+    float nv[SROWS], nzv[SROWS];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) nv[u] = fetch(iy0 + 3 + rr + u);
+    for (int u = 0; u < SROWS; ++u) nv[u] = fetch(iy0 + 3 + u);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float h3 = hpass(nv[u]);
-        finish(h0 * ka[0] + h1 * ka[1] + h2 * ka[2] + h3 * ka[3], oy0 + rr + u);
-        h0 = h1; h1 = h2; h2 = h3;
-      }
+    for (int u = 0; u < SROWS; ++u) nzv[u] = EPI ? noise_at(oy0 + u) : 0.f;
+    float h0 = hpass(r0), h1 = hpass(r1), h2 = hpass(r2);
+#pragma unroll
+    for (int u = 0; u < SROWS; ++u) {
+      const float h3 = hpass(nv[u]);
+      finish(h0 * ka[0] + h1 * ka[1] + h2 * ka[2] + h3 * ka[3], oy0 + u, nzv[u]);
+      h0 = h1; h1 = h2; h2 = h3;
     }
     return;
   }
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc += w[r][c] * kf[r * 4 + c];
-    finish(acc, oy0 + rr);
+    finish(acc, oy0 + rr, EPI ? noise_at(oy0 + rr) : 0.f);
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -445,7 +453,6 @@ int upfirdn2d_impl(T* out, const T* in, const T* kernel, int major, int in_h, in
   if (out_h <= 0 || out_w <= 0 || major == 0) return 0;
   if (!out || !in || !kernel) return gg::fail(-2, "upfirdn2d: null pointer");
   hipStream_t st = gg::as_stream(stream);
-  const long long total = (long long)major * out_h * out_w;
   const bool blur4 = sizeof(T) == 4 && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4 &&
                      out_h >= 24 && out_w >= 24;
   if (blur4)
