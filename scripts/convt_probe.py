@@ -29,9 +29,12 @@ def timeit(fn):
     return s.elapsed_time(e) / ITERS
 
 
-for (name, cin, cout, h, mode) in (('upconv 32->65', 512, 512, 32, 1), ('upconv 64->129', 512, 256, 64, 1),
-                                   ('upconv 128->257', 256, 128, 128, 1), ('s2 corr 129->64', 256, 512, 129, 0),
-                                   ('s2 corr 257->128', 128, 256, 257, 0)):
+LAYERS = (('upconv 32->65', 512, 512, 32, 1), ('upconv 64->129', 512, 256, 64, 1),
+          ('upconv 128->257', 256, 128, 128, 1), ('s2 corr 129->64', 256, 512, 129, 0),
+          ('s2 corr 257->128', 128, 256, 257, 0))
+if os.environ.get('CONVT_ONLY'):                # substring filter (counter passes)
+    LAYERS = tuple(l for l in LAYERS if os.environ['CONVT_ONLY'] in l[0])
+for (name, cin, cout, h, mode) in LAYERS:
     g = torch.Generator(device='cpu').manual_seed(1)
     x0 = torch.randn(N, cin, h, h, generator=g).to(dev)
     w0 = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(dev)
