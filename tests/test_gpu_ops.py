@@ -94,6 +94,23 @@ def test_upfirdn2d_hot_shapes_vs_oracle(cuda):
         close(out, np_ops.upfirdn2d(x, k * gain, pad=(pad[0], pad[1], pad[0], pad[1])), 1e-5)
 
 
+def test_upfirdn2d_resampling_paths_vs_oracle(cuda):
+    """The generic kernel's constant-trip-count paths (4x4 taps, up 2 / down 2) and its plane loop: odd and non-square
+    planes, the ToRGB / ResBlock-skip pads, more planes than the grid's y extent covers in one pass."""
+    from gangealing_amd.op import upfirdn2d
+    from oracle import np_ops
+    rs = np.random.RandomState(3)
+    k = (np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0).astype(np.float32)
+    for (shape, up, down, pad) in [((2, 3, 16, 16), 2, 1, (2, 1)), ((1, 2, 17, 13), 2, 1, (2, 1)), ((1, 1, 1, 1), 2, 1, (2, 1)),
+                                   ((2, 5, 32, 32), 1, 2, (1, 1)), ((1, 3, 33, 21), 1, 2, (1, 1)), ((1, 2, 15, 64), 1, 2, (2, 2)),
+                                   ((1, 2, 16, 16), 1, 2, (0, 0)), ((3, 700, 8, 8), 1, 2, (1, 1)), ((3, 700, 4, 4), 2, 1, (2, 1)),
+                                   ((1, 2, 9, 11), 2, 2, (2, 1))]:
+        x = rs.randn(*shape).astype(np.float32)
+        kk = k * (up * up)
+        out = upfirdn2d(T(x, cuda), T(kk, cuda), up=up, down=down, pad=pad)
+        close(out, np_ops.upfirdn2d(x, kk, up=(up, up), down=(down, down), pad=(pad[0], pad[1], pad[0], pad[1])), 1e-5)
+
+
 def test_upfirdn2d_f64_gradcheck(cuda):
     from gangealing_amd.op import upfirdn2d
     k = torch.rand(4, 4, dtype=torch.float64, device=cuda)
