@@ -442,6 +442,14 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
   const int chan0 = (pn * a.groups + g) * a.cin_g;
   const float* xg = a.x + (size_t)chan0 * hw;
   const float* sg = IN_SCALE ? a.in_scale + chan0 : nullptr;
+  // The gather through ONE buffer resource over the whole input (when it is smaller than 2 GB): lane offset = the
+  // pixel's byte offset (its image included: the lanes of a wave may straddle images), scalar offset = the channel.
+  // The pointer form spends two 64-bit VALU adds per loaded element on addresses - a fifth of the VALU work of a
+  // kernel whose gather is re-done for every tap.
+  const long long x_bytes = (long long)a.batch * a.groups * a.cin_g * hw * 4;
+  const bool xbuf = x_bytes < (1LL << 31);
+  const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(a.x, xbuf ? (int)x_bytes : 0);
+  const int khalf_u = __builtin_amdgcn_readfirstlane(khalf);          // tid / TPIX is wave-uniform (TPIX % 64 == 0)
   // ---- weight rows: row (tid >> 1), 16-k part (tid & 1)
   const int wrow = (tid >> 1) & (TCO - 1), wpart = tid & 1;
   const bool w_thr = tid < 2 * TCO;                 // the first 256 threads move the weight slab
@@ -473,10 +481,17 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
     const int iy = base_y + dy, ix = base_x + dx;
     x_ok = m_ok & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
     const int cbase = ci0 + khalf * EPT;
-    const float* src = xg + (x_ok ? (size_t)cbase * hw + iy * a.w + ix : 0);
-    const int step = x_ok ? hw : 0;
+    if (xbuf) {
+      const unsigned vo = x_ok ? (unsigned)(chan0 * hw + iy * a.w + ix) * 4u : kOobOffset;
+      const int so = __builtin_amdgcn_readfirstlane((ci0 + khalf_u * EPT) * hw * 4);
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) xa[j] = src[(size_t)j * step];
+      for (int j = 0; j < EPT; ++j) xa[j] = buffer_load_f32(xrs, vo, so + j * hw * 4);
+    } else {
+      const float* src = xg + (x_ok ? (size_t)cbase * hw + iy * a.w + ix : 0);
+      const int step = x_ok ? hw : 0;
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) xa[j] = src[(size_t)j * step];
+    }
     if (IN_SCALE) {
       const float4* s4 = reinterpret_cast<const float4*>(sg + cbase);
 #pragma unroll
@@ -2481,6 +2496,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ 
   const int C = a.groups * a.cout_g;
   const float anw = (a.act && a.act_noise) ? a.act_noise_w[0] : 0.f;
   const long long gstride = (long long)gridDim.x * blockDim.x;
+  const bool small = nvec * VEC < (1LL << 31);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gstride) {
     const long long e = i * VEC;
     float v[VEC];
@@ -2496,13 +2512,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ 
       for (int sidx = 1; sidx < splits; ++sidx) t += part[(size_t)sidx * stride + e];
       v[0] = t;
     }
-    const long long plane = e / ohw;
-    const int c = (int)(plane % C);
+    // (32-bit index math when the tensor allows it: each 64-bit division is ~100 VALU instructions)
+    long long plane, n, p;
+    int c;
+    if (small) {
+      const unsigned pl = (unsigned)e / (unsigned)ohw, nn = pl / (unsigned)C;
+      plane = pl; n = nn; c = (int)(pl - nn * (unsigned)C); p = (unsigned)e - pl * (unsigned)ohw;
+    } else {
+      plane = e / ohw; n = plane / C; c = (int)(plane - n * C); p = e - plane * ohw;
+    }
     const float sc = a.acc_scale * (a.out_scale ? a.out_scale[plane] : 1.f), bi = a.bias ? a.bias[c] : 0.f;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) v[q] = v[q] * sc + bi;
     if (a.act) {
-      const long long n = plane / C, p = e - plane * ohw;
       const float ab = a.act_bias ? a.act_bias[c] : 0.f;
 #pragma unroll
       for (int q = 0; q < VEC; ++q) {
