@@ -80,7 +80,9 @@ GRAD_FACTOR = 4.0                        # HIP-path error allowed as a multiple 
 # Round 3: the library has no float atomics any more, so these errors are exactly reproducible run to run; the floors
 # were re-measured (profiles/parity_r03.json: worst flow-stage / latent / generator gradient 9.7e-4 fp32, 3.3e-3
 # bf16x3; perceptual-loss input gradient 1.8e-3 / 3.9e-3) and tightened from 5e-3 / 2e-2 to 3e-3 / 6e-3.
-GRAD_FLOOR = {'fp32': (3e-3, 3e-3), 'bf16x3': (6e-3, 6e-3), 'fp16x3': (6e-3, 6e-3)}
+# fp16x3 (the benched arithmetic): its FORWARD is fp32-class, so the branch pattern - which is what these floors are about -
+# is the exact-fp32 kernels'; it gets their floors (measured worst: flow stage 6.3e-4, latent 3.7e-4, generator 7e-4)
+GRAD_FLOOR = {'fp32': (3e-3, 3e-3), 'bf16x3': (6e-3, 6e-3), 'fp16x3': (3e-3, 3e-3)}
 # the similarity stage additionally receives gradient through MipmapWarp's level selection, where a similarity warp
 # makes the four neighbour distances EXACTLY tied in real arithmetic: arg-max (and with it the sub-gradient) is decided
 # by last-ulp noise of the grid in every implementation, the reference's float32 and float64 runs included
