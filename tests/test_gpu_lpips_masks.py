@@ -124,6 +124,12 @@ def test_lpips_gradient_is_exact_once_branch_decisions_are_pinned(lp, mode, cuda
     # the decisions themselves: only a handful of the 6.6 M units sit close enough to a kink to flip
     assert out[False]['relu_flips'] + out[False]['pool_flips'] <= (16 if mode == 'fp32' else 128), out[False]
     # with the reference's decisions the gradient is the reference's, to the rounding of 13 layers of arithmetic
-    bound = {'fp32': 1e-5, 'bf16x3': 1e-4, 'fp16x3': 1e-4}[mode]              # measured: 3.5e-6 / 5.7e-5 (un-pinned: 1.8e-3 / 3.9e-3)
+    # measured: fp32 3.5e-6, bf16x3 5.7e-5, fp16x3 9.3e-6 (the backward of fp16x3 runs on bf16 limbs; un-pinned: 1.8e-3 /
+    # 3.9e-3 / 9.3e-6)
+    bound = {'fp32': 1e-5, 'bf16x3': 1e-4, 'fp16x3': 2e-5}[mode]
     assert out[True]['rel_l2_vs_reference_fp32'] <= bound, out
     assert out[True]['rel_l2_vs_reference_fp64'] <= 2 * bound, out
+    if mode == 'fp16x3':
+        # the benched arithmetic on this fixture: its single differing ReLU decision is inconsequential, so even the
+        # UN-pinned gradient is the reference's (the library is bitwise reproducible: this holds on every run)
+        assert out[False]['rel_l2_vs_reference_fp32'] <= bound, out
