@@ -541,9 +541,11 @@ class Generator(nn.Module):
             latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
                                 styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
         if grad_latents is not None and latent.requires_grad:
-            lat = [latent[:, j] if j < grad_latents else latent[:, j].detach() for j in range(self.n_latent)]
+            # one `unbind` (backward: one `stack`) instead of a `select` per slot, whose backward writes a full-size zero
+            # tensor and adds it into the latent's gradient once per slot
+            lat = list(latent[:, :grad_latents].unbind(1)) + list(latent[:, grad_latents:].detach().unbind(1))
         else:
-            lat = [latent[:, j] for j in range(self.n_latent)]
+            lat = list(latent.unbind(1))
         first_free = 0
         if latent.requires_grad and torch.is_grad_enabled():
             first_free = self.n_latent if grad_latents is None else grad_latents

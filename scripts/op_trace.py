@@ -12,7 +12,7 @@ from torch.profiler import profile, ProfilerActivity          # noqa: E402
 from gangealing_amd.op import conv_mfma                        # noqa: E402
 from gangealing_amd.train_step import GangealingTrainer        # noqa: E402
 
-conv_mfma.set_precision('bf16x3')
+conv_mfma.set_precision(os.environ.get('GANGEALING_CONV_PRECISION', 'fp16x3'))
 dev = torch.device('cuda', 0)
 tr = GangealingTrainer(dev, gen_size=256, flow_size=128, batch=16, transform=('similarity', 'flow'), inject=5, ndirs=1,
                        perturb_heads=0.02, stn_lr=1e-4, ll_lr=1e-4)
