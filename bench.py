@@ -99,41 +99,36 @@ DTYPE = {'fp32': 'f32', 'bf16': 'bf16 (convolution operands rounded to bf16, fp3
 
 def _reference_step_fn(wl):
     """The REFERENCE's own training-loss step on its pure-PyTorch CPU op fallback (upfirdn2d_native, CPU
-    fused_leaky_relu, F.conv2d / grid_sample), imported from /root/reference through the stub loader of
-    oracle/make_golden.py.  Only possible where the reference checkout exists (the authoring container); None on
-    the GPU box."""
-    ref = os.environ.get('GANGEALING_REFERENCE', '/root/reference')
-    if not os.path.isdir(os.path.join(ref, 'models')):
-        return None
+    fused_leaky_relu, F.conv2d / grid_sample): its modules are imported through the stub loader of
+    oracle/make_golden.py from the checkout (authoring container) or from oracle/_ref/pyref, the copy `make -C oracle`
+    stages so that it travels to the GPU box (oracle/pyref.py).  None when neither exists."""
     try:
-        from oracle.make_golden import import_reference
-        import_reference()
-        from models.stylegan2.networks import Generator
-        from models.spatial_transformers.spatial_transformer import get_stn
-        from models.latent_learner import DirectionInterpolator
-        from models.losses.loss import gangealing_loss
-        from models import accumulate
+        from oracle import pyref
+        api = pyref.cpu_api()
     except Exception:                          # noqa: BLE001 - any import problem: fall back to the port
         return None
-    gen = Generator(wl['gen_size'], 512, 8).eval().requires_grad_(False)
-    stn = get_stn(list(wl['transform']), flow_size=wl['flow_size'], supersize=wl['gen_size'], channel_multiplier=0.5,
-                  num_heads=1)
-    ema = get_stn(list(wl['transform']), flow_size=wl['flow_size'], supersize=wl['gen_size'], channel_multiplier=0.5,
-                  num_heads=1)
-    ll = DirectionInterpolator(None, wl['ndirs'], wl['inject'], gen.n_latent)
+    if api is None:
+        return None
+    gen = api.Generator(wl['gen_size'], 512, 8).eval().requires_grad_(False)
+    stn = api.get_stn(list(wl['transform']), flow_size=wl['flow_size'], supersize=wl['gen_size'],
+                      channel_multiplier=0.5, num_heads=1)
+    ema = api.get_stn(list(wl['transform']), flow_size=wl['flow_size'], supersize=wl['gen_size'],
+                      channel_multiplier=0.5, num_heads=1)
+    ll = api.DirectionInterpolator(None, wl['ndirs'], wl['inject'], gen.n_latent)
     t_optim = torch.optim.Adam(stn.parameters(), lr=1e-3)
     ll_optim = torch.optim.Adam(ll.parameters(), lr=1e-2)
     mse = lambda x, y: ((x - y) ** 2).mean(dim=(1, 2, 3))         # torchvision (LPIPS trunk) is not installed
 
     def step():
-        loss, _ = gangealing_loss(gen, stn, ll, mse, torch.nn.Sequential(), 0.5, wl['batch'], 512, False, 'cpu',
-                                  padding_mode=wl['padding_mode'])
+        loss, _ = api.gangealing_loss(gen, stn, ll, mse, torch.nn.Sequential(), 0.5, wl['batch'], 512, False, 'cpu',
+                                      padding_mode=wl['padding_mode'])
         stn.zero_grad()
         ll.zero_grad()
         loss.backward()
         t_optim.step()
         ll_optim.step()
-        accumulate(ema, stn, 0.5 ** (32 / 10000))
+        api.accumulate(ema, stn, 0.5 ** (32 / 10000))
+    step.source = api.root
     return step
 
 
@@ -194,12 +189,25 @@ def cpu_baseline(budget_s=20.0):
         dt = time.perf_counter() - t0
         if dt >= budget_s or steps >= 50:
             break
-    src = 'the reference\'s own modules (imported from the reference checkout)' if kind == 'reference' \
-        else 'oracle/torch_ref.py (reference checkout absent on this box)'
+    src = (f'the reference\'s own modules on its pure-PyTorch CPU op fallback (imported from {os.path.relpath(step.source, REPO) if step.source.startswith(REPO) else step.source})'
+           if kind == 'reference' else 'oracle/torch_ref.py (no reference Python on this box)')
     return dict(value=round(steps * wl['batch'] / dt, 3), unit='images/sec', cores=threads, kind=kind,
                 sample=f'{steps} full train steps of config C1 (gen 64, similarity STN@64, batch {wl["batch"]}, '
                        f'MSE stand-in loss) in {dt:.1f} s via {src}; {threads} of {cores} host cores, chosen by a '
                        f'one-step sweep: ' + ', '.join(f'{t} threads {v:.2f} s' for t, v in sorted(sweep.items())))
+
+
+def cpu_baseline_child(budget_s):
+    """cpu_baseline() in a child interpreter: the reference's modules on their CPU fallback and the same modules on the
+    HIP operators (extras.dropin_route) both bind `models.*` in sys.modules, so one process holds only one of them."""
+    import subprocess
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--cpu-budget', str(budget_s)],
+                         capture_output=True, text=True, env=env, timeout=max(600.0, 30 * budget_s))
+    for line in reversed(out.stdout.strip().splitlines()):
+        if line.startswith('{'):
+            return json.loads(line)
+    raise RuntimeError('cpu baseline child failed: ' + out.stderr[-400:])
 
 
 SYNTHETIC_LR = 1e-4      # the work per step does not depend on the learning rate; with randomly initialised G / VGG the
@@ -277,6 +285,76 @@ def _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile)
     return res
 
 
+def measure_reference_dropin(device, wl, precision, steps, warmup):
+    """The literal drop-in route: the REFERENCE's own modules (networks.py with its per-sample-weight / groups = N
+    modulated convolutions, spatial_transformer.py, warping_heads.py, latent_learner.py, loss.py, lpips.py),
+    imported unmodified through gangealing_amd.launch.inject (oracle/pyref.hip_api), run the iteration of
+    train.py:106-134 on the HIP operators with torch.optim.Adam and models.accumulate - what a user of
+    `python -m gangealing_amd.launch train.py` gets.  None when no reference Python is on this box."""
+    from oracle import pyref                        # checker-side loader; the timed modules are the reference's
+    api = pyref.hip_api()
+    if api is None:
+        return None
+    from gangealing_amd.op import conv_mfma
+    conv_mfma.set_precision(precision)
+    torch.manual_seed(0)
+    gen = api.Generator(wl['gen_size'], 512, 8, channel_multiplier=2).to(device).eval().requires_grad_(False)
+    kw = dict(flow_size=wl['flow_size'], supersize=wl['gen_size'], channel_multiplier=0.5, num_heads=wl['num_heads'])
+    stn = api.get_stn(list(wl['transform']), **kw).to(device)
+    with torch.no_grad():                           # as GangealingTrainer(perturb_heads=0.02): a non-identity warp
+        for name, p in stn.named_parameters():
+            if 'warp_head.linear' in name or 'flow_out.2' in name:
+                p.normal_(0.0, 0.02)
+    ema = api.get_stn(list(wl['transform']), **kw).to(device)
+    api.accumulate(ema, stn, 0)
+    ll = api.DirectionInterpolator(None, wl['ndirs'], wl['inject'], gen.n_latent, wl['num_heads']).to(device)
+    net = api.LPIPS(net='vgg', lpips=False, pnet_rand=True, pretrained=False, verbose=False).to(device).eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.Conv2d) and m.bias is not None:
+                m.bias.fill_(0.1)                   # as losses.py: no all-zero feature vectors under a random trunk
+    loss_fn = lambda x, y: net(x, y) / 18.0        # lpips.py:17
+    factor = wl['gen_size'] // wl['flow_size']
+    resize = api.BilinearDownsample(factor, 3).to(device) if factor > 1 else torch.nn.Sequential()
+    t_optim = torch.optim.Adam(stn.parameters(), lr=SYNTHETIC_LR, betas=(0.9, 0.999), eps=1e-8)
+    ll_optim = torch.optim.Adam(ll.parameters(), lr=SYNTHETIC_LR, betas=(0.9, 0.999), eps=1e-8)
+    clustering = wl['num_heads'] > 1 or wl['flips']
+    tv_w, id_w = wl.get('tv_weight', 1000.0), wl.get('flow_identity_weight', 1.0)
+    common = dict(sample_from_full_res=wl['sample_from_full_res'], padding_mode=wl['padding_mode'])
+
+    def step():
+        if clustering:
+            ploss, delta = api.gangealing_cluster_loss(gen, stn, ll, loss_fn, resize, 0.5, wl['batch'], 512, False,
+                                                       wl['num_heads'], wl['flips'], device, **common)
+        else:
+            ploss, delta = api.gangealing_loss(gen, stn, ll, loss_fn, resize, 0.5, wl['batch'], 512, False, device,
+                                               **common)
+        total = ploss
+        if 'flow' in wl['transform']:
+            total = ploss + tv_w * api.total_variation_loss(delta) + id_w * api.flow_identity_loss(delta)
+        stn.zero_grad()
+        ll.zero_grad()
+        total.backward()
+        t_optim.step()
+        ll_optim.step()
+        api.accumulate(ema, stn, 0.5 ** (32 / 10000))
+        return ploss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ploss = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    loss = float(ploss)
+    assert loss == loss and abs(loss) != float('inf'), 'non-finite loss'
+    root = api.root
+    return dict(elapsed=elapsed, images=wl['batch'] * steps, loss=loss,
+                source=os.path.relpath(root, REPO) if root.startswith(REPO) else root)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -296,7 +374,11 @@ def main():
                     help='skip the additional single-GPU measurements (hipGraph replay, plain-bf16 arithmetic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:           # the child of cpu_baseline_child(): host cores only, no HIP library
+        print(json.dumps(cpu_baseline(args.cpu_budget)), flush=True)
+        return
 
     from gangealing_amd import _lib
     _lib.load()                      # fail loudly when the HIP library is missing
@@ -373,9 +455,9 @@ def main():
                                         ('bf16x3_eager', 'bf16x3', False, 'shared'),
                                         ('bf16_eager', 'bf16', False, 'shared'),
                                         ('bf16_hipgraph_replay', 'bf16', True, 'shared'),
-                                        # the literal drop-in route: reference-form generator (per-sample weights +
-                                        # grouped convolutions through op.conv2d_gradfix), same step otherwise
-                                        ('dropin_route', args.precision, False, 'grouped')):
+                                        # the reference's generator FORMULATION (per-sample weights + grouped
+                                        # convolutions through op.conv2d_gradfix) inside this package's trainer
+                                        ('grouped_form', args.precision, False, 'grouped')):
             if (name.startswith('bf16_') and args.precision == 'bf16') or (name == 'bf16x3_eager' and args.precision == 'bf16x3'):
                 continue
             try:
@@ -388,10 +470,27 @@ def main():
                                                  'conv2d / conv_transpose2d with groups = N')
             except Exception as e:             # noqa: BLE001 - an extra must never take the headline line down
                 extras[name] = {'error': str(e)[:200]}
+        # the literal drop-in route: the reference's OWN modules on the HIP operators (last: it binds `models.*`)
+        try:
+            r = measure_reference_dropin(device, wl, args.precision, args.steps, args.warmup)
+            if r is None:
+                extras['dropin_route'] = {'error': 'no reference Python on this box (oracle/_ref/pyref not staged)'}
+            else:
+                extras['dropin_route'] = {
+                    'value': round(r['images'] / r['elapsed'], 3), 'ms_per_step': round(1e3 * r['elapsed'] / args.steps, 3),
+                    'dtype': DTYPE[args.precision], 'launch': 'eager', 'loss': r['loss'],
+                    'modules': f'the reference\'s own networks.py / spatial_transformer.py / warping_heads.py / '
+                               f'latent_learner.py / loss.py / lpips.py (from {r["source"]}) through '
+                               f'gangealing_amd.launch.inject, torch.optim.Adam, models.accumulate'}
+        except Exception as e:                 # noqa: BLE001
+            extras['dropin_route'] = {'error': str(e)[:300]}
         out['extras'] = extras
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.cpu_budget)
+            try:
+                out['cpu_baseline'] = cpu_baseline_child(args.cpu_budget)
+            except Exception as e:             # noqa: BLE001 - report, never lose the line
+                out['cpu_baseline'] = {'error': str(e)[:300]}
         print(json.dumps(out), flush=True)
     if world > 1:
         gdist.synchronize()

@@ -49,6 +49,9 @@ def stub_missing(names=('torchvision', 'torchvision.models', 'torchvision.datase
             m = _Stub(name)
             m.__path__ = []
             sys.modules[name] = m
+            parent, _, leaf = name.rpartition('.')
+            if isinstance(sys.modules.get(parent), _Stub):        # `from torchvision import models` must find the stub
+                setattr(sys.modules[parent], leaf, m)
 
 
 def inject(reference_root):

@@ -168,10 +168,13 @@ class GangealingTrainer:
                  flow_identity_weight=1.0, stn_lr=1e-3, ll_lr=1e-2, sample_from_full_res=False, freeze_ll=False,
                  loss_fn='vgg_ssl', seed=0, perturb_heads=0.0, pipeline_update=None, anneal_psi=150000,
                  anneal_fn='cosine', period=37500, decay=0.9, tm=2, perceptual_weights=None, use_graph=False,
-                 graph_warmup=3, allow_random_loss=None, perceptual_trunk_weights=None):
+                 graph_warmup=3, allow_random_loss=None, perceptual_trunk_weights=None, collectives=None):
         """allow_random_loss: run on a seeded RANDOM perceptual trunk when the weight files are missing (synthetic
         benchmark / parity runs).  Default None = only when GANGEALING_SYNTHETIC=1 is set; training otherwise raises
-        FileNotFoundError instead of silently optimising a meaningless objective."""
+        FileNotFoundError instead of silently optimising a meaningless objective.
+        collectives: issue the gradient all-reduces (default: when the process group has more than one rank).  True
+        on a ONE-rank group runs the exact multi-GPU call sequence - async all-reduce of the flat arena on RCCL's
+        stream, work.wait(), deferred Adam / EMA / re-pack - on a single-GPU box (tests/test_gpu_rccl_single_rank.py)."""
         self.device = device
         self._pending = None
         # optional timing of the gradient exchange (bench.py --gpus N): list of (event before, event after) pairs
@@ -227,7 +230,8 @@ class GangealingTrainer:
         self.world = world
         # defer the STN optimizer step behind the next iteration's generator passes (see step()); only pays when there
         # is a collective to hide
-        self.pipeline_update = (world > 1) if pipeline_update is None else bool(pipeline_update)
+        self.collectives = (world > 1) if collectives is None else bool(collectives)
+        self.pipeline_update = self.collectives if pipeline_update is None else bool(pipeline_update)
         self.stn.register_forward_pre_hook(lambda module, inputs: self.flush())
         # whole-iteration hipGraph (single process): after `graph_warmup` eager iterations the step - zeroing the
         # gradient arenas, loss forward, backward, both optimizers, EMA, weight re-pack: ~900 launches - is captured
@@ -327,7 +331,7 @@ class GangealingTrainer:
         with conv_mfma.grad_slots():             # conv weight gradients accumulate straight into the arena
             total.backward()
         scale = 1.0 / self.world
-        if self.world > 1:
+        if self.collectives:
             import torch.distributed as dist
             dist.all_reduce(self.ll_arena.grad, op=dist.ReduceOp.SUM)
             ev = self._comm_mark() if not self.pipeline_update else None

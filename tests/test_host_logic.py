@@ -103,22 +103,34 @@ def test_cosine_psi():
     assert cosine_psi(0, 100) == 1.0 and abs(cosine_psi(50, 100) - 0.5) < 1e-12 and cosine_psi(100, 100) == 0.0
 
 
-@pytest.mark.skipif(not os.path.isdir('/root/reference/models'), reason='needs the reference checkout')
+def _reference_root():
+    from oracle import pyref
+    return pyref.find_root()
+
+
+@pytest.mark.skipif(_reference_root() is None, reason='needs the reference checkout or its staged copy (make -C oracle)')
 def test_launcher_injects_ops_into_reference_imports():
-    """In the authoring container: with the launcher's injection, the reference's own networks.py /
-    warping_heads.py import OUR operator modules (and never trigger the CUDA JIT build)."""
+    """With the launcher's injection, the reference's own networks.py / warping_heads.py / lpips.py import OUR operator
+    modules (and never trigger the CUDA JIT build).  Runs on the checkout (authoring container) and on the staged copy
+    oracle/_ref/pyref that travels to the GPU box (round 4)."""
     import subprocess
-    code = (
-        "import sys; sys.path.insert(0, %r); sys.dont_write_bytecode = True\n"
-        "from gangealing_amd import launch\n"
-        "launch.inject('/root/reference')\n"
-        "import models.stylegan2.networks as n, models.spatial_transformers.warping_heads as wh\n"
-        "import gangealing_amd.op as op, gangealing_amd.spatial_transformers.antialiased_sampling as aa\n"
-        "assert n.upfirdn2d is op.upfirdn2d and n.FusedLeakyReLU is op.FusedLeakyReLU\n"
-        "assert n.conv2d_gradfix is op.conv2d_gradfix and wh.MipmapWarp is aa.MipmapWarp\n"
-        "print('ok')\n" % REPO)
-    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+    from oracle import pyref
+    roots = {pyref.find_root()} | ({pyref.STAGED} if os.path.isdir(os.path.join(pyref.STAGED, 'models')) else set())
+    for root in sorted(roots):
+        code = (
+            "import sys; sys.path.insert(0, %r); sys.dont_write_bytecode = True\n"
+            "from oracle import pyref\n"
+            "api = pyref.hip_api(%r)\n"
+            "import models.stylegan2.networks as n, models.spatial_transformers.warping_heads as wh\n"
+            "import gangealing_amd.op as op, gangealing_amd.spatial_transformers.antialiased_sampling as aa\n"
+            "assert n.upfirdn2d is op.upfirdn2d and n.FusedLeakyReLU is op.FusedLeakyReLU\n"
+            "assert n.conv2d_gradfix is op.conv2d_gradfix and wh.MipmapWarp is aa.MipmapWarp\n"
+            "assert api.Generator is n.Generator and api.root == %r, api.root\n"
+            "net = api.LPIPS(net='vgg', lpips=False, pnet_rand=True, pretrained=False, verbose=False)\n"
+            "assert sum(p.numel() for p in net.parameters()) > 14e6\n"
+            "print('ok')\n" % (REPO, root, root))
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.strip().endswith('ok'), (root, out.stderr[-2000:])
 
 
 # ---------------------------------------------------------------------------------------------------------------
