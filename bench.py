@@ -348,7 +348,7 @@ def measure_reference_dropin(device, wl, precision, steps, warmup):
         ploss = step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    loss = float(ploss)
+    loss = float(ploss.detach())
     assert loss == loss and abs(loss) != float('inf'), 'non-finite loss'
     root = api.root
     return dict(elapsed=elapsed, images=wl['batch'] * steps, loss=loss,
@@ -472,7 +472,9 @@ def main():
                 extras[name] = {'error': str(e)[:200]}
         # the literal drop-in route: the reference's OWN modules on the HIP operators (last: it binds `models.*`)
         try:
-            r = measure_reference_dropin(device, wl, args.precision, args.steps, args.warmup)
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):       # the reference's modules print while they build
+                r = measure_reference_dropin(device, wl, args.precision, args.steps, args.warmup)
             if r is None:
                 extras['dropin_route'] = {'error': 'no reference Python on this box (oracle/_ref/pyref not staged)'}
             else:

@@ -12,6 +12,11 @@ generator is called through NoiseFeeder, which turns `noise=None` into explicit 
 Configurations:
   c2  LSUN Cats 256^2, similarity+flow STN at 128^2, per-GPU batch 16, vgg_ssl loss form      (the benchmark config)
   c2t the same with textured generator images (noise-injection weights x10)
+  c2r the same with a WIDE DYNAMIC RANGE inside the generator: the modulation (style) layers of the 13 styled
+      convolutions drawn with scales 1e-5 .. 1e5, so the operand x * style of the modulated convolutions
+      (networks.py:243-253) spans 1e-5 .. 3e5 from layer to layer while demodulation keeps the outputs O(1) - what
+      trained StyleGAN2 generators do at their high-resolution layers (the reason for the reference's fp16 `normalize`
+      branch, networks.py:237-242).  Exercises the exponent range of the split-precision limbs.
   c1  LSUN Cats 64^2, similarity-only STN, batch 4 (BASELINE.json configs[0])
   c4  CelebA-HQ 512^2 flags (scripts/training/celeba.sh:4-6 at gen_size 512): BilinearDownsample(4), border padding,
       inject 6, ndirs 512, sample_from_full_res, tv 2500, LPIPS with lin layers; batch 2
@@ -39,6 +44,16 @@ CONFIGS = {
     'c2t': dict(gen_size=256, flow_size=128, real_size=256, batch=16, transform=['similarity', 'flow'], num_heads=1,
                 flips=False, inject=5, ndirs=1, padding_mode='reflection', tv_weight=1000.0, flow_identity_weight=1.0,
                 sample_from_full_res=False, loss='vgg_ssl', psi=0.5, gen_rules=(('noise', 1.0),)),
+    'c2r': dict(gen_size=256, flow_size=128, real_size=256, batch=16, transform=['similarity', 'flow'], num_heads=1,
+                flips=False, inject=5, ndirs=1, padding_mode='reflection', tv_weight=1000.0, flow_identity_weight=1.0,
+                sample_from_full_res=False, loss='vgg_ssl', psi=0.5,
+                gen_rules=(('conv1.conv.modulation', 1e5), ('convs.0.conv.modulation', 1e-5),
+                           ('convs.1.conv.modulation', 1e3), ('convs.2.conv.modulation', 3e-3),
+                           ('convs.3.conv.modulation', 3e4), ('convs.4.conv.modulation', 1e-4),
+                           ('convs.5.conv.modulation', 30.0), ('convs.6.conv.modulation', 1e4),
+                           ('convs.7.conv.modulation', 1e-2), ('convs.8.conv.modulation', 1e2),
+                           ('convs.9.conv.modulation', 1e-5), ('convs.10.conv.modulation', 1e5),
+                           ('convs.11.conv.modulation', 1e-3))),
     # BASELINE.json configs[0]: 64^2, similarity-only STN, batch 4 (delta_flow is the (N, 2, 3) matrix; no TV /
     # identity terms: train.py only evaluates them for flow STNs)
     'c1': dict(gen_size=64, flow_size=64, real_size=64, batch=4, transform=['similarity'], num_heads=1,

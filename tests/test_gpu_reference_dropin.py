@@ -126,7 +126,7 @@ def test_reference_training_iterations_run(cuda):
         t_optim.step()
         ll_optim.step()
         api.accumulate(ema, stn, 0.5 ** (32 / 10000))
-        losses.append(float(total))
+        losses.append(float(total.detach()))
     assert all(np.isfinite(losses)), losses
     moved = sum(float((p.detach() - b).abs().sum()) for p, b in zip(stn.parameters(), before))
     assert moved > 0
