@@ -80,6 +80,7 @@ struct ConvArgs {
   long long part_stride;
   int f16;                        // split-precision limbs are binary16 (forward convolutions), see Limb<>
   float acc_scale;                // accumulators are multiplied by this first (1 / kF16WeightScale with f16 limbs)
+  int nt_store;                   // the 8-wave tiles' epilogues store with the non-temporal hint (outputs beyond the caches)
 };
 
 // k -> (ci, ky, kx, dy, dx).  MODE 0: correlation taps; MODE 1: taps of one parity class.
@@ -328,16 +329,16 @@ __device__ __forceinline__ void buffer_store_f32x4(f32x4 v, __amdgpu_buffer_rsrc
 __device__ __forceinline__ void buffer_store_f32(float v, __amdgpu_buffer_rsrc_t r, unsigned voffset, int soffset) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voffset, soffset, 0);
 }
+// the same with the non-temporal hint (aux = 2): for outputs far larger than L2 + Infinity Cache, which their consumer
+// will read from HBM anyway; measured on the 541 MB up-convolution output: -5.6 % of the launch, -1 % on the 268 - 537 MB
+// stride-1 outputs, +4 % on a 138 MB output that the next kernel would have found in the Infinity Cache - hence per
+// launch (ConvArgs::nt_store; profiles/r03_s_nt_store_experiment.txt)
+__device__ __forceinline__ void buffer_store_f32x4_nt(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voffset, int soffset) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, v), r, (int)voffset, soffset, 2);
+}
+constexpr long long kNtStoreBytes = 256LL << 20;          // Infinity Cache size
 // orders one wave's LDS writes before its own later LDS reads (and vice versa) when the lanes exchange data through a
 // region no other wave touches: DS operations of a wave execute in order, so only the compiler has to be held back
-#ifdef GG_EXP_STAGGER            // measurement build: de-phase the first wave of blocks by (block % 8) / 8 of `cycles`
-__device__ __forceinline__ void exp_stagger(unsigned block, long long ref_ticks) {
-  if (block >= 256u) return;
-  const long long t0 = wall_clock64();
-  const long long wait = ref_ticks * (long long)(block & 7u) / 8;
-  while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-}
-#endif
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -403,6 +404,71 @@ struct Limb<true> {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
 };
+// ---- block floating point for the binary16 limbs (round 4) ---------------------------------------------------------
+// binary16 spans 6e-8 .. 65504, fp32 operands do not: activation x style reaches 1e5 in trained generators, gradients
+// sit at 1e-8.  Every block therefore carries ONE power-of-two exponent E for the operand it stages (activations or
+// gradients, after the style / mask factors): values are multiplied by 2^-E before they are split into limbs and the
+// accumulators by 2^E in the epilogue - both exact.  E comes from the data itself: while a chunk (32 input channels of
+// the tile's patch, or one gathered slab) waits in registers, the block takes the maximum magnitude of what it is about
+// to stage (v_max per element, one wave butterfly, one LDS word per wave, published by a barrier the loop already has).
+//   * amax in [2^-3, 2^11]: E = 0, nothing is scaled (bit-identical to the unscaled kernel; 16x headroom to 65504);
+//   * otherwise E = floor(log2 amax) - 6, i.e. amax 2^-E in [2^6, 2^7): limb 0 keeps 11 bits of every element down to
+//     2^-14 of that, limb 1 another 11 bits down to 2^-3 and an ABSOLUTE 2^-25 below - 2^-31 of the chunk's largest
+//     element, so the error of a dot product is 2^-22 of its terms' scale whatever the operand's magnitude;
+//   * E only grows inside a tile: when a later chunk needs a larger exponent the accumulators are multiplied by
+//     2^(E_old - E_new) once (exact) and E moves; a chunk that is much smaller than its predecessors is staged with the
+//     tile's E (its terms are small against the sum already accumulated).
+// No state outside the block, no calibration pass, no saturation: overflow cannot happen for finite inputs, and two
+// runs of the same launch do the same arithmetic (the maximum does not depend on the order of its operands).
+struct BlockExp {
+  int e = 0;          // current exponent
+  int set = 0;        // a non-zero chunk has been seen
+};
+__device__ __forceinline__ int f16_block_exp(float amax) {          // amax > 0, uniform
+  if (amax >= 0.125f && amax <= 2048.f) return 0;
+  int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127 - 6;
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+__device__ __forceinline__ float exp2i(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
+// -> factor for the accumulators (1 = leave them), updates `b` for a chunk whose largest magnitude is `amax`
+__device__ __forceinline__ float block_exp_update(BlockExp& b, float amax) {
+  if (!(amax > 0.f)) return 1.f;
+  if (!b.set) {
+    b.set = 1;
+    b.e = f16_block_exp(amax);
+    return 1.f;                       // the accumulators are still zero
+  }
+  if (amax * exp2i(-b.e) <= 2048.f) return 1.f;
+  const int ne = f16_block_exp(amax);
+  const float f = exp2i(b.e - ne);    // ne > b.e
+  b.e = ne;
+  return f;
+}
+// maximum over the wave, then lane 0 publishes it in slot[wave]; the caller's next barrier makes it visible
+// (DPP, not ds_bpermute shuffles: six VALU instructions and no LDS round trips - the reduction sits inside the MFMA
+// stream of the tap loop)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, CTRL, ROW_MASK, 0xf, false)));
+}
+__device__ __forceinline__ void publish_wave_amax(float m, float* slot, int wid, int lane) {
+  m = dpp_max<0x128, 0xf>(m);        // row_ror:8, 4, 2, 1: every lane of a 16-lane row holds the row's maximum
+  m = dpp_max<0x124, 0xf>(m);
+  m = dpp_max<0x122, 0xf>(m);
+  m = dpp_max<0x121, 0xf>(m);
+  m = dpp_max<0x142, 0xa>(m);        // row_bcast:15 into rows 1 and 3
+  m = dpp_max<0x143, 0xc>(m);        // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's maximum
+  if (lane == 63) slot[wid] = m;
+}
+template <int NW>
+__device__ __forceinline__ float read_block_amax(const float* slot) {
+  float m = slot[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) m = fmaxf(m, slot[i]);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+}
+
 // host-side-exact variant for the weight packs (run once per weight version): nearest rounding with explicit saturation
 __device__ __forceinline__ unsigned short f16_limb_rn(float v) {
   return __builtin_bit_cast(unsigned short, (_Float16)fminf(fmaxf(v, -65504.f), 65504.f));
@@ -411,7 +477,7 @@ __device__ __forceinline__ unsigned short f16_limb_rn(float v) {
 template <int KS, int MODE, int LIMBS, bool IN_SCALE, int TPIX, bool F16 = false>
 __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs a) {
   using L = Limb<F16>;
-  constexpr int TCO = 128, MI = 2, NJ = 2, PWAVES = TPIX / 64;
+  constexpr int TCO = 128, MI = 2, NJ = 2, PWAVES = TPIX / 64, NT = TPIX * 2;
   __shared__ __attribute__((aligned(16))) unsigned char sW[LIMBS][TCO * ROWB];
   __shared__ __attribute__((aligned(16))) unsigned char sX[LIMBS][TPIX * ROWB];
 
@@ -505,14 +571,33 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
       for (int q = 0; q < EPT / 8; ++q) wv[l][q] = w4[q];
     }
   };
-  auto store_slab = [&]() {
-    float v[EPT];
+  // the gathered slab in its final fp32 form (zero padding, style); binary16 limbs: + this wave's largest magnitude
+  // for the block exponent (see BlockExp)
+  __shared__ float sAmax[16];
+  BlockExp bexp;
+  auto prep_slab = [&]() {
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) v[j] = x_ok ? xa[j] : 0.f;
+    for (int j = 0; j < EPT; ++j) xa[j] = x_ok ? xa[j] : 0.f;
     if (IN_SCALE) {
       const float* rs = reinterpret_cast<const float*>(rs4);
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) v[j] *= rs[j];
+      for (int j = 0; j < EPT; ++j) xa[j] *= rs[j];
+    }
+    if (F16) {
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) m = fmaxf(m, fabsf(xa[j]));
+      publish_wave_amax(m, sAmax, wid, lane);
+    }
+  };
+  auto store_slab = [&]() {
+    float v[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) v[j] = xa[j];
+    if (F16 && bexp.e != 0) {                      // uniform branch: most tiles never leave E = 0
+      const float ps = exp2i(-bexp.e);
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) v[j] *= ps;
     }
 #pragma unroll
     for (int l = 0; l < LIMBS; ++l) {
@@ -547,7 +632,24 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
   if (slab0 < slab1) {
     const int kh = lane >> 5, l31 = lane & 31;
     load_slab(slab0);
+    if (F16) {
+      prep_slab();
+      __syncthreads();
+    }
     for (int slab = slab0; slab < slab1; ++slab) {
+      if (F16) {            // the slab's block exponent (published behind the previous barrier)
+        const float f = block_exp_update(bexp, read_block_amax<NT / 64>(sAmax));
+        if (f != 1.f) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+        }
+      } else {
+        prep_slab();
+      }
       store_slab();
       __syncthreads();
       if (slab + 1 < slab1) load_slab(slab + 1);
@@ -576,12 +678,17 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
                 acc[i][j] = L::mfma(fa[la][i], fb[lb][j], acc[i][j]);
           }
       }
+      if (F16 && slab + 1 < slab1) {       // the next slab's loads had this slab's MFMAs to land
+        __builtin_amdgcn_sched_barrier(0);
+        prep_slab();
+      }
       __syncthreads();
     }
   }
 
   const int ohw = a.oh * a.ow;
   const bool partial = a.part != nullptr;
+  const float esc = F16 ? exp2i(bexp.e) : 1.f;          // undo the block exponent (exact)
   float* ybase = partial ? a.part + (size_t)split * a.part_stride : a.y;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -602,7 +709,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + (wco * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (co >= a.cout_g) continue;
-        float v = acc[i][j][r];
+        float v = acc[i][j][r] * esc;
         if (!partial) v *= a.acc_scale;
         if (osc) v *= osc[co];
         if (bia) v += bia[co];
@@ -648,8 +755,9 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   // (the epilogue also keeps the tile's per-channel scale / bias / activation bias and per-pixel noise in LDS: EPI_BYTES)
   constexpr int MAIN_BYTES = LIMBS * (PATCH_MAX + WBUF * TPI * TCO) * ROWB, STAGE_BYTES = (NT / 64) * 32 * 64 * 4;
   constexpr int EPI_BYTES = (3 * TCO + TPIX) * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char
-      smem[MAIN_BYTES > STAGE_BYTES + EPI_BYTES ? MAIN_BYTES : STAGE_BYTES + EPI_BYTES];
+  constexpr int SMEM_BYTES = MAIN_BYTES > STAGE_BYTES + EPI_BYTES ? MAIN_BYTES : STAGE_BYTES + EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES + 64];
+  float* sAmax = reinterpret_cast<float*>(smem + SMEM_BYTES);      // per-wave operand maxima (binary16 limbs: BlockExp)
   unsigned char (*sP)[PATCH_MAX * ROWB] = reinterpret_cast<unsigned char (*)[PATCH_MAX * ROWB]>(smem);
   unsigned char (*sW)[TCO * ROWB] = reinterpret_cast<unsigned char (*)[TCO * ROWB]>(smem + LIMBS * PATCH_MAX * ROWB);
 
@@ -668,9 +776,6 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   const int trem = tile_pix - pn * tiles_x * tiles_y;
   const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
-#ifdef GG_EXP_STAGGER
-  exp_stagger(blockIdx.x, (long long)a.slabs_per_split * 600);
-#endif
 
   const int chan0 = (pn * a.groups + g) * a.cin_g;
   const float* sg = IN_SCALE ? a.in_scale + chan0 : nullptr;
@@ -721,13 +826,6 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   U4 wv[TPI][LIMBS][EPT / 8];
 
   auto load_patch = [&](int chunk) {
-#ifdef GG_EXP_PATCH_NO_PLOAD     // measurement build: no activation loads
-    if (chunk >= 0) {
-#pragma unroll
-      for (int j = 0; j < BKS; ++j) xa[j] = 1.f + j;
-      return;
-    }
-#endif
     const int cbase = __builtin_amdgcn_readfirstlane(chunk * BKS * hw * 4);
 #pragma unroll
     for (int j = 0; j < BKS; ++j) xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
@@ -743,9 +841,6 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   // number of requests in flight, so the burst held every wave in its VMEM issue phase - in front of the chunk's first
   // MFMA - for 1.4 - 4 thousand cycles per chunk (r03 session O: 7 - 16 % of the launch).
   auto load_patch_slice = [&](int chunk, int j0, int j1, bool tail) {
-#ifdef GG_EXP_PATCH_NO_PLOAD
-    if (chunk >= 0) return;
-#endif
     const int cbase = __builtin_amdgcn_readfirstlane(chunk * BKS * hw * 4);
 #pragma unroll
     for (int j = 0; j < BKS; ++j)
@@ -758,17 +853,37 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       if (MASK) xml = buffer_load_f32(mr, lvoff, cbase);
     }
   };
-  auto store_patch = [&](int chunk) {
+  // prep_patch: the chunk's registers in their final fp32 form (activation mask, style); with binary16 limbs also
+  // this wave's largest magnitude, published for the block exponent.  store_patch: scale by 2^-E, split, write.
+  BlockExp bexp;
+  auto prep_patch = [&](int chunk) {
     if (MASK) {
 #pragma unroll
       for (int j = 0; j < BKS; ++j) xa[j] *= xm[MASK ? j : 0] > 0.f ? mpos : mneg;
       xl *= xml > 0.f ? mpos : mneg;
     }
-    if (pin) {
-      if (IN_SCALE) {
+    if (IN_SCALE) {
+      if (pin) {
 #pragma unroll
         for (int j = 0; j < BKS; ++j) xa[j] *= sg[chunk * BKS + j];
       }
+      if (lin) xl *= sg[chunk * BKS + lci];
+    }
+    if (F16) {
+      float m = fabsf(xl);
+#pragma unroll
+      for (int j = 0; j < BKS; ++j) m = fmaxf(m, fabsf(xa[j]));
+      publish_wave_amax(m, sAmax, wid, lane);
+    }
+  };
+  auto store_patch = [&]() {
+    if (F16 && bexp.e != 0) {                      // uniform branch: most tiles never leave E = 0
+      const float ps = exp2i(-bexp.e);
+#pragma unroll
+      for (int j = 0; j < BKS; ++j) xa[j] *= ps;
+      xl *= ps;
+    }
+    if (pin) {
 #pragma unroll
       for (int l = 0; l < LIMBS; ++l) {
         U4* dst = reinterpret_cast<U4*>(&sP[l][tid * ROWB]);
@@ -790,7 +905,6 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
     }
     if (lin) {
       float v = xl;
-      if (IN_SCALE) v *= sg[chunk * BKS + lci];
 #pragma unroll
       for (int l = 0; l < LIMBS; ++l) {
         const unsigned short hb = L::one(v, l == 0);
@@ -799,20 +913,11 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       }
     }
   };
+  // top of a chunk: binary16 limbs take the block exponent published behind the last barrier (and rescale the
+  // accumulators if it grew); the other formats finish the registers here, as before
   // interval i of a chunk covers taps [i * TPI, i * TPI + TPI)
   auto load_w = [&](int chunk, int interval) {
     if (!w_thr) return;
-#ifdef GG_EXP_PATCH_NO_WLOAD     // measurement build: no weight loads
-    if (chunk >= 0) {
-#pragma unroll
-      for (int u = 0; u < TPI; ++u)
-#pragma unroll
-        for (int l = 0; l < LIMBS; ++l)
-#pragma unroll
-          for (int q = 0; q < EPT / 8; ++q) wv[u][l][q] = U4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-      return;
-    }
-#endif
 #pragma unroll
     for (int u = 0; u < TPI; ++u) {
       const int soff = __builtin_amdgcn_readfirstlane(((interval * TPI + u) * a.cin_g + chunk * BKS) * 2);
@@ -854,10 +959,29 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
     pbase[j] = (r * PW + c) * ROWB;
   }
 
+  auto begin_chunk = [&](int chunk) {
+    if (F16) {
+      const float f = block_exp_update(bexp, read_block_amax<NT / 64>(sAmax));
+      if (f != 1.f) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+      }
+    } else {
+      prep_patch(chunk);
+    }
+    store_patch();
+  };
+
   if (chunk0 < chunk1) {
     load_patch(chunk0);
     load_w(chunk0, 0);
+    if (F16) prep_patch(chunk0);       // published by the barrier below (PIPE) / the chunk loop's first barrier
     if constexpr (PIPE) {
+      if (F16) __syncthreads();
       // Software-pipelined tap loop (BKS = 32: two k-steps per tap).  Tap t reads weight buffer t & 1 while slab t + 1
       // is written to the other one, so ONE barrier per tap both publishes slab t + 1 and retires buffer t & 1; the
       // fragments of a tap's first k-step are fetched right after the previous tap's barrier and those of its second
@@ -897,7 +1021,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       for (int chunk = chunk0; chunk < chunk1; ++chunk) {
         // here: every wave is past the barrier that followed its last LDS fetch of the previous chunk (or at kernel
         // start); registers hold this chunk's patch and its tap-0 slab
-        store_patch(chunk);
+        begin_chunk(chunk);
         store_w(0);
         load_w(chunk, 1);
         const bool more = chunk + 1 < chunk1;
@@ -919,6 +1043,9 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
           // (the scheduler otherwise sinks each fetch down to its first use to shorten the live ranges, which puts
           // the LDS round trip back in front of the MFMAs)
           __builtin_amdgcn_sched_barrier(0);
+          // binary16 limbs: the next chunk's patch is complete in registers (issued over taps 0 .. 5) - finish it and
+          // publish its magnitude behind this tap's barrier; the VALU work shares the region with the 12 MFMAs
+          if (F16 && more && t == 8) prep_patch(chunk + 1);
           mma(fa0, fb0);
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();
@@ -934,7 +1061,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
     } else {
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
       __syncthreads();                         // previous chunk's readers are done with sP
-      store_patch(chunk);
+      begin_chunk(chunk);
       if (chunk + 1 < chunk1) load_patch(chunk + 1);
       for (int iv = 0; iv < 9 / TPI; ++iv) {
         store_w(0);
@@ -975,23 +1102,13 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
         }
         __syncthreads();                       // sW may be overwritten
       }
+      // binary16 limbs: the next chunk's registers landed during the nine taps; published by the loop's top barrier
+      if (F16 && chunk + 1 < chunk1) prep_patch(chunk + 1);
     }
     }
   }
+  const float esc = F16 ? exp2i(bexp.e) : 1.f;          // undo the block exponent (exact)
 
-#ifdef GG_EXP_NO_EPILOGUE        // measurement build: main loop only
-  {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-    if (t == 1234.5678f) a.y[0] = t;
-    return;
-  }
-#endif
   const int ochan0 = (pn * a.groups + g) * a.cout_g;
   const float* osc = a.out_scale ? a.out_scale + ochan0 : nullptr;
   const float* bia = a.bias ? a.bias + g * a.cout_g : nullptr;
@@ -1007,7 +1124,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + (wco * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           if (co >= a.cout_g) continue;
-          yp[(size_t)co * hw] = acc[i][j][r];
+          yp[(size_t)co * hw] = acc[i][j][r] * esc;
         }
       }
     }
@@ -1029,7 +1146,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   for (int c = tid; c < TCO; c += NT) {
     const int co = co0 + c;
     const bool ok = co < a.cout_g;
-    ep_scale[c] = (osc && ok) ? a.acc_scale * osc[co] : a.acc_scale;
+    ep_scale[c] = (osc && ok) ? a.acc_scale * esc * osc[co] : a.acc_scale * esc;
     ep_bias[c] = (bia && ok) ? bia[co] : 0.f;
     ep_abias[c] = (a.act && a.act_bias && ok) ? a.act_bias[g * a.cout_g + co] : 0.f;
   }
@@ -1086,10 +1203,9 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
           t = v4.z + anw * nz.z + ab; v4.z = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
           t = v4.w + anw * nz.w + ab; v4.w = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
         }
-#ifdef GG_EXP_PATCH_EPI_NOSTORE  // measurement build: the whole epilogue except its global stores
-        if (v4.x == 1234.5678f && v4.y == 8765.4321f)
-#endif
-        *reinterpret_cast<float4*>(a.y + (size_t)(ochan0 + co) * hw + (size_t)oy * a.w + ox) = v4;
+        float* dst = a.y + (size_t)(ochan0 + co) * hw + (size_t)oy * a.w + ox;
+        if (a.nt_store) __builtin_nontemporal_store(f32x4{v4.x, v4.y, v4.z, v4.w}, reinterpret_cast<f32x4*>(dst));
+        else *reinterpret_cast<float4*>(dst) = v4;
       }
     }
     wave_lds_sync();                // the staging rows are this wave's own
@@ -1123,8 +1239,9 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   constexpr int TPI = (TQ == 128) ? 3 : 1;
   constexpr int MAIN_BYTES = LIMBS * (PATCH_MAX + TPI * TCO) * ROWB, STAGE_BYTES = (NT / 64) * 8 * 128 * 4;
   constexpr int EPI_BYTES = 2 * TCO * 4;          // per-channel scale and bias of the tile (see the epilogue)
-  __shared__ __attribute__((aligned(16))) unsigned char
-      smem[MAIN_BYTES > STAGE_BYTES + EPI_BYTES ? MAIN_BYTES : STAGE_BYTES + EPI_BYTES];
+  constexpr int SMEM_BYTES = MAIN_BYTES > STAGE_BYTES + EPI_BYTES ? MAIN_BYTES : STAGE_BYTES + EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES + 64];
+  float* sAmax = reinterpret_cast<float*>(smem + SMEM_BYTES);      // per-wave operand maxima (binary16 limbs: BlockExp)
   unsigned char (*sP)[PATCH_MAX * ROWB] = reinterpret_cast<unsigned char (*)[PATCH_MAX * ROWB]>(smem);
   unsigned char (*sW)[TCO * ROWB] = reinterpret_cast<unsigned char (*)[TCO * ROWB]>(smem + LIMBS * PATCH_MAX * ROWB);
 
@@ -1153,9 +1270,6 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
     x0 = a.w;
   }
   const int TW = 1 << tw_log2, TH = TQ >> tw_log2, PW = TW + 1, PP = (TH + 1) * PW;
-#ifdef GG_EXP_STAGGER
-  exp_stagger(blockIdx.x, (long long)a.slabs_per_split * 700);      // 100 MHz ticks: ~7 us per 32-channel chunk
-#endif
 
   const int chan0 = (pn * a.groups + g) * a.cin_g;
   const float* sg = IN_SCALE ? a.in_scale + chan0 : nullptr;
@@ -1200,13 +1314,6 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   U4 wv[TPI][LIMBS][WEPT / 8];
 
   auto load_patch = [&](int chunk) {
-#ifdef GG_EXP_CONVT_NO_PLOAD     // measurement build: no activation loads
-    if (chunk >= 0) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) xa[j] = 1.f + j;
-      return;
-    }
-#endif
     const int cbase = __builtin_amdgcn_readfirstlane(chunk * BKS * hw * 4);
 #pragma unroll
     for (int j = 0; j < 16; ++j) xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
@@ -1214,21 +1321,38 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   };
   // sliced form of load_patch (see conv3x3_patch_kernel): channels [j0, j1) of the lane's 16 (+ the left-over element)
   auto load_patch_slice = [&](int chunk, int j0, int j1, bool tail) {
-#ifdef GG_EXP_CONVT_NO_PLOAD
-    if (chunk >= 0) return;
-#endif
     const int cbase = __builtin_amdgcn_readfirstlane(chunk * BKS * hw * 4);
 #pragma unroll
     for (int j = 0; j < 16; ++j)
       if (j >= j0 && j < j1) xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
     if (tail) xl = buffer_load_f32(xr, lvoff, cbase);
   };
-  auto store_patch = [&](int chunk) {
-    if (pin) {
-      if (IN_SCALE) {
+  // prep_patch / store_patch: as in conv3x3_patch_kernel (style first; binary16 limbs publish the wave's magnitude for
+  // the block exponent, then scale by 2^-E; split; write)
+  BlockExp bexp;
+  auto prep_patch = [&](int chunk) {
+    if (IN_SCALE) {
+      if (pin) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) xa[j] *= sg[chunk * BKS + half * 16 + j];
       }
+      if (lin) xl *= sg[chunk * BKS + lci];
+    }
+    if (F16) {
+      float m = fabsf(xl);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) m = fmaxf(m, fabsf(xa[j]));
+      publish_wave_amax(m, sAmax, wid, lane);
+    }
+  };
+  auto store_patch = [&]() {
+    if (F16 && bexp.e != 0) {
+      const float ps = exp2i(-bexp.e);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) xa[j] *= ps;
+      xl *= ps;
+    }
+    if (pin) {
 #pragma unroll
       for (int l = 0; l < LIMBS; ++l) {
         U4* dst = reinterpret_cast<U4*>(&sP[l][pp * ROWB + half * 32]);
@@ -1250,7 +1374,6 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
     }
     if (lin) {
       float v = xl;
-      if (IN_SCALE) v *= sg[chunk * BKS + lci];
 #pragma unroll
       for (int l = 0; l < LIMBS; ++l) {
         const unsigned short hb = L::one(v, l == 0);
@@ -1261,17 +1384,6 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   };
   // interval i of a chunk covers taps [i * TPI, i * TPI + TPI)
   auto load_w = [&](int chunk, int interval) {
-#ifdef GG_EXP_CONVT_NO_WLOAD     // measurement build: no weight loads
-    if (chunk >= 0) {
-#pragma unroll
-      for (int u = 0; u < TPI; ++u)
-#pragma unroll
-        for (int l = 0; l < LIMBS; ++l)
-#pragma unroll
-          for (int q = 0; q < WEPT / 8; ++q) wv[u][l][q] = U4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-      return;
-    }
-#endif
 #pragma unroll
     for (int u = 0; u < TPI; ++u) {
       const int soff = __builtin_amdgcn_readfirstlane(((interval * TPI + u) * a.cin_g + chunk * BKS) * 2);
@@ -1312,9 +1424,23 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   if (chunk0 < chunk1) {
     load_patch(chunk0);
     load_w(chunk0, 0);
+    if (F16) prep_patch(chunk0);             // published by the chunk loop's first barrier
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
       __syncthreads();
-      store_patch(chunk);
+      if (F16) {          // block exponent of this chunk (rescales the accumulators if it grew)
+        const float f = block_exp_update(bexp, read_block_amax<NT / 64>(sAmax));
+        if (f != 1.f) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[c][j][r] *= f;
+        }
+      } else {
+        prep_patch(chunk);
+      }
+      store_patch();
       const bool more = chunk + 1 < chunk1;
       // 8-wave tile: the next chunk's patch is issued in slices inside the first two intervals (below); the 4-wave
       // tile (two blocks per CU, one tap per interval) keeps the single burst
@@ -1374,28 +1500,14 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
         }
         __syncthreads();
       }
+      // binary16 limbs: the next chunk's registers landed during the nine taps; published by the loop's top barrier
+      if (F16 && more) prep_patch(chunk + 1);
     }
   }
+  const float esc = F16 ? exp2i(bexp.e) : 1.f;          // undo the block exponent (exact)
 
-#ifdef GG_EXP_NO_EPILOGUE        // measurement build: main loop only
-  {
-    float t = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[c][j][r];
-    if (t == 1234.5678f) a.y[0] = t;
-    return;
-  }
-#endif
   const int ohw = a.oh * a.ow;
-#ifdef GG_EXP_CONVT_PITCH        // measurement build (results land at wrong addresses): 16-byte aligned output rows
-  const int owp = (a.ow + 3) & ~3, ohwp = a.oh * owp;
-#else
   const int owp = a.ow, ohwp = ohw;
-#endif
   const int ochan0 = (pn * a.groups + g) * a.cout_g;
   const float* osc = a.out_scale ? a.out_scale + ochan0 : nullptr;
   const float* bia = a.bias ? a.bias + g * a.cout_g : nullptr;
@@ -1412,7 +1524,7 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           if (co >= a.cout_g) continue;
-          yp[(size_t)co * ohw] = acc[c][j][r];
+          yp[(size_t)co * ohw] = acc[c][j][r] * esc;
         }
       }
     }
@@ -1432,15 +1544,12 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
   for (int c = tid; c < TCO; c += NT) {
     const int co = co0 + c;
     const bool ok = co < a.cout_g;
-    ep_scale[c] = (osc && ok) ? a.acc_scale * osc[co] : a.acc_scale;
+    ep_scale[c] = (osc && ok) ? a.acc_scale * esc * osc[co] : a.acc_scale * esc;
     ep_bias[c] = (bia && ok) ? bia[co] : 0.f;
   }
   __syncthreads();
   const __amdgpu_buffer_rsrc_t yr = uniform_rsrc(a.y + (size_t)ochan0 * ohw, a.cout_g * ohw * 4);
   const bool vec = tw_log2 > 0;                             // edge tiles (one q column): scalar stores
-#ifdef GG_EXP_CONVT_EPI_NOLDS
-  float exp_sum = 0.f;
-#endif
   // the lane's 16 channel scales / biases in registers before the passes (LDS reads interleaved with the staging writes
   // are ordered after them by the compiler: one round trip each)
   float4 sc4[4], bi4[4];
@@ -1459,9 +1568,6 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
         const int lrow = rr + 4 * (lane >> 5);
         const float sc = rr == 0 ? sc4[q4].x : rr == 1 ? sc4[q4].y : rr == 2 ? sc4[q4].z : sc4[q4].w;
         const float bi = rr == 0 ? bi4[q4].x : rr == 1 ? bi4[q4].y : rr == 2 ? bi4[q4].z : bi4[q4].w;
-#ifdef GG_EXP_CONVT_EPI_NOLDS    // measurement build: no LDS transposition (the stores carry garbage)
-        for (int j = 0; j < NJ; ++j) exp_sum += acc[py * 2 + 0][j][r] * sc + acc[py * 2 + 1][j][r] * sc + bi;
-#else
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           float2 v2;
@@ -1469,22 +1575,15 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
           v2.y = acc[py * 2 + 1][j][r] * sc + bi;
           *reinterpret_cast<float2*>(stage + lrow * 128 + (j * 32 + l31) * 2) = v2;
         }
-#endif
       }
-#ifndef GG_EXP_CONVT_EPI_NOLDS
       wave_lds_sync();
-#endif
       if (vec) {
         // the pass's four LDS reads first, then its four stores (one LDS round trip per pass instead of four)
         f32x4 v4s[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int idx = it * 64 + lane;
-#ifdef GG_EXP_CONVT_EPI_NOLDS
-          v4s[it] = f32x4{exp_sum, exp_sum, exp_sum, exp_sum};
-#else
           v4s[it] = *reinterpret_cast<const f32x4*>(stage + (idx >> 5) * 128 + (idx & 31) * 4);
-#endif
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -1496,12 +1595,9 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
           const int co = co0 + wco * 32 + lrow + 8 * q4;
           const bool rowok = co < a.cout_g && (unsigned)oy < (unsigned)a.oh;
           const unsigned off = (unsigned)(co * ohwp + oy * owp + ox) * 4u;
-#ifdef GG_EXP_CONVT_EPI_NOSTORE  // measurement build: the LDS transposition without the global stores
-          if (v4[0] == 1234.5678f && v4[1] == 8765.4321f) buffer_store_f32x4(v4, yr, off, 0);
-          continue;
-#endif
           if (rowok && ox >= 0 && ox + 3 < a.ow) {
-            buffer_store_f32x4(v4, yr, off, 0);
+            if (a.nt_store) buffer_store_f32x4_nt(v4, yr, off, 0);
+            else buffer_store_f32x4(v4, yr, off, 0);
           } else if (rowok) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -1509,9 +1605,6 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
           }
         }
       } else {
-#ifdef GG_EXP_CONVT_PITCH
-        if (owp != a.ow) continue;
-#endif
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
           const int idx = it * 64 + lane;
@@ -2731,7 +2824,21 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
   }
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
-  if (a.mask_ref) {          // limbs == 2 (checked by the caller)
+  if (a.mask_ref && a.f16) {     // masked data gradient on binary16 limbs (block exponents: any gradient magnitude)
+    if (narrow && tpix == 256) {
+      if (sc) conv3x3_patch_kernel<2, true, 256, 1, true, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 256, 1, true, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+    } else if (narrow) {
+      if (sc) conv3x3_patch_kernel<2, true, 128, 1, true, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 128, 1, true, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+    } else if (tpix == 256) {
+      if (sc) conv3x3_patch_kernel<2, true, 256, 2, true, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 256, 2, true, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+    } else {
+      if (sc) conv3x3_patch_kernel<2, true, 128, 2, true, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 128, 2, true, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+    }
+  } else if (a.mask_ref) {   // limbs == 2 (checked by the caller)
     if (narrow && tpix == 256) {
       if (sc) LIMBS12(limbs, conv3x3_patch_kernel<L, true, 256, 1, true><<<grid, 512, 0, st>>>(a, tw_log2));
       else LIMBS12(limbs, conv3x3_patch_kernel<L, false, 256, 1, true><<<grid, 512, 0, st>>>(a, tw_log2));
@@ -3023,7 +3130,7 @@ template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {
   if (a.mask_ref) {
     int tw_log2;
-    if (a.f16 || !((limbs == 1 || limbs == 2) && KS == 3 && mode == 0 && stride == 1 && pad == 1)) return kNotFused;
+    if (!((limbs == 1 || limbs == 2) && KS == 3 && mode == 0 && stride == 1 && pad == 1)) return kNotFused;
     const long long tiles256 = (long long)a.batch * a.oh * a.ow / 256 * ((a.cout_g + 127) / 128) * a.groups;
     if (tiles256 >= 2 * gg::kNumCu && a.cin_g > patch256_min_cin() && patch_geometry(a, 256, tw_log2))
       return launch_conv_patch(a, limbs, tw_log2, 256, st);
@@ -3151,7 +3258,7 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   if (mode == 1 && stride != 2)
     return gg::fail(-2, "conv2d: transposed mode is implemented for stride 2 (stride 1 = mode 0 with flipped taps)");
   const bool f16 = (limbs & 16) != 0;      // format code: bit 4 = binary16 limbs (see Limb<>), low bits = limb count
-  if (f16 && (limbs != 18 || mask.ref)) return gg::fail(-2, "conv2d_split: binary16 limbs come in pairs (code 18), forward only");
+  if (f16 && limbs != 18) return gg::fail(-2, "conv2d_split: binary16 limbs come in pairs (code 18)");
   limbs &= 15;
   if (limbs) {
     if (limbs < 1 || limbs > 3) return gg::fail(-2, "conv2d_split: limbs must be 1, 2, 3 or 18");
@@ -3182,6 +3289,9 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
     if (out_w > 0) { if (out_w < a.ow || out_w >= a.ow + stride) return gg::fail(-2, "conv2d: bad out_w"); a.ow = out_w; }
   }
   if (a.oh <= 0 || a.ow <= 0) return 0;
+  static const int nt_env = env_int("GG_NT_STORE", -1);             // measurement override: 0 = never, 1 = always
+  a.nt_store = nt_env >= 0 ? nt_env
+                           : ((long long)batch * groups * cout_g * a.oh * a.ow * 4 > kNtStoreBytes ? 1 : 0);
   hipStream_t st = gg::as_stream(stream);
   return ksize == 3 ? conv_dispatch<3>(a, stride, pad, mode, st, limbs) : conv_dispatch<1>(a, stride, pad, mode, st, limbs);
 }
@@ -3224,7 +3334,7 @@ extern "C" int gg_conv3x3_masked_dgrad_f32(float* y, const float* x, const float
                                            const float* in_scale, const float* out_scale, int batch, int cin,
                                            int cout, int h, int w, void* stream) {
   if (!mask_ref) return gg::fail(-2, "conv3x3_masked_dgrad: mask_ref missing");
-  if (limbs != 1 && limbs != 2) return kNotFused;
+  if (limbs != 1 && limbs != 2 && limbs != 18) return kNotFused;
   MaskArgs mask;
   mask.ref = mask_ref; mask.alpha = alpha; mask.gain = gain;
   return conv2d_entry(y, x, nullptr, wsplit, limb_stride, limbs, in_scale, out_scale, nullptr, batch, 1, cin, cout, h,

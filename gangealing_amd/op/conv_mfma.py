@@ -47,13 +47,18 @@ import os as _os
 PRECISION = _os.environ.get('GANGEALING_CONV_PRECISION', 'fp32')
 _LIMBS = {'fp32': 0, 'bf16': 1, 'bf16x3': 2, 'bf16x6': 3, 'fp16x3': 2}
 _F16_FORWARD = frozenset(['fp16x3'])
+# Round 4: the DATA-gradient convolutions of fp16x3 run on binary16 limbs too.  What kept them on bf16 limbs in round 3
+# was binary16's exponent range (gradients sit at 1e-8 .. 1e-2); the kernels now carry a block exponent per tile that is
+# taken from the data (csrc/conv_mfma.hip, BlockExp), so any magnitude is staged at full limb precision.  Weight
+# gradients keep bf16 limbs.  GANGEALING_F16_GRADS=0 restores round 3's arithmetic (A/B).
+_F16_GRAD = frozenset(['fp16x3']) if _os.environ.get('GANGEALING_F16_GRADS', '1') != '0' else frozenset()
 
 
 def limb_code(grad=False):
     """Format code of the split-precision entry points for the current mode: limb count, + 16 when the limbs are
-    binary16 (forward launches of the fp16x3 mode; `grad` = the launch is a gradient convolution)."""
+    binary16 (the fp16x3 mode; `grad` = the launch is a data-gradient convolution)."""
     limbs = _LIMBS[PRECISION]
-    return limbs | 16 if (PRECISION in _F16_FORWARD and not grad) else limbs
+    return limbs | 16 if PRECISION in (_F16_GRAD if grad else _F16_FORWARD) else limbs
 
 
 def set_precision(mode):
@@ -642,8 +647,8 @@ def masked_dgrad(dy, y_act, alpha, gain, wmat_bwd, n, cin, cout, h, w, in_scale=
     """Data gradient of a 3x3 conv + leaky-ReLU layer with the activation's backward applied while the gradient is
     gathered (gg_conv3x3_masked_dgrad_f32): no separate masked-gradient tensor.  `cin` = reduction channels (the
     layer's output channels), `cout` = the layer's input channels.  None when the shape is not served."""
-    limbs = _LIMBS[PRECISION]
-    if limbs not in (1, 2) or 'mask_dgrad' in DISABLED or not isinstance(wmat_bwd, PackedWeight) or \
+    limbs = limb_code(grad=True)
+    if limbs not in (1, 2, 18) or 'mask_dgrad' in DISABLED or not isinstance(wmat_bwd, PackedWeight) or \
             not wmat_bwd.split_ok():
         return None
     wbuf, stride_l = wmat_bwd.split(limbs)

@@ -1,7 +1,7 @@
 """Golden vectors at BASELINE.json's own configurations, produced by the REFERENCE on CPU.
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py); authoring container only (needs /root/reference).
 
-    python oracle/make_golden_configs.py [c2_generator c2_stn c1 c2 c2t c2r c4 c5 lpips lpips_masks]      # ~15 min on 8 cores for all
+    python oracle/make_golden_configs.py [c2_generator c2_stn c1 c2 c2t c2r c4 c5 c4b4 c5b4 c4b16 c5b8 lpips lpips_masks]      # ~15 min on 8 cores for all
 
 Writes tests/golden/{c2_generator,c2_stn,cfg_c1,cfg_c2,cfg_c2t,cfg_c4,cfg_c5,lpips}.npz.  The reference runs unmodified: its
 modules are imported exactly as oracle/make_golden.py does, plus a local VGG16 `features` stack placed where
@@ -223,7 +223,8 @@ if __name__ == '__main__':
     only = sys.argv[1:]
     jobs = dict(lpips=lambda: gen_lpips(api), lpips_masks=lambda: gen_lpips_masks(api), c2_generator=lambda: gen_c2_generator(api), c2_stn=lambda: gen_c2_stn(api),
                 c1=lambda: gen_config(api, 'c1'), c5=lambda: gen_config(api, 'c5'), c4=lambda: gen_config(api, 'c4'),
-                c2=lambda: gen_config(api, 'c2'), c2t=lambda: gen_config(api, 'c2t'), c2r=lambda: gen_config(api, 'c2r'))
+                c2=lambda: gen_config(api, 'c2'), c2t=lambda: gen_config(api, 'c2t'), c2r=lambda: gen_config(api, 'c2r'),
+                **{n: (lambda n=n: gen_config(api, n)) for n in ('c4b4', 'c5b4', 'c4b16', 'c5b8')})
     for name, fn in jobs.items():
         if only and name not in only:
             continue

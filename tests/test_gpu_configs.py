@@ -221,12 +221,16 @@ def test_c2_stn_batch16(ci, mode, cuda):
                 floor_scale=SIM_FLOOR_SCALE)
 
 
-@pytest.mark.parametrize('name', ['c1', 'c2', 'c2t', 'c4', 'c5'])
+@pytest.mark.parametrize('name', ['c1', 'c2', 'c2t', 'c2r', 'c4', 'c5', 'c4b4', 'c5b4', 'c4b16', 'c5b8'])
 def test_config_loss_step(name, mode, cuda):
     """One loss evaluation + backward of BASELINE config `name` (train.py:106-124) through the same driver that ran
     the reference.  c2t = c2 with textured generator images (per-pixel noise at full strength: neighbouring pixels of
     the warped 128^2 output differ by 0.07 on average at amplitude 2.5); c1 = configs[0], similarity-only STN (its
-    "flow" is the (N, 2, 3) matrix and there are no flow regularisers)."""
+    "flow" is the (N, 2, 3) matrix and there are no flow regularisers).  Round 4: c2r = c2 with a wide dynamic range
+    inside the generator (style layers drawn with scales 1e-5 .. 1e5: the operands of the modulated convolutions span
+    1e-5 .. 3e5 from layer to layer - outside binary16's range in both directions; the block exponents of the fp16x3
+    kernels have to hold 1e-4 there); c4 / c5 at the batch `bench.py --workload c4|c5` runs (4) and at the per-GPU
+    batch of the reference's 8-GPU recipes (16; c5 at 8 - its float64 reference run at 16 exceeds the authoring container's memory): the batch decides which tile variant each convolution launches."""
     from oracle import config_cases as cc
     (c,) = load_golden(f'cfg_{name}')
     res = cc.run_config(our_api(), name, cuda)
