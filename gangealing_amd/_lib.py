@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GANGEALING_HIP_LIB selects another build of the same library (kernel A/B measurements); the ABI check still applies.
 LIB_PATH = os.environ.get('GANGEALING_HIP_LIB') or os.path.join(_HERE, 'lib', 'libgangealing_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 NOT_SERVED = -1000            # GG_NOT_SERVED of the header
 
 # signature alphabet: p device pointer (tensor or None), i int, q long long, f float, d double, s stream
@@ -85,7 +85,7 @@ class HipLibraryError(RuntimeError):
 
 
 def exported_symbols():
-    return ['gg_abi_version', 'gg_last_error', 'gg_build_arch', 'gg_scratch_release'] + sorted(_PROTOS)
+    return ['gg_abi_version', 'gg_last_error', 'gg_build_arch', 'gg_scratch_release', 'gg_set_allocator'] + sorted(_PROTOS)
 
 
 def load():
@@ -109,8 +109,43 @@ def load():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [_CTYPE[c] for c in proto]
+    _install_allocator(lib)
     _lib = lib
     return lib
+
+
+# The library's scratch (partial results of split reductions) comes out of torch's caching allocator: no hipMalloc
+# outside torch's accounting (which fails once torch has reserved most of HBM), and growth while a stream is being
+# captured is legal (torch serves it from the graph's private pool).  The tensors are kept alive here until the library
+# hands the pointer back (gg_scratch_release); allocation happens on torch's current stream = the stream `call` launches on.
+_ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_longlong)
+_FREE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+_SCRATCH_TENSORS = {}
+_CALLBACKS = []
+
+
+def _install_allocator(lib):
+    if os.environ.get('GANGEALING_SCRATCH_HIPMALLOC') == '1' or not torch.cuda.is_available():
+        return
+
+    def alloc(nbytes):
+        try:
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=torch.device('cuda', torch.cuda.current_device()))
+        except Exception:            # noqa: BLE001 - reported by the library as an allocation failure
+            return None
+        _SCRATCH_TENSORS[t.data_ptr()] = t
+        return t.data_ptr()
+
+    def free(ptr):
+        _SCRATCH_TENSORS.pop(ptr, None)
+
+    cbs = (_ALLOC_FN(alloc), _FREE_FN(free))
+    _CALLBACKS.append(cbs)           # ctypes callbacks must outlive the library's use of them
+    lib.gg_set_allocator.restype = ctypes.c_int
+    lib.gg_set_allocator.argtypes = [_ALLOC_FN, _FREE_FN]
+    rc = lib.gg_set_allocator(*cbs)
+    if rc != 0:
+        raise HipLibraryError(f'gg_set_allocator failed: {lib.gg_last_error().decode()}')
 
 
 class Strided:

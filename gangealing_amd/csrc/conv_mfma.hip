@@ -3440,10 +3440,16 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
     long long upb = tiles * total_units / (2LL * gg::kNumCu);
     if (upb < 1) upb = 1;
     if (upb > 8) upb = 8;
+    // every split costs a partial tile of 144 KB per (co, ci) tile: bound the partials at 1 GiB by chaining more
+    // K-units per block (fewer, longer blocks) instead of asking the allocator for whatever the shape implies
+    constexpr long long kMaxPartialBytes = 1LL << 30;
+    while (upb < total_units &&
+           tiles * ((total_units + upb - 1) / upb) * 9LL * 4096 * (long long)sizeof(float) > kMaxPartialBytes)
+      upb *= 2;
     const long long splits = (total_units + upb - 1) / upb;
     const long long need_dw = tiles * splits * 9LL * 4096 * (long long)sizeof(float);
     const long long need = need_dw + (dbias ? splits * (long long)groups * cout_g * (long long)sizeof(float) : 0);
-    if ((!workspace || workspace_bytes < need) && need < (8LL << 30)) {   // no caller workspace: the stream's scratch
+    if ((!workspace || workspace_bytes < need) && need < (2LL << 30)) {   // no caller workspace: the stream's scratch
       workspace = reinterpret_cast<float*>(gg::scratch(st, (size_t)need));
       if (!workspace) return -3;
       workspace_bytes = need;

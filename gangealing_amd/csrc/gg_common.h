@@ -75,9 +75,9 @@ __device__ __forceinline__ T block_sum_256(T v, T* smem) {
 // summation order, whatever order the blocks ran in (one atomic add per block would combine them in arrival order: a
 // different rounding every run).  Returns true in thread 0 of that last block, with v[] = the totals; the counter is
 // left at zero for the next launch.  `smem`: >= 4 values of block-shared scratch.
-// Hand-off protocol of the CDNA4 guide (inter-workgroup communication): write-through (agent-scope relaxed atomic =
-// sc1) payload stores, drained, THEN the ticket; the last arriver issues one agent-scope acquire (per-CU L1 is never
-// refreshed by other CUs' stores) and reads with agent-scope loads.
+// Hand-off protocol of the CDNA4 guide (inter-workgroup communication): agent-scope payload stores, an agent-scope
+// RELEASE fence, THEN the ticket; the last arriver issues one agent-scope ACQUIRE (per-CU L1 is never refreshed by
+// other CUs' stores) and reads with agent-scope loads.
 template <typename T, int NV>
 __device__ __forceinline__ bool ordered_grid_sum(T (&v)[NV], T* part, unsigned* ticket, int row, int blk, int nblk,
                                                  T* smem) {
@@ -87,7 +87,9 @@ __device__ __forceinline__ bool ordered_grid_sum(T (&v)[NV], T* part, unsigned* 
     T* mine = part + ((size_t)row * nblk + blk) * NV;
 #pragma unroll
     for (int i = 0; i < NV; ++i) __hip_atomic_store(mine + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // release at agent scope: the payload is visible to the agent before the ticket is (the memory model's statement of
+    // "drain the stores, then arrive"; round 3 relied on s_waitcnt vmcnt(0) + write-through stores)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const unsigned t = __hip_atomic_fetch_add(ticket + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_arriver = (t == (unsigned)(nblk - 1)) ? 1u : 0u;
     if (t == (unsigned)(nblk - 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

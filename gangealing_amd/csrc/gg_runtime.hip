@@ -36,6 +36,32 @@ int launch_status(const char* what) {
 // buffer.  Buffers only grow (geometrically); outgrown ones stay allocated until gg_scratch_release(), because
 // launches already enqueued - or captured into a hipGraph - still reference them.
 namespace {
+// Where scratch memory comes from.  Default: hipMalloc / hipFree.  A host framework that runs its own caching
+// allocator installs it here (gg_set_allocator; gangealing_amd/_lib.py installs torch's): the library's buffers then
+// live inside the framework's pool - visible to its accounting, satisfiable after it has reserved most of HBM (it
+// releases cached blocks and retries), and legal while a stream is being captured into a hipGraph (torch serves
+// capture-time allocations from the graph's private pool).
+gg_alloc_fn g_alloc = nullptr;
+gg_free_fn g_free = nullptr;
+
+void* dev_alloc(size_t bytes, hipError_t* err) {
+  *err = hipSuccess;
+  if (g_alloc) {
+    void* p = g_alloc((long long)bytes);
+    if (!p) *err = hipErrorOutOfMemory;
+    return p;
+  }
+  void* p = nullptr;
+  *err = hipMalloc(&p, bytes);
+  if (*err != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+  return p;
+}
+void dev_free(void* p) {
+  if (!p) return;
+  if (g_free) g_free(p);
+  else (void)hipFree(p);
+}
+
 struct ScratchEntry {
   void* buf = nullptr;
   size_t bytes = 0;
@@ -61,12 +87,12 @@ void* scratch(hipStream_t st, size_t bytes) {
   if (want < bytes) want = bytes;
   const size_t gran = (size_t)1 << 24;                       // 16 MiB granules
   want = (want + gran - 1) / gran * gran;
-  void* p = nullptr;
-  const hipError_t err = hipMalloc(&p, want);                 // (not legal while the stream is being captured: the
-  if (err != hipSuccess || !p) {                              //  eager warm-up iterations size the buffer first)
-    (void)hipGetLastError();
-    fail((int)err, "scratch: hipMalloc(%zu) failed: %s (during a hipGraph capture?  run the step eagerly once "
-         "before capturing, or call gg_scratch_reserve)", want, hipGetErrorString(err));
+  hipError_t err;
+  void* p = dev_alloc(want, &err);                            // (plain hipMalloc is not legal during a capture: see
+  if (!p) {                                                   //  gg_set_allocator / gg_scratch_reserve)
+    fail((int)err, "scratch: allocation of %zu bytes failed: %s (during a hipGraph capture without an installed "
+         "allocator?  run the step eagerly once before capturing, or call gg_scratch_reserve)", want,
+         hipGetErrorString(err));
     return nullptr;
   }
   if (e->buf) e->retired.push_back(e->buf);
@@ -80,9 +106,10 @@ unsigned* tickets(hipStream_t st) {
   ScratchEntry* e = scratch_entry(st);
   if (!e) { fail(-3, "tickets: no current device"); return nullptr; }
   if (e->tickets) return e->tickets;
-  void* p = nullptr;
-  hipError_t err = hipMalloc(&p, sizeof(unsigned) * kTickets);
-  if (err == hipSuccess) err = hipMemset(p, 0, sizeof(unsigned) * kTickets);
+  hipError_t err;
+  void* p = dev_alloc(sizeof(unsigned) * kTickets, &err);
+  // cleared on the stream whose kernels will use them (stream-ordered, and legal inside a capture)
+  if (p) err = hipMemsetAsync(p, 0, sizeof(unsigned) * kTickets, st);
   if (err != hipSuccess || !p) {
     (void)hipGetLastError();
     fail((int)err, "tickets: allocation failed: %s", hipGetErrorString(err));
@@ -106,14 +133,25 @@ extern "C" int gg_scratch_release(void) {
   std::lock_guard<std::mutex> lock(gg::g_scratch_mu);
   if (hipDeviceSynchronize() != hipSuccess) return gg::fail(-3, "scratch_release: device synchronisation failed");
   for (auto& kv : gg::g_scratch) {
-    for (void* p : kv.second.retired) (void)hipFree(p);
-    if (kv.second.buf) (void)hipFree(kv.second.buf);
-    if (kv.second.tickets) (void)hipFree(kv.second.tickets);
+    for (void* p : kv.second.retired) gg::dev_free(p);
+    gg::dev_free(kv.second.buf);
+    gg::dev_free(kv.second.tickets);
   }
   gg::g_scratch.clear();
   return 0;
 }
 
-extern "C" int gg_abi_version(void) { return 2; }
+extern "C" int gg_set_allocator(gg_alloc_fn alloc, gg_free_fn free_fn) {
+  std::lock_guard<std::mutex> lock(gg::g_scratch_mu);
+  if ((alloc == nullptr) != (free_fn == nullptr)) return gg::fail(-2, "set_allocator: both functions or neither");
+  if (!gg::g_scratch.empty())
+    return gg::fail(-2, "set_allocator: scratch buffers exist already (install the allocator first, or call "
+                        "gg_scratch_release)");
+  gg::g_alloc = alloc;
+  gg::g_free = free_fn;
+  return 0;
+}
+
+extern "C" int gg_abi_version(void) { return 3; }
 extern "C" const char* gg_last_error(void) { return gg::g_err; }
 extern "C" const char* gg_build_arch(void) { return "gfx950"; }

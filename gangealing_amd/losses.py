@@ -52,7 +52,11 @@ def sample_gan_supervised_pairs(generator, ll, resize_fake2stn, psi, batch, dim_
         # the main stream with no dependency between them: a read-before-write race on the first iteration and after
         # every weight load.  So the first call for a given set of weight versions (and arithmetic mode) runs both
         # passes on the current stream - which builds every cache there - and only later calls fork.
-        key = (conv_mfma.PRECISION, z.device, psi is not None) + tuple(p._version for p in generator.parameters())
+        # (storage address + version of every parameter: in-place updates bump the version, `p.data = ...` / .to()
+        # re-pointing changes the address.  ~130 parameters: tens of microseconds of host time per step, hidden behind
+        # a GPU-bound step)
+        key = (conv_mfma.PRECISION, z.device, psi is not None) + tuple(
+            (p.data_ptr(), p._version) for p in generator.parameters())
         if generator.__dict__.get('_two_stream_ready') != key:
             generator.__dict__['_two_stream_ready'] = key
             overlap = False

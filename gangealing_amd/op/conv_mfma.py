@@ -315,7 +315,12 @@ _SLOTS_ACTIVE = False
 
 
 class grad_slots:
-    """Context manager: weight gradients of registered parameters accumulate into their arena slots."""
+    """Context manager: weight gradients of registered parameters accumulate into their arena slots.
+
+    Enter it ONLY around the `.backward()` call whose gradients are meant for the arena (the trainer's
+    `total.backward()`).  Inside the block the backward of a registered parameter ADDS into the arena and hands autograd
+    None, so a `torch.autograd.grad(..., inputs=[registered parameter])` issued there would see no gradient for it while
+    the arena changes: run diagnostics, penalties on parameter gradients and second losses outside the block."""
 
     def __enter__(self):
         global _SLOTS_ACTIVE

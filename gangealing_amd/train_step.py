@@ -32,6 +32,13 @@ class FlatArena:
 
     def __init__(self, module):
         params = [p for p in module.parameters()]
+        # parameters whose backward can add straight into the arena (conv_mfma.grad_slots): trainable convolution
+        # weights and the biases of FusedLeakyReLU activations - nothing else is registered (other 1-D parameters get
+        # their gradient from autograd as usual)
+        from .op.fused_act import FusedLeakyReLU
+        self._slot_ids = {id(m.bias) for m in module.modules()
+                          if isinstance(m, FusedLeakyReLU) and getattr(m, 'bias', None) is not None}
+        self._slot_ids |= {id(p) for p in params if p.dim() == 4}
         self.numel = sum(p.numel() for p in params)
         dev = params[0].device
         self.param = torch.empty(self.numel, dtype=torch.float32, device=dev)
@@ -45,9 +52,8 @@ class FlatArena:
                 self.param[off:off + n].copy_(p.reshape(-1))
                 p.data = self.param[off:off + n].view(p.shape)
                 p.grad = self.grad[off:off + n].view(p.shape)
-                if p.dim() in (1, 4) and p.requires_grad:
-                    # trainable conv weights and activation biases: inside `with conv_mfma.grad_slots():` the backward
-                    # adds straight into the arena
+                if id(p) in self._slot_ids and p.requires_grad:
+                    # inside `with conv_mfma.grad_slots():` the backward adds straight into the arena
                     conv_mfma.register_grad_slot(p, p.grad)
                 off += n
         self.params = params
@@ -74,7 +80,7 @@ class FlatArena:
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + n].view(p.shape)
-                if p.dim() in (1, 4) and p.requires_grad:
+                if id(p) in self._slot_ids and p.requires_grad:
                     conv_mfma.register_grad_slot(p, p.grad)
             off += n
 
@@ -242,7 +248,10 @@ class GangealingTrainer:
             raise NotImplementedError('use_graph: single-process only (the multi-GPU path keeps the pipelined eager step)')
         self._graph = None
         self._graph_calls = 0
-        self._graph_warmup = max(int(graph_warmup), 1)
+        # two eager iterations at least when the generator passes fork onto a side stream (batch <= 8): the first call
+        # of sample_gan_supervised_pairs does not fork (it builds the weight caches on one stream), so only the second
+        # creates the side stream's scratch / ticket page - which must exist before the capture, not inside it
+        self._graph_warmup = max(int(graph_warmup), 2 if batch <= 8 else 1)
         self._psi_dev = torch.zeros((), dtype=torch.float32, device=device)
         self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=device)        # [stn x4, ll x4]
         self._cap_stream = None

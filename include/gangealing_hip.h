@@ -32,13 +32,22 @@ extern "C" {
 
 #define GG_NOT_SERVED (-1000)
 
-/* 2: library-owned scratch (gg_scratch_*), gg_lpips_tail_bwd_f32 gained `accumulate` */
+/* 2: library-owned scratch (gg_scratch_*), gg_lpips_tail_bwd_f32 gained `accumulate`
+ * 3: gg_set_allocator; binary16 limbs (format code 18) accepted by the data-gradient entry points */
 int gg_abi_version(void);
 /* Pre-size the scratch buffer of `stream` on the current device to at least `bytes` (and create its ticket page).
  * Optional: the entry points grow it on demand. */
 int gg_scratch_reserve(long long bytes, void* stream);
 /* Free every scratch buffer (synchronises the device).  Graphs captured earlier must not be replayed afterwards. */
 int gg_scratch_release(void);
+/* ABI 3: source of the scratch memory.  By default the library calls hipMalloc / hipFree.  A host that runs a caching
+ * device allocator installs it here BEFORE the first scratch use: `alloc(bytes)` returns device memory valid on the
+ * current device and usable on the calling thread's current stream (NULL on failure), `free(ptr)` takes it back.
+ * gangealing_amd/_lib.py installs torch's allocator: the scratch is then part of torch's pool (no allocation outside
+ * its accounting, and growth during a hipGraph capture is legal).  Pass two NULLs to restore the default. */
+typedef void* (*gg_alloc_fn)(long long bytes);
+typedef void (*gg_free_fn)(void* ptr);
+int gg_set_allocator(gg_alloc_fn alloc, gg_free_fn free_fn);
 const char* gg_last_error(void);
 /* Name of the gfx target the device code was built for ("gfx950"). */
 const char* gg_build_arch(void);

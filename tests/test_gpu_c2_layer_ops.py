@@ -26,10 +26,10 @@ pytestmark = pytest.mark.gpu
 MODES = ['fp32', 'bf16x3', 'fp16x3', 'bf16']
 # 'bf16' (one bf16 limb per operand) is the plain-bf16 arithmetic of BASELINE.json's benchmark configuration, not a
 # parity mode: operands carry 8 mantissa bits, errors of a 4608-term dot product are ~3e-3 of the largest output
-# 'fp16x3': binary16 limbs on the forward convolutions (fp32-class: held to the fp32 kernels' bound there), bf16 limbs on
-# the gradient convolutions (the bf16x3 bound)
+# 'fp16x3': binary16 limbs with a per-tile block exponent on the forward AND (round 4) the data-gradient convolutions -
+# fp32-class, held to the fp32 kernels' bound there; bf16 limbs on the weight gradients (the bf16x3 bound)
 TOL = {'fp32': 2e-5, 'bf16x3': 5e-5, 'fp16x3': 5e-5, 'bf16': 2e-2}
-FWD_TOL = {'fp16x3': 2e-5}
+FWD_TOL = {'fp16x3': 2e-5}                 # applies to 'forward' and 'dgrad' checks
 N = 16
 
 
@@ -55,7 +55,7 @@ def check(test, mode, name, got, ref):
     from conftest import PARITY
     PARITY.setdefault('c2_layer_ops', {}).setdefault(mode, {})[f'{test}/{name}'] = dict(
         max_err_rel_to_max=err / scale, rel_l2_err=l2)
-    tol = FWD_TOL.get(mode, TOL[mode]) if 'forward' in name else TOL[mode]
+    tol = FWD_TOL.get(mode, TOL[mode]) if ('forward' in name or 'dgrad' in name) else TOL[mode]
     assert err <= tol * scale, (test, name, err / scale, l2)
 
 

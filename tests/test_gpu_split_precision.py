@@ -132,7 +132,18 @@ def test_styled_conv_fused_activation_matches_unfused(shape, mode_name, cuda, pr
     scale = float(ref.detach().abs().max())
     # same kernels, same accumulation order: only the epilogue's fused multiply-add differs
     assert float((fused - ref).detach().abs().max()) <= 2e-6 * scale
-    assert float((dx_fused - dx_ref).abs().max()) <= 2e-6 * float(dx_ref.abs().max())
+    # The two backward passes take their leaky-ReLU masks from their OWN forward outputs, which differ by ~1e-7: an
+    # activation that close to zero takes the other branch in one of them (measured: one such unit among 4.2 M in the
+    # 256^2 case moves a 3x3 neighbourhood of dx by 5e-3 of the largest entry).  Without a flip the gradients agree to
+    # rounding; with flips only the mean-square error is bounded.
+    flips = int(((fused > 0) != (ref > 0)).sum())
+    err = (dx_fused - dx_ref).abs()
+    if flips == 0:
+        assert float(err.max()) <= 2e-6 * float(dx_ref.abs().max())
+    else:
+        assert flips <= 4, flips
+        assert float(err.norm() / dx_ref.norm()) <= 2e-4 * flips ** 0.5, (flips, float(err.max()))
+        assert float((err > 2e-6 * float(dx_ref.abs().max())).float().mean()) <= 1e-3 * flips
     # a style that needs a gradient (learned W+ slots) must keep the unfused path
     assert not layer.conv.can_fuse_act(x, style.clone().requires_grad_(True), layer.noise.weight, layer.activate.bias)
 
