@@ -20,7 +20,8 @@
  *     calls at the largest shapes); hipMalloc is not legal while a stream is being captured into a hipGraph, so run
  *     the step eagerly once before capturing it (or call gg_scratch_reserve).  Exceptions, documented at the entry
  *     points: the IMAGE gradient of the warp (gg_mipmap_warp_bwd_f32 with grad_pyr*, gg_mip_downsample2x_bwd_f32) and
- *     gg_splat_forward_f32 scatter with float atomics - neither is on the training path.
+ *     gg_splat_forward_f32 / gg_splat2d_f32 for points whose box exceeds 33 pixels scatter with float atomics -
+ *     neither is on the training path.
  *   - outputs are fully overwritten unless the comment says "accumulates".
  */
 #ifndef GANGEALING_HIP_H
@@ -147,6 +148,10 @@ int gg_blur4_fused_f32(float* out, const float* in, const float* kernel, int n, 
  * gg_splat2d_f32 replaces splat_forward_cuda (splat_gpu.c:12-42): output = clone(input) + splats,
  *   then output /= ((soft_normalize ? max(alpha,1) : alpha) + 1e-8).  alpha_ws is an (N,H,W)
  *   caller-provided workspace.
+ * Round 4: points whose +-2 sigma box is at most 33 pixels wide (sigma <= 8) are binned per 32 x 32-pixel tile (lists in
+ *   the library's scratch, sorted by point index) and gathered by one block per tile - no floating-point atomics, results
+ *   bitwise reproducible, every pixel written once (gg_splat2d_f32 fuses the normalisation into that write).  Larger
+ *   boxes use hardware float atomics (arrival order), as the reference kernel does for every point.
  * ------------------------------------------------------------------------------------------ */
 int gg_splat_forward_f32(const float* coords, const float* values, const float* sigma,
                          float* alpha_splats, float* output,

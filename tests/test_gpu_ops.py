@@ -308,6 +308,59 @@ def test_splat2d_against_live_reference_kernel(shape, cuda):
         assert err <= 5e-5 * max(1.0, float(want.abs().max())), (soft, err)
 
 
+@pytest.mark.parametrize('case', [
+    dict(n=2, c=3, h=96, w=130, p=4000, sigma=(1.3, 0.4), tag='two sigmas, ragged tiles'),
+    dict(n=1, c=6, h=64, w=64, p=1500, sigma=(2.0,), tag='two channel passes'),
+    dict(n=1, c=2, h=160, w=96, p=600, sigma=(12.0,), tag='boxes beyond 33 pixels: the atomic path'),
+    dict(n=2, c=1, h=128, w=128, p=800, sigma=(7.9, 9.5), tag='binned and large boxes in one call'),
+    dict(n=1, c=3, h=64, w=64, p=12000, sigma=(1.0,), crowd=True, tag='> 8192 points in one tile: global sort'),
+], ids=lambda c: c['tag'])
+def test_splat2d_binned_gather_against_restatement(case, cuda):
+    """Round 4 formulation (bins per 32x32 tile, lists sorted by point index, one gather block per tile, normalisation
+    fused into the single write per pixel) against the numpy restatement of the reference semantics (float64 sums),
+    on the cases that exercise its branches; and two calls are BITWISE identical whenever no box exceeds 33 pixels."""
+    from gangealing_amd.splat2d_cuda import splat2d
+    from oracle import np_ops
+    n, c, h, w, p = case['n'], case['c'], case['h'], case['w'], case['p']
+    g = torch.Generator().manual_seed(p + c)
+    if case.get('crowd'):
+        coords = torch.rand(n, p, 2, generator=g) * 20.0 + 5.0               # everything inside tile (0, 0)
+    else:
+        coords = torch.rand(n, p, 2, generator=g) * torch.tensor([w + 8.0, h + 8.0]) - 4.0
+    values = torch.randn(n, p, c, generator=g)
+    sigma = torch.tensor(case['sigma'], dtype=torch.float32)
+    inp = torch.randn(n, c, h, w, generator=g) * 0.1
+    for soft in (False, True):
+        want = np_ops.splat2d(inp.numpy(), coords.numpy(), values.numpy(), sigma.numpy(), soft)
+        got = splat2d(inp.to(cuda), coords.to(cuda), values.to(cuda), sigma.to(cuda), soft)
+        # un-normalised pixels that no point reached are input / 1e-8: compare relative to each plane's largest value
+        err = float(np.abs(got.cpu().numpy() - want).max() / max(1.0, float(np.abs(want).max())))
+        assert err <= 2e-5, (soft, err)
+        again = splat2d(inp.to(cuda), coords.to(cuda), values.to(cuda), sigma.to(cuda), soft)
+        if max(case['sigma']) <= 8.0:
+            assert torch.equal(got, again), 'binned gather must be bitwise reproducible'
+
+
+def test_splat_forward_accumulates_like_the_reference_entry_point(cuda):
+    """gg_splat_forward_f32 = SplatForwardGpu (splat_gpu_impl.cuh:11-22): ADDS alpha and alpha * value onto what the
+    two buffers hold (the torch glue pre-fills them with zeros / a copy of the input)."""
+    from gangealing_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    n, p, c, h, w = 2, 700, 3, 70, 45
+    coords = (torch.rand(n, p, 2, generator=g) * torch.tensor([w * 1.0, h * 1.0])).to(cuda)
+    values = torch.randn(n, p, c, generator=g).to(cuda)
+    sigma = torch.tensor([1.1, 2.3]).to(cuda)
+    alpha0 = torch.rand(n, h, w, generator=g).to(cuda)
+    out0 = torch.randn(n, c, h, w, generator=g).to(cuda)
+    alpha, out = alpha0.clone(), out0.clone()
+    _lib.call('gg_splat_forward_f32', coords, values, sigma, alpha, out, p, c, h, w, n * p)
+    za, zo = torch.zeros_like(alpha0), torch.zeros_like(out0)
+    _lib.call('gg_splat_forward_f32', coords, values, sigma, za, zo, p, c, h, w, n * p)
+    assert float(za.max()) > 0
+    assert float((alpha - (alpha0 + za)).abs().max()) <= 1e-5 * float(za.max())
+    assert float((out - (out0 + zo)).abs().max()) <= 1e-5 * float(zo.abs().max())
+
+
 def test_splat2d_errors(cuda):
     from gangealing_amd.splat2d_cuda import splat2d
     with pytest.raises(NotImplementedError):
