@@ -85,7 +85,8 @@ class HipLibraryError(RuntimeError):
 
 
 def exported_symbols():
-    return ['gg_abi_version', 'gg_last_error', 'gg_build_arch', 'gg_scratch_release', 'gg_set_allocator'] + sorted(_PROTOS)
+    return ['gg_abi_version', 'gg_last_error', 'gg_build_arch', 'gg_scratch_release', 'gg_set_allocator',
+            'gg_last_conv_kernel'] + sorted(_PROTOS)
 
 
 def load():
@@ -102,6 +103,8 @@ def load():
     lib.gg_last_error.restype = ctypes.c_char_p
     lib.gg_build_arch.restype = ctypes.c_char_p
     lib.gg_scratch_release.restype = ctypes.c_int
+    lib.gg_last_conv_kernel.restype = ctypes.c_char_p
+    lib.gg_last_conv_kernel.argtypes = []
     lib.gg_scratch_release.argtypes = []
     if lib.gg_abi_version() != ABI_VERSION:
         raise HipLibraryError(f'ABI mismatch: library {lib.gg_abi_version()} != python {ABI_VERSION}; rebuild')

@@ -528,12 +528,20 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
   int slab1 = slab0 + a.slabs_per_split;
   if (slab1 > a.nslabs) slab1 = a.nslabs;
 
-  float xa[EPT];
-  float4 rs4[EPT / 4];
-  U4 wv[LIMBS][EPT / 8];
-  bool x_ok = false;
+  // Two register sets, two slabs in flight: while slab s is multiplied, slab s + 1 waits complete in the other set (its
+  // loads were issued one slab earlier) and slab s + 2 is being fetched into the set that slab s just vacated.  Round
+  // 3 had one set: a slab's loads had only the previous slab's MFMAs to land.  With binary16 limbs the waiting slab
+  // is also finished (zero padding, style) and measured (block exponent, see BlockExp) next to the current slab's MFMAs.
+  struct SlabRegs {
+    float xa[EPT];
+    float4 rs4[EPT / 4];
+    U4 wv[LIMBS][EPT / 8];
+    bool x_ok;
+  };
+  SlabRegs ra, rb;
+  ra.x_ok = rb.x_ok = false;
 
-  auto load_slab = [&](int slab) {
+  auto load_slab = [&](int slab, SlabRegs& R) {
     const int t = slab / cslabs;
     const int ci0 = (slab - t * cslabs) * BKS;
     int ky, kx, dy, dx;
@@ -545,55 +553,55 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
       ky = a.py + 2 * jy; kx = a.px + 2 * jx; dy = -jy; dx = -jx;
     }
     const int iy = base_y + dy, ix = base_x + dx;
-    x_ok = m_ok & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
+    R.x_ok = m_ok & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
     const int cbase = ci0 + khalf * EPT;
     if (xbuf) {
-      const unsigned vo = x_ok ? (unsigned)(chan0 * hw + iy * a.w + ix) * 4u : kOobOffset;
+      const unsigned vo = R.x_ok ? (unsigned)(chan0 * hw + iy * a.w + ix) * 4u : kOobOffset;
       const int so = __builtin_amdgcn_readfirstlane((ci0 + khalf_u * EPT) * hw * 4);
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) xa[j] = buffer_load_f32(xrs, vo, so + j * hw * 4);
+      for (int j = 0; j < EPT; ++j) R.xa[j] = buffer_load_f32(xrs, vo, so + j * hw * 4);
     } else {
-      const float* src = xg + (x_ok ? (size_t)cbase * hw + iy * a.w + ix : 0);
-      const int step = x_ok ? hw : 0;
+      const float* src = xg + (R.x_ok ? (size_t)cbase * hw + iy * a.w + ix : 0);
+      const int step = R.x_ok ? hw : 0;
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) xa[j] = src[(size_t)j * step];
+      for (int j = 0; j < EPT; ++j) R.xa[j] = src[(size_t)j * step];
     }
     if (IN_SCALE) {
       const float4* s4 = reinterpret_cast<const float4*>(sg + cbase);
 #pragma unroll
-      for (int j = 0; j < EPT / 4; ++j) rs4[j] = s4[j];
+      for (int j = 0; j < EPT / 4; ++j) R.rs4[j] = s4[j];
     }
     const unsigned short* wsrc = wrow_ptr + (size_t)(ky * KS + kx) * a.cin_g + ci0;
 #pragma unroll
     for (int l = 0; l < LIMBS && w_thr; ++l) {
       const U4* w4 = reinterpret_cast<const U4*>(wsrc + (size_t)l * a.wsplit_stride);
 #pragma unroll
-      for (int q = 0; q < EPT / 8; ++q) wv[l][q] = w4[q];
+      for (int q = 0; q < EPT / 8; ++q) R.wv[l][q] = w4[q];
     }
   };
   // the gathered slab in its final fp32 form (zero padding, style); binary16 limbs: + this wave's largest magnitude
   // for the block exponent (see BlockExp)
   __shared__ float sAmax[16];
   BlockExp bexp;
-  auto prep_slab = [&]() {
+  auto prep_slab = [&](SlabRegs& R) {
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) xa[j] = x_ok ? xa[j] : 0.f;
+    for (int j = 0; j < EPT; ++j) R.xa[j] = R.x_ok ? R.xa[j] : 0.f;
     if (IN_SCALE) {
-      const float* rs = reinterpret_cast<const float*>(rs4);
+      const float* rs = reinterpret_cast<const float*>(R.rs4);
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) xa[j] *= rs[j];
+      for (int j = 0; j < EPT; ++j) R.xa[j] *= rs[j];
     }
     if (F16) {
       float m = 0.f;
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) m = fmaxf(m, fabsf(xa[j]));
+      for (int j = 0; j < EPT; ++j) m = fmaxf(m, fabsf(R.xa[j]));
       publish_wave_amax(m, sAmax, wid, lane);
     }
   };
-  auto store_slab = [&]() {
+  auto store_slab = [&](SlabRegs& R) {
     float v[EPT];
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) v[j] = xa[j];
+    for (int j = 0; j < EPT; ++j) v[j] = R.xa[j];
     if (F16 && bexp.e != 0) {                      // uniform branch: most tiles never leave E = 0
       const float ps = exp2i(-bexp.e);
 #pragma unroll
@@ -616,7 +624,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
 #pragma unroll
       for (int q = 0; q < EPT / 8; ++q) {
         dst[q] = U4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
-        if (w_thr) wd[q] = w_ok ? wv[l][q] : z;
+        if (w_thr) wd[q] = w_ok ? R.wv[l][q] : z;
       }
     }
   };
@@ -629,60 +637,65 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (slab0 < slab1) {
-    const int kh = lane >> 5, l31 = lane & 31;
-    load_slab(slab0);
-    if (F16) {
-      prep_slab();
-      __syncthreads();
+  const int kh = lane >> 5, l31 = lane & 31;
+  // one slab: `cur` holds it (loaded two slabs ago, and - binary16 limbs - already finished and measured), `nxt` the
+  // following one
+  auto step = [&](int slab, SlabRegs& cur, SlabRegs& nxt) {
+    if (F16) {            // the slab's block exponent (published behind the previous barrier)
+      const float f = block_exp_update(bexp, read_block_amax<NT / 64>(sAmax));
+      if (f != 1.f) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+      }
+    } else {
+      prep_slab(cur);
     }
-    for (int slab = slab0; slab < slab1; ++slab) {
-      if (F16) {            // the slab's block exponent (published behind the previous barrier)
-        const float f = block_exp_update(bexp, read_block_amax<NT / 64>(sAmax));
-        if (f != 1.f) {
+    store_slab(cur);
+    __syncthreads();
+    if (slab + 2 < slab1) load_slab(slab + 2, cur);
+    if (F16 && slab + 1 < slab1) prep_slab(nxt);          // next to the MFMAs below; published by the closing barrier
+#pragma unroll
+    for (int ks = 0; ks < BKS / 16; ++ks) {
+      bf16x8 fa[LIMBS][MI], fb[LIMBS][NJ];
+#pragma unroll
+      for (int l = 0; l < LIMBS; ++l) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          fa[l][i] = *reinterpret_cast<const bf16x8*>(&sW[l][((wco * MI + i) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          fb[l][j] = *reinterpret_cast<const bf16x8*>(&sX[l][((wpix * NJ + j) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
+      }
+      // smallest terms first
+#pragma unroll
+      for (int sum = LIMBS - 1; sum >= 0; --sum)
+#pragma unroll
+        for (int la = 0; la <= sum; ++la) {
+          const int lb = sum - la;
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+              acc[i][j] = L::mfma(fa[la][i], fb[lb][j], acc[i][j]);
         }
-      } else {
-        prep_slab();
-      }
-      store_slab();
+    }
+    __syncthreads();
+  };
+
+  if (slab0 < slab1) {
+    load_slab(slab0, ra);
+    if (slab0 + 1 < slab1) load_slab(slab0 + 1, rb);
+    if (F16) {
+      prep_slab(ra);
       __syncthreads();
-      if (slab + 1 < slab1) load_slab(slab + 1);
-#pragma unroll
-      for (int ks = 0; ks < BKS / 16; ++ks) {
-        bf16x8 fa[LIMBS][MI], fb[LIMBS][NJ];
-#pragma unroll
-        for (int l = 0; l < LIMBS; ++l) {
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-            fa[l][i] = *reinterpret_cast<const bf16x8*>(&sW[l][((wco * MI + i) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            fb[l][j] = *reinterpret_cast<const bf16x8*>(&sX[l][((wpix * NJ + j) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
-        }
-        // smallest terms first
-#pragma unroll
-        for (int sum = LIMBS - 1; sum >= 0; --sum)
-#pragma unroll
-          for (int la = 0; la <= sum; ++la) {
-            const int lb = sum - la;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-              for (int j = 0; j < NJ; ++j)
-                acc[i][j] = L::mfma(fa[la][i], fb[lb][j], acc[i][j]);
-          }
-      }
-      if (F16 && slab + 1 < slab1) {       // the next slab's loads had this slab's MFMAs to land
-        __builtin_amdgcn_sched_barrier(0);
-        prep_slab();
-      }
-      __syncthreads();
+    }
+    for (int slab = slab0; slab < slab1; slab += 2) {
+      step(slab, ra, rb);
+      if (slab + 1 < slab1) step(slab + 1, rb, ra);
     }
   }
 
@@ -856,26 +869,33 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   // prep_patch: the chunk's registers in their final fp32 form (activation mask, style); with binary16 limbs also
   // this wave's largest magnitude, published for the block exponent.  store_patch: scale by 2^-E, split, write.
   BlockExp bexp;
-  auto prep_patch = [&](int chunk) {
-    if (MASK) {
+  // (in parts: the pipelined tile finishes channels [j0, j1) per tap while the matrix pipe works, `last` adds the
+  // left-over element and publishes)
+  float pmax = 0.f;
+  auto prep_patch_part = [&](int chunk, int j0, int j1, bool last) {
+    if (j0 == 0) pmax = 0.f;
 #pragma unroll
-      for (int j = 0; j < BKS; ++j) xa[j] *= xm[MASK ? j : 0] > 0.f ? mpos : mneg;
-      xl *= xml > 0.f ? mpos : mneg;
-    }
-    if (IN_SCALE) {
-      if (pin) {
-#pragma unroll
-        for (int j = 0; j < BKS; ++j) xa[j] *= sg[chunk * BKS + j];
+    for (int j = 0; j < BKS; ++j)
+      if (j >= j0 && j < j1) {
+        if (MASK) xa[j] *= xm[MASK ? j : 0] > 0.f ? mpos : mneg;
       }
-      if (lin) xl *= sg[chunk * BKS + lci];
+    if (IN_SCALE && pin) {
+#pragma unroll
+      for (int j = 0; j < BKS; ++j)
+        if (j >= j0 && j < j1) xa[j] *= sg[chunk * BKS + j];
     }
     if (F16) {
-      float m = fabsf(xl);
 #pragma unroll
-      for (int j = 0; j < BKS; ++j) m = fmaxf(m, fabsf(xa[j]));
-      publish_wave_amax(m, sAmax, wid, lane);
+      for (int j = 0; j < BKS; ++j)
+        if (j >= j0 && j < j1) pmax = fmaxf(pmax, fabsf(xa[j]));
+    }
+    if (last) {
+      if (MASK) xl *= xml > 0.f ? mpos : mneg;
+      if (IN_SCALE && lin) xl *= sg[chunk * BKS + lci];
+      if (F16) publish_wave_amax(fmaxf(pmax, fabsf(xl)), sAmax, wid, lane);
     }
   };
+  auto prep_patch = [&](int chunk) { prep_patch_part(chunk, 0, BKS, true); };
   auto store_patch = [&]() {
     if (F16 && bexp.e != 0) {                      // uniform branch: most tiles never leave E = 0
       const float ps = exp2i(-bexp.e);
@@ -959,9 +979,10 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
     pbase[j] = (r * PW + c) * ROWB;
   }
 
+  float amax_next = 0.f;                // pipelined tile: the next chunk's magnitude, fetched one barrier early
   auto begin_chunk = [&](int chunk) {
     if (F16) {
-      const float f = block_exp_update(bexp, read_block_amax<NT / 64>(sAmax));
+      const float f = block_exp_update(bexp, PIPE ? amax_next : read_block_amax<NT / 64>(sAmax));
       if (f != 1.f) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -981,7 +1002,10 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
     load_w(chunk0, 0);
     if (F16) prep_patch(chunk0);       // published by the barrier below (PIPE) / the chunk loop's first barrier
     if constexpr (PIPE) {
-      if (F16) __syncthreads();
+      if (F16) {
+        __syncthreads();
+        amax_next = read_block_amax<NT / 64>(sAmax);
+      }
       // Software-pipelined tap loop (BKS = 32: two k-steps per tap).  Tap t reads weight buffer t & 1 while slab t + 1
       // is written to the other one, so ONE barrier per tap both publishes slab t + 1 and retires buffer t & 1; the
       // fragments of a tap's first k-step are fetched right after the previous tap's barrier and those of its second
@@ -1043,12 +1067,18 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
           // (the scheduler otherwise sinks each fetch down to its first use to shorten the live ranges, which puts
           // the LDS round trip back in front of the MFMAs)
           __builtin_amdgcn_sched_barrier(0);
-          // binary16 limbs: the next chunk's patch is complete in registers (issued over taps 0 .. 5) - finish it and
-          // publish its magnitude behind this tap's barrier; the VALU work shares the region with the 12 MFMAs
-          if (F16 && more && t == 8) prep_patch(chunk + 1);
+          // binary16 limbs: the next chunk's patch arrives in registers over taps 0 .. 5 - its channels are finished
+          // (mask, style, running maximum) a third per tap over taps 6 .. 8, next to the MFMAs, and the block's magnitude
+          // is published behind tap 8's barrier
+          // (the masked variant also holds the chunk's 32 mask references: it finishes each slice two taps after it was
+          // issued, which frees those registers early instead of keeping all 64 prefetch registers alive to tap 8)
+          if (F16 && more && !MASK && t >= 6) prep_patch_part(chunk + 1, 12 * (t - 6), t == 8 ? BKS : 12 * (t - 5), t == 8);
+          if (F16 && more && MASK && t >= 2)
+            prep_patch_part(chunk + 1, 6 * (t - 2) < BKS ? 6 * (t - 2) : BKS, 6 * (t - 1) < BKS ? 6 * (t - 1) : BKS, t == 8);
           mma(fa0, fb0);
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();
+          if (F16 && more && t == 8) amax_next = read_block_amax<NT / 64>(sAmax);   // (lands under the next 12 MFMAs)
           if (t < 8) {
             const int t1 = t + 1, ky1 = t1 / 3, kx1 = t1 - ky1 * 3;
             read_frag(fa0, fb0, buf ^ 1, (ky1 * PW + kx1) * ROWB, 0);
@@ -1501,6 +1531,7 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
         __syncthreads();
       }
       // binary16 limbs: the next chunk's registers landed during the nine taps; published by the loop's top barrier
+      // (inside the last interval's MFMA region the extra live registers spill: 80 bytes per lane)
       if (F16 && more) prep_patch(chunk + 1);
     }
   }
@@ -2630,6 +2661,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ 
   }
 }
 
+// Which kernel instantiation the last convolution entry point of this thread launched (gg_last_conv_kernel): what
+// bench.py's per-kernel timing keys on, so that its roofline entries name the kernel that actually ran.
+thread_local char g_last_kernel[96] = "";
+#define NOTE_KERNEL(...) snprintf(g_last_kernel, sizeof(g_last_kernel), __VA_ARGS__)
+
 // Scratch for `splits` partial copies of the output of `a`; sets a.part / a.part_stride.  zero: clear it first
 // (launches that do not cover every output element: parity-class plans of the generic transposed path).
 int splitk_prepare(ConvArgs& a, int splits, bool zero, hipStream_t st) {
@@ -2687,6 +2723,7 @@ int launch_conv(const ConvArgs& a, int tile, hipStream_t st) {
   if ((long long)a.tiles_pix * a.tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
+  NOTE_KERNEL("conv_igemm<k%d,mode%d,tile%d,fp32>", KS, MODE, tile);
   if (tile == 1) {
     if (sc) conv_igemm_kernel<KS, MODE, 1, 4, 1, 2, true><<<grid, 256, 0, st>>>(a);
     else conv_igemm_kernel<KS, MODE, 1, 4, 1, 2, false><<<grid, 256, 0, st>>>(a);
@@ -2730,6 +2767,7 @@ int launch_conv_split(const ConvArgs& a, int limbs, hipStream_t st) {
   if ((long long)a.tiles_pix * a.tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
+  NOTE_KERNEL("conv_split<k%d,mode%d,s%d,limbs%d,%dpx,%s>", KS, MODE, a.bs, limbs, a.tile_pixels, a.f16 ? "f16" : "bf16");
   if (a.f16) {          // two binary16 limbs (forward convolutions of the fp16x3 mode)
     if (a.tile_pixels == 256) {
       if (sc) conv_split_kernel<KS, MODE, 2, true, 256, true><<<grid, 512, 0, st>>>(a);
@@ -2824,6 +2862,8 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
   }
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
+  NOTE_KERNEL("conv3x3_patch<limbs%d,%dpx,%dco,%s,%s>", limbs, tpix, narrow ? 64 : 128, a.mask_ref ? "masked" : "plain",
+              a.f16 ? "f16" : "bf16");
   if (a.mask_ref && a.f16) {     // masked data gradient on binary16 limbs (block exponents: any gradient magnitude)
     if (narrow && tpix == 256) {
       if (sc) conv3x3_patch_kernel<2, true, 256, 1, true, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
@@ -2931,6 +2971,7 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   }
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
+  NOTE_KERNEL("convT3x3s2_patch<limbs%d,%dq,%s>", limbs, tq, a.f16 ? "f16" : "bf16");
   if (a.f16) {
     if (tq == 128) {
       if (sc) convT3x3s2_patch_kernel<2, true, 128, true><<<grid, 512, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
@@ -3020,6 +3061,7 @@ bool fewout_serves(const ConvArgs& a, int stride, int pad, int mode) {
 }
 
 int launch_conv1x1_fewout(const ConvArgs& a, hipStream_t st) {
+  NOTE_KERNEL("conv1x1_fewout");
   const long long hw = (long long)a.h * a.w;
   dim3 grid((unsigned)((hw + 255) / 256), (unsigned)a.batch);
   switch (a.cout_g) {
@@ -3112,6 +3154,7 @@ bool fewout3_serves(const ConvArgs& a, int stride, int pad, int mode) {
 }
 
 int launch_conv3x3_fewout(const ConvArgs& a, hipStream_t st) {
+  NOTE_KERNEL("conv3x3_fewout");
   const long long hw = (long long)a.h * a.w;
   dim3 grid((unsigned)((hw + 255) / 256), (unsigned)a.batch);
   const size_t smem = sizeof(float) * (size_t)a.cin_g * 9 * a.cout_g;
@@ -3218,6 +3261,8 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
 }
 
 }  // namespace
+
+extern "C" const char* gg_last_conv_kernel(void) { return g_last_kernel; }
 
 extern "C" int gg_conv_pack_weight_f32(float* wmat, const float* w, int groups, int cout_g, int cin_g, int kh,
                                        int kw, int transpose_io, int flip, float scale, void* stream) {

@@ -13,18 +13,51 @@ from .. import _lib
 
 
 class LaunchProfiler:
-    """Optional per-launch timing of the dominant kernel instantiation (3x3 correlation, 128x128 tile):
-    HIP events recorded on the stream the kernel is launched on (torch's current stream).  Used by
-    bench.py for the roofline entry; None (the default) costs nothing."""
+    """Optional per-launch timing with HIP events recorded on the stream the kernel is launched on (torch's current
+    stream).  Used by bench.py for the roofline entry; None (the default) costs nothing.
 
-    def __init__(self):
-        self.records = []          # (start_event, end_event, flops)
+    every=False: only the launches of the dominant kernel instantiation of config C2 (the predicate in conv_forward
+    mirrors the library's dispatch and was checked against rocprofv3 traces).  every=True: every convolution and FIR
+    launch, keyed by the kernel the library reports it launched (gg_last_conv_kernel) - how bench.py finds out which
+    kernel dominates another workload (C4: the transposed tile / the 513^2 blur; C5: the STN / VGG tiles).  only=name
+    keeps the records of that kernel alone (the timed region of those workloads)."""
+
+    def __init__(self, every=False, only=None):
+        self.records = []          # (start_event, end_event, work, kernel name, unit of work)
+        self.every = bool(every) or only is not None
+        self.only = only
+
+    def begin(self):
+        start = torch.cuda.Event(enable_timing=True)
+        start.record()
+        return start
+
+    def end(self, start, work, name='dominant', unit='flop'):
+        if self.only is not None and name != self.only:
+            return
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        self.records.append((start, end, float(work), name, unit))
 
     def summary(self):
         torch.cuda.synchronize()
-        ms = [s.elapsed_time(e) for s, e, _ in self.records]
-        flops = [f for _, _, f in self.records]
-        return dict(launches=len(ms), total_ms=sum(ms), total_flops=float(sum(flops)))
+        ms = [r[0].elapsed_time(r[1]) for r in self.records]
+        return dict(launches=len(ms), total_ms=sum(ms), total_flops=float(sum(r[2] for r in self.records)))
+
+    def by_kernel(self):
+        """{kernel name: dict(launches, ms, work, unit)} over the recorded launches."""
+        torch.cuda.synchronize()
+        out = {}
+        for start, end, work, name, unit in self.records:
+            ent = out.setdefault(name, dict(launches=0, ms=0.0, work=0.0, unit=unit))
+            ent['launches'] += 1
+            ent['ms'] += start.elapsed_time(end)
+            ent['work'] += work
+        return out
+
+
+def last_conv_kernel():
+    return _lib.load().gg_last_conv_kernel().decode()
 
 
 PROFILER = None
@@ -262,8 +295,8 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
         code = limb_code(grad)
         limbs = code & 15
         use_split = limbs > 0 and isinstance(wmat, PackedWeight) and wmat.split_ok()
-        prof = None
-        if PROFILER is not None and k == 3 and mode == 0 and cout_g > 64:
+        prof = PROFILER if (PROFILER is not None and PROFILER.every) else None
+        if prof is None and PROFILER is not None and k == 3 and mode == 0 and cout_g > 64:
             if use_split:
                 # exactly the launches that run conv3x3_patch_kernel<2, true, 256> (csrc/conv_mfma.hip: patch_geometry
                 # + the 256-pixel-tile rule): the generator's style-scaled 3x3 stride-1 layers that fill the chip
@@ -279,8 +312,7 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             elif limbs == 0 and cout_g > 64 and batch * oh * ow >= 4096:
                 prof = PROFILER          # fp32 mode: conv_igemm_kernel<3,0,2,2,2,2,*> launches without split-K
         if prof is not None:
-            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            start.record()
+            start = prof.begin()
         if act is not None:
             if (k, stride, pad, mode, groups) != (3, 1, 1, 0, 1) or bias is not None or (oh * ow) % 4:
                 raise NotImplementedError('conv_forward: the fused activation needs a 3x3 stride-1 pad-1 single-group conv')
@@ -298,8 +330,10 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             _lib.call('gg_conv2d_f32', y, x, wm, in_scale, out_scale, bias, batch, groups, cin_g, cout_g, h, w,
                       k, stride, pad, mode, oh if mode == 1 else 0, ow if mode == 1 else 0)
         if prof is not None:
-            end.record()
-            prof.records.append((start, end, 2.0 * batch * groups * cout_g * cin_g * k * k * oh * ow))
+            # algorithmic FLOPs: a transposed stride-2 convolution does its multiply-adds at the INPUT positions
+            pos = oh * ow if mode == 0 else h * w
+            prof.end(start, 2.0 * batch * groups * cout_g * cin_g * k * k * pos,
+                     last_conv_kernel() if prof.every else 'dominant')
     return y
 
 

@@ -49,6 +49,9 @@ int gg_scratch_release(void);
 typedef void* (*gg_alloc_fn)(long long bytes);
 typedef void (*gg_free_fn)(void* ptr);
 int gg_set_allocator(gg_alloc_fn alloc, gg_free_fn free_fn);
+/* Name of the kernel instantiation the calling thread's last convolution entry point launched (tile shape, limb format;
+ * "" before the first call): measurement aid - bench.py keys its per-kernel HIP-event timing on it. */
+const char* gg_last_conv_kernel(void);
 const char* gg_last_error(void);
 /* Name of the gfx target the device code was built for ("gfx950"). */
 const char* gg_build_arch(void);

@@ -4,7 +4,8 @@ sigma in {0.3, 1.3}, C = 3 value channels, the HIP kernel next to the reference'
 points/s, and the achieved rate against the ALGORITHMIC traffic 4*P*(3+C) bytes of point data read +
 4*(C+1)*H*W bytes of canvas read-modify-write (each atomic touches a 4-byte word that lives in L2: this is an
 L2-atomic-bound operator, so the HBM figure is a lower bound on what the atomic units do: atomics issued =
-P * footprint * (C+1)).
+P * footprint * (C+1)).  Round 4: the HIP operator bins the points per 32x32 tile and gathers (no float atomics);
+`atomics_issued_upper_bound` now describes the reference formulation only, and a bitwise-repeat check is added.
 
     python scripts/splat_bench.py [out.json]
 """
@@ -64,6 +65,8 @@ def main():
                 row.update(reference_kernel_ms=round(ref_ms, 4), speedup_vs_reference_kernel=round(ref_ms / ms, 2),
                            max_abs_diff_vs_reference_kernel=float((out - ref).abs().max()),
                            ref_scale=float(ref.abs().max()))
+            row['bitwise_repeatable'] = bool(torch.equal(splat2d(canvas, coords, values, sig, False),
+                                                         splat2d(canvas, coords, values, sig, False)))
             rows.append(row)
             print(json.dumps(row), flush=True)
     if len(sys.argv) > 1:

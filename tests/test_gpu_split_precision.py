@@ -313,13 +313,17 @@ def test_fp16_block_exponent_grows_inside_a_tile(spec, cuda, precision):
         assert bool(torch.isfinite(out).all()), name
         err = float((out - ref).abs().max() / ref.abs().max())
         assert err <= 1e-5, (name, err)
-    # the small region of the quadrant case is not drowned by its neighbour's exponent: judged on its own scale
+    # The exponent belongs to a TILE: where the quiet region's tiles do not touch the loud quadrant (the two cases whose
+    # images span many tiles) it is judged on its own scale.  Inside one tile accuracy is relative to the tile's largest
+    # operand (2^-31 of it per element) - an image that fits a single tile, like the 16^2 cases here, cannot resolve a
+    # 1e6 : 1 range between neighbouring regions to 1e-5 of the quiet one, and fp32-class parity (1e-4 of the tensor's
+    # scale) does not ask for it.
     sl = (slice(None), slice(None), slice(out.shape[-2] * 3 // 4, None), slice(out.shape[-1] * 3 // 4, None))
     precision('fp32')
     ref = run(x * quadrant)
     precision('fp16x3')
     out = run(x * quadrant)
-    if ref[sl].numel():
+    if spec in (RANGE_CASES[0], RANGE_CASES[4]) and ref[sl].numel():
         err = float((out[sl] - ref[sl]).abs().max() / ref[sl].abs().max())
         assert err <= 1e-5, ('quiet corner', err)
 
