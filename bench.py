@@ -74,11 +74,11 @@ def kernel_source_hash():
 
 def pmc_traffic(precision, workload, batch):
     """HBM bytes per launch of the dominant kernel, measured offline with rocprofv3 --pmc on this same command
-    (scripts/measure_r03.sh) and committed under profiles/.  None for configurations that were not profiled AND
+    (scripts/measure_r04.sh) and committed under profiles/.  None for configurations that were not profiled AND
     whenever the recorded kernel-source hash differs from the tree's (a profile of another version of the kernel says
     nothing about this one)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             with open(os.path.join(here, 'profiles', name)) as f:
                 rec = json.load(f)

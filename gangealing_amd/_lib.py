@@ -103,8 +103,9 @@ def load():
     lib.gg_last_error.restype = ctypes.c_char_p
     lib.gg_build_arch.restype = ctypes.c_char_p
     lib.gg_scratch_release.restype = ctypes.c_int
-    lib.gg_last_conv_kernel.restype = ctypes.c_char_p
-    lib.gg_last_conv_kernel.argtypes = []
+    if hasattr(lib, 'gg_last_conv_kernel'):          # (absent from A/B builds of older kernel sources)
+        lib.gg_last_conv_kernel.restype = ctypes.c_char_p
+        lib.gg_last_conv_kernel.argtypes = []
     lib.gg_scratch_release.argtypes = []
     if lib.gg_abi_version() != ABI_VERSION:
         raise HipLibraryError(f'ABI mismatch: library {lib.gg_abi_version()} != python {ABI_VERSION}; rebuild')

@@ -528,20 +528,12 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
   int slab1 = slab0 + a.slabs_per_split;
   if (slab1 > a.nslabs) slab1 = a.nslabs;
 
-  // Two register sets, two slabs in flight: while slab s is multiplied, slab s + 1 waits complete in the other set (its
-  // loads were issued one slab earlier) and slab s + 2 is being fetched into the set that slab s just vacated.  Round
-  // 3 had one set: a slab's loads had only the previous slab's MFMAs to land.  With binary16 limbs the waiting slab
-  // is also finished (zero padding, style) and measured (block exponent, see BlockExp) next to the current slab's MFMAs.
-  struct SlabRegs {
-    float xa[EPT];
-    float4 rs4[EPT / 4];
-    U4 wv[LIMBS][EPT / 8];
-    bool x_ok;
-  };
-  SlabRegs ra, rb;
-  ra.x_ok = rb.x_ok = false;
+  float xa[EPT];
+  float4 rs4[EPT / 4];
+  U4 wv[LIMBS][EPT / 8];
+  bool x_ok = false;
 
-  auto load_slab = [&](int slab, SlabRegs& R) {
+  auto load_slab = [&](int slab) {
     const int t = slab / cslabs;
     const int ci0 = (slab - t * cslabs) * BKS;
     int ky, kx, dy, dx;
@@ -553,55 +545,57 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
       ky = a.py + 2 * jy; kx = a.px + 2 * jx; dy = -jy; dx = -jx;
     }
     const int iy = base_y + dy, ix = base_x + dx;
-    R.x_ok = m_ok & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
+    x_ok = m_ok & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
     const int cbase = ci0 + khalf * EPT;
     if (xbuf) {
-      const unsigned vo = R.x_ok ? (unsigned)(chan0 * hw + iy * a.w + ix) * 4u : kOobOffset;
+      const unsigned vo = x_ok ? (unsigned)(chan0 * hw + iy * a.w + ix) * 4u : kOobOffset;
       const int so = __builtin_amdgcn_readfirstlane((ci0 + khalf_u * EPT) * hw * 4);
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) R.xa[j] = buffer_load_f32(xrs, vo, so + j * hw * 4);
+      for (int j = 0; j < EPT; ++j) xa[j] = buffer_load_f32(xrs, vo, so + j * hw * 4);
     } else {
-      const float* src = xg + (R.x_ok ? (size_t)cbase * hw + iy * a.w + ix : 0);
-      const int step = R.x_ok ? hw : 0;
+      const float* src = xg + (x_ok ? (size_t)cbase * hw + iy * a.w + ix : 0);
+      const int step = x_ok ? hw : 0;
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) R.xa[j] = src[(size_t)j * step];
+      for (int j = 0; j < EPT; ++j) xa[j] = src[(size_t)j * step];
     }
     if (IN_SCALE) {
       const float4* s4 = reinterpret_cast<const float4*>(sg + cbase);
 #pragma unroll
-      for (int j = 0; j < EPT / 4; ++j) R.rs4[j] = s4[j];
+      for (int j = 0; j < EPT / 4; ++j) rs4[j] = s4[j];
     }
     const unsigned short* wsrc = wrow_ptr + (size_t)(ky * KS + kx) * a.cin_g + ci0;
 #pragma unroll
     for (int l = 0; l < LIMBS && w_thr; ++l) {
       const U4* w4 = reinterpret_cast<const U4*>(wsrc + (size_t)l * a.wsplit_stride);
 #pragma unroll
-      for (int q = 0; q < EPT / 8; ++q) R.wv[l][q] = w4[q];
+      for (int q = 0; q < EPT / 8; ++q) wv[l][q] = w4[q];
     }
   };
   // the gathered slab in its final fp32 form (zero padding, style); binary16 limbs: + this wave's largest magnitude
   // for the block exponent (see BlockExp)
   __shared__ float sAmax[16];
   BlockExp bexp;
-  auto prep_slab = [&](SlabRegs& R) {
+  auto prep_slab = [&]() {
+    if (!xbuf) {          // (the buffer path's out-of-range offset already returned 0 for masked lanes)
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) R.xa[j] = R.x_ok ? R.xa[j] : 0.f;
+      for (int j = 0; j < EPT; ++j) xa[j] = x_ok ? xa[j] : 0.f;
+    }
     if (IN_SCALE) {
-      const float* rs = reinterpret_cast<const float*>(R.rs4);
+      const float* rs = reinterpret_cast<const float*>(rs4);
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) R.xa[j] *= rs[j];
+      for (int j = 0; j < EPT; ++j) xa[j] *= rs[j];
     }
     if (F16) {
       float m = 0.f;
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) m = fmaxf(m, fabsf(R.xa[j]));
+      for (int j = 0; j < EPT; j += 2) m = fmaxf(fmaxf(m, fabsf(xa[j])), fabsf(xa[j + 1]));      // v_max3_f32
       publish_wave_amax(m, sAmax, wid, lane);
     }
   };
-  auto store_slab = [&](SlabRegs& R) {
+  auto store_slab = [&]() {
     float v[EPT];
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) v[j] = R.xa[j];
+    for (int j = 0; j < EPT; ++j) v[j] = xa[j];
     if (F16 && bexp.e != 0) {                      // uniform branch: most tiles never leave E = 0
       const float ps = exp2i(-bexp.e);
 #pragma unroll
@@ -624,7 +618,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
 #pragma unroll
       for (int q = 0; q < EPT / 8; ++q) {
         dst[q] = U4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
-        if (w_thr) wd[q] = w_ok ? R.wv[l][q] : z;
+        if (w_thr) wd[q] = w_ok ? wv[l][q] : z;
       }
     }
   };
@@ -637,65 +631,60 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int kh = lane >> 5, l31 = lane & 31;
-  // one slab: `cur` holds it (loaded two slabs ago, and - binary16 limbs - already finished and measured), `nxt` the
-  // following one
-  auto step = [&](int slab, SlabRegs& cur, SlabRegs& nxt) {
-    if (F16) {            // the slab's block exponent (published behind the previous barrier)
-      const float f = block_exp_update(bexp, read_block_amax<NT / 64>(sAmax));
-      if (f != 1.f) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
-      }
-    } else {
-      prep_slab(cur);
+  if (slab0 < slab1) {
+    const int kh = lane >> 5, l31 = lane & 31;
+    load_slab(slab0);
+    if (F16) {
+      prep_slab();
+      __syncthreads();
     }
-    store_slab(cur);
-    __syncthreads();
-    if (slab + 2 < slab1) load_slab(slab + 2, cur);
-    if (F16 && slab + 1 < slab1) prep_slab(nxt);          // next to the MFMAs below; published by the closing barrier
-#pragma unroll
-    for (int ks = 0; ks < BKS / 16; ++ks) {
-      bf16x8 fa[LIMBS][MI], fb[LIMBS][NJ];
-#pragma unroll
-      for (int l = 0; l < LIMBS; ++l) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-          fa[l][i] = *reinterpret_cast<const bf16x8*>(&sW[l][((wco * MI + i) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          fb[l][j] = *reinterpret_cast<const bf16x8*>(&sX[l][((wpix * NJ + j) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
-      }
-      // smallest terms first
-#pragma unroll
-      for (int sum = LIMBS - 1; sum >= 0; --sum)
-#pragma unroll
-        for (int la = 0; la <= sum; ++la) {
-          const int lb = sum - la;
+    for (int slab = slab0; slab < slab1; ++slab) {
+      if (F16) {            // the slab's block exponent (published behind the previous barrier)
+        const float f = block_exp_update(bexp, read_block_amax<NT / 64>(sAmax));
+        if (f != 1.f) {
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-              acc[i][j] = L::mfma(fa[la][i], fb[lb][j], acc[i][j]);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
         }
-    }
-    __syncthreads();
-  };
-
-  if (slab0 < slab1) {
-    load_slab(slab0, ra);
-    if (slab0 + 1 < slab1) load_slab(slab0 + 1, rb);
-    if (F16) {
-      prep_slab(ra);
+      } else {
+        prep_slab();
+      }
+      store_slab();
       __syncthreads();
-    }
-    for (int slab = slab0; slab < slab1; slab += 2) {
-      step(slab, ra, rb);
-      if (slab + 1 < slab1) step(slab + 1, rb, ra);
+      if (slab + 1 < slab1) load_slab(slab + 1);
+#pragma unroll
+      for (int ks = 0; ks < BKS / 16; ++ks) {
+        bf16x8 fa[LIMBS][MI], fb[LIMBS][NJ];
+#pragma unroll
+        for (int l = 0; l < LIMBS; ++l) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+            fa[l][i] = *reinterpret_cast<const bf16x8*>(&sW[l][((wco * MI + i) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            fb[l][j] = *reinterpret_cast<const bf16x8*>(&sX[l][((wpix * NJ + j) * 32 + l31) * ROWB + ks * 32 + kh * 16]);
+        }
+        // smallest terms first
+#pragma unroll
+        for (int sum = LIMBS - 1; sum >= 0; --sum)
+#pragma unroll
+          for (int la = 0; la <= sum; ++la) {
+            const int lb = sum - la;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int j = 0; j < NJ; ++j)
+                acc[i][j] = L::mfma(fa[la][i], fb[lb][j], acc[i][j]);
+          }
+      }
+      if (F16 && slab + 1 < slab1) {       // the next slab's loads had this slab's MFMAs to land
+        __builtin_amdgcn_sched_barrier(0);
+        prep_slab();
+      }
+      __syncthreads();
     }
   }
 

@@ -85,25 +85,75 @@ __global__ __launch_bounds__(256) void splat_large_kernel(
   }
 }
 
-// ---- binning: count / fill (integer atomics: the COUNTS are order independent, the slots are sorted afterwards) ----
-// FILL = false: counts[tile] += 1 for every tile a point's box overlaps; FILL = true: the point's index goes into
-// lists[offsets[tile] + slot], slot handed out by cursor[tile]
+// ---- binning: count / fill ----------------------------------------------------------------------------------------
+// Integer atomics only (the COUNTS are order independent; the fill pass's slots are sorted afterwards).  One global atomic
+// per (point, tile) was the first version - and the bottleneck: 1e6 points onto the 256 tile counters of a 512^2 image are
+// ~4000 atomics per ADDRESS, which the L2 serialises (2.6 ms; the whole atomic-scatter kernel of round 3 took 0.7).  So a
+// block aggregates kPtsPerBlock points of one image in an LDS histogram over the image's tiles and touches each global
+// counter once.  FILL: the block reserves its range of every list with that one atomic and hands out the slots inside
+// the range from LDS.  Images with more than kMaxLdsTiles tiles (beyond 2048^2) use direct atomics - there the
+// contention per address is low anyway.
+constexpr int kPtsPerBlock = 4096;
+constexpr int kMaxLdsTiles = 4096;
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void splat_bin_kernel(const float* __restrict__ coords, const float* __restrict__ sigma,
                                                         int* __restrict__ counts, const int* __restrict__ offsets,
                                                         int* __restrict__ lists, int num_points, int height, int width,
                                                         int top_count, int tiles_x, int tiles_y) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < top_count; index += stride) {
+  __shared__ int s_hist[kMaxLdsTiles];
+  __shared__ int s_base[FILL ? kMaxLdsTiles : 1];
+  const int n = blockIdx.y;
+  const int tiles = tiles_x * tiles_y;
+  const bool lds = tiles <= kMaxLdsTiles;
+  const int p0 = blockIdx.x * kPtsPerBlock;
+  int p1 = p0 + kPtsPerBlock;
+  if (p1 > num_points) p1 = num_points;
+  if ((long long)n * num_points + p1 > top_count) p1 = (int)(top_count - (long long)n * num_points);      // ragged last image
+  int* gcount = counts + (size_t)n * tiles;
+  if (lds) {
+    for (int t = threadIdx.x; t < tiles; t += 256) s_hist[t] = 0;
+    __syncthreads();
+  }
+  // pass 1: histogram of this block's points (direct global atomics when the image has too many tiles for LDS)
+  for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+    const long long index = (long long)n * num_points + p;
     Footprint f;
     if (!footprint(coords, sigma, index, num_points, height, width, f) || !binned(f)) continue;
-    const int n = (int)(index / num_points);
     const int tx0 = f.l / TS, tx1 = f.r / TS, ty0 = f.t / TS, ty1 = f.b / TS;
     for (int ty = ty0; ty <= ty1; ++ty)
       for (int tx = tx0; tx <= tx1; ++tx) {
-        const int tile = (n * tiles_y + ty) * tiles_x + tx;
-        const int slot = atomicAdd(counts + tile, 1);
-        if (FILL) lists[offsets[tile] + slot] = (int)index;
+        const int tile = ty * tiles_x + tx;
+        if (lds) {
+          atomicAdd(&s_hist[tile], 1);
+        } else {
+          const int slot = atomicAdd(gcount + tile, 1);
+          if (FILL) lists[offsets[(size_t)n * tiles + tile] + slot] = (int)index;
+        }
+      }
+  }
+  if (!lds) return;
+  __syncthreads();
+  // one global atomic per tile this block touched; FILL: it returns the block's first slot in that tile's list
+  for (int t = threadIdx.x; t < tiles; t += 256) {
+    const int c = s_hist[t];
+    if (c > 0) {
+      const int first = atomicAdd(gcount + t, c);
+      if (FILL) s_base[t] = offsets[(size_t)n * tiles + t] + first;
+    }
+    if (FILL) s_hist[t] = 0;               // re-used as the block-local cursor
+  }
+  if (!FILL) return;
+  __syncthreads();
+  for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+    const long long index = (long long)n * num_points + p;
+    Footprint f;
+    if (!footprint(coords, sigma, index, num_points, height, width, f) || !binned(f)) continue;
+    const int tx0 = f.l / TS, tx1 = f.r / TS, ty0 = f.t / TS, ty1 = f.b / TS;
+    for (int ty = ty0; ty <= ty1; ++ty)
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        const int tile = ty * tiles_x + tx;
+        lists[s_base[tile] + atomicAdd(&s_hist[tile], 1)] = (int)index;
       }
   }
 }
@@ -181,6 +231,10 @@ __global__ __launch_bounds__(256) void splat_sort_kernel(int* __restrict__ lists
 
 // ---- gather: one block per tile, thread = 4 consecutive pixels of one row --------------------------------------
 // FUSED: out = (out + splat) / (max?(alpha_in + alpha, 1) + 1e-8) (splat_gpu.c:33-40); else alpha += , out += .
+// Every wave walks the tile's whole (sorted) list on its own, 64 points at a time: lane l computes the box of point l,
+// then the wave visits the 64 points through v_readlane - the box of a point is SCALAR data, so "none of my 8 rows"
+// is a scalar branch that costs six instructions and no LDS round trip (the first version staged the boxes in LDS and
+// paid its latency once per point: a dependent ds_read -> readfirstlane -> branch chain).
 template <bool FUSED>
 __global__ __launch_bounds__(256) void splat_tile_kernel(
     const float* __restrict__ coords, const float* __restrict__ values, const float* __restrict__ sigma,
@@ -188,11 +242,9 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(
     float* __restrict__ output, int num_points, int channels, int height, int width, int tiles_x, int tiles_y,
     int soft) {
   constexpr int CG = 4;                  // channels per pass over the list
-  __shared__ float sx[256], sy[256], snorm[256];
-  __shared__ int st[256], sb[256], sl[256], sr[256], sidx[256];
   const int tile = blockIdx.x;
   const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-  const int tid = threadIdx.x, wid = tid >> 6;
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   const int py = ty * TS + (tid >> 3), px0 = tx * TS + (tid & 7) * 4;
   const int wrow0 = ty * TS + wid * 8;                       // this wave's rows: wrow0 .. wrow0 + 7
   const int beg = offsets[tile], len = offsets[tile + 1] - beg;
@@ -209,25 +261,29 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(
     for (int c = 0; c < CG; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc_v[c][e] = 0.f;
-    for (int base = 0; base < len; base += 256) {
-      __syncthreads();
-      const int m = len - base < 256 ? len - base : 256;
-      if (tid < m) {
-        const int idx = lists[beg + base + tid];
-        Footprint f;
-        footprint(coords, sigma, idx, num_points, height, width, f);       // (a listed point always has a box)
-        sx[tid] = f.xc; sy[tid] = f.yc; snorm[tid] = f.normalizer;
-        st[tid] = f.t; sb[tid] = f.b; sl[tid] = f.l; sr[tid] = f.r; sidx[tid] = idx;
+    for (int base = 0; base < len; base += 64) {
+      const int m = len - base < 64 ? len - base : 64;
+      // lane -> one point of this batch of 64
+      Footprint f;
+      f.t = 1; f.b = 0; f.l = 1; f.r = 0; f.xc = f.yc = f.normalizer = 0.f;        // an empty box for idle lanes
+      int idx = 0;
+      if (lane < m) {
+        idx = lists[beg + base + lane];
+        footprint(coords, sigma, idx, num_points, height, width, f);               // (a listed point always has a box)
       }
-      __syncthreads();
-      for (int i = 0; i < m; ++i) {
-        const int t = __builtin_amdgcn_readfirstlane(st[i]), b = __builtin_amdgcn_readfirstlane(sb[i]);
-        if (b < wrow0 || t > wrow0 + 7) continue;             // none of this wave's rows: scalar branch
-        if (py < t || py > b) continue;
-        const int l = sl[i], r = sr[i];
-        if (px0 + 3 < l || px0 > r) continue;
-        const float xc = sx[i], yc = sy[i], nz = snorm[i];
-        const float* val = values + (size_t)__builtin_amdgcn_readfirstlane(sidx[i]) * channels + c0;
+      // does any of the 64 boxes reach this wave's rows?  (most batches of most waves: no)
+      const bool mine = f.b >= wrow0 && f.t <= wrow0 + 7;
+      unsigned long long todo = __ballot(mine);
+      while (todo) {
+        const int i = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int t = __builtin_amdgcn_readlane(f.t, i), b = __builtin_amdgcn_readlane(f.b, i);
+        const int l = __builtin_amdgcn_readlane(f.l, i), r = __builtin_amdgcn_readlane(f.r, i);
+        if (py < t || py > b || px0 + 3 < l || px0 > r) continue;
+        const float xc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f.xc), i));
+        const float yc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f.yc), i));
+        const float nz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f.normalizer), i));
+        const float* val = values + (size_t)__builtin_amdgcn_readlane(idx, i) * channels + c0;
         float v[CG];
 #pragma unroll
         for (int c = 0; c < CG; ++c) v[c] = c < nc ? val[c] : 0.f;
@@ -283,7 +339,8 @@ int build_bins(const float* coords, const float* sigma, int num_points, int heig
   int* lst = offs + tiles + 2;               // [4 * top_count]
   hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)tiles, st);
   if (e != hipSuccess) return gg::fail((int)e, "splat2d: memset failed: %s", hipGetErrorString(e));
-  const unsigned grid = gg::stream_grid(top_count, 256);
+  const dim3 grid((unsigned)((num_points + kPtsPerBlock - 1) / kPtsPerBlock), (unsigned)n_images);
+  if (n_images > 65535) return gg::fail(-2, "splat2d: too many images");
   splat_bin_kernel<false><<<grid, 256, 0, st>>>(coords, sigma, counts, nullptr, nullptr, num_points, height, width,
                                                  top_count, tiles_x, tiles_y);
   splat_scan_kernel<<<1, 1024, 0, st>>>(counts, offs, (int)tiles);

@@ -57,7 +57,8 @@ class LaunchProfiler:
 
 
 def last_conv_kernel():
-    return _lib.load().gg_last_conv_kernel().decode()
+    lib = _lib.load()
+    return lib.gg_last_conv_kernel().decode() if hasattr(lib, 'gg_last_conv_kernel') else 'unknown'
 
 
 PROFILER = None
@@ -87,11 +88,32 @@ _F16_FORWARD = frozenset(['fp16x3'])
 _F16_GRAD = frozenset(['fp16x3']) if _os.environ.get('GANGEALING_F16_GRADS', '1') != '0' else frozenset()
 
 
-def limb_code(grad=False):
+# ... except on the generic (re-gathering) kernel: it is instruction-issue bound (~350 VALU / scalar instructions per 24
+# MFMAs), so the block-exponent bookkeeping per gathered slab costs it 9-12 % (profiles/r04_*_ab*: 0.738 -> 0.828 ms
+# on the 257^2 -> 128^2 data gradient) where the patch / transposed tiles hide it under their MFMAs.  Its gradient
+# launches (stride-2 correlations = data gradients of the generator's up-convolutions, 1x1, images narrower than 16)
+# therefore stay on bf16 limbs unless GANGEALING_F16_GRADS=all.
+_F16_GRAD_GENERIC = _os.environ.get('GANGEALING_F16_GRADS', '1') == 'all'
+
+
+def limb_code(grad=False, generic=False):
     """Format code of the split-precision entry points for the current mode: limb count, + 16 when the limbs are
-    binary16 (the fp16x3 mode; `grad` = the launch is a data-gradient convolution)."""
+    binary16 (the fp16x3 mode; `grad` = the launch is a data-gradient convolution, `generic` = a shape the library serves
+    with the generic re-gathering kernel)."""
     limbs = _LIMBS[PRECISION]
+    if grad and generic and not _F16_GRAD_GENERIC:
+        return limbs
     return limbs | 16 if PRECISION in (_F16_GRAD if grad else _F16_FORWARD) else limbs
+
+
+def _generic_shape(k, stride, pad, mode, w):
+    """True when csrc/conv_mfma.hip::conv_dispatch sends this split-precision launch to conv_split_kernel (neither the
+    3x3 / stride-1 patch tile nor the transposed 3x3 / stride-2 tile serves it).  A performance hint only: either limb
+    format is valid on every kernel."""
+    pow2 = (w & (w - 1)) == 0
+    if mode == 1:
+        return not (k == 3 and pad <= 1 and w >= 4 and pow2)
+    return not (k == 3 and stride == 1 and pad == 1 and w >= 16 and pow2)
 
 
 def set_precision(mode):
@@ -292,7 +314,7 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             oh, ow = out_hw
     y = torch.empty((batch, groups * cout_g, oh, ow), dtype=torch.float32, device=x.device)
     if y.numel():
-        code = limb_code(grad)
+        code = limb_code(grad, grad and _generic_shape(k, stride, pad, mode, w))
         limbs = code & 15
         use_split = limbs > 0 and isinstance(wmat, PackedWeight) and wmat.split_ok()
         prof = PROFILER if (PROFILER is not None and PROFILER.every) else None

@@ -1,0 +1,122 @@
+#!/usr/bin/env python
+"""Copy the summaries of one scripts/measure_r04.sh session (gpurun_out/r04/) into profiles/ under their round-4 names,
+stamp each with the commit / kernel-source hash the session ran at, and rebuild profiles/r04_pmc_traffic.json from the
+FETCH_SIZE / WRITE_SIZE passes and the calibration kernel (bench.py only trusts that file while the recorded
+kernel-source hash equals the tree's)."""
+import json
+import os
+import re
+import shutil
+import subprocess
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O = os.path.join(R, 'gpurun_out', 'r04')
+P = os.path.join(R, 'profiles')
+DOM = 'conv3x3_patch_kernel<2, true, 256, 2, fals'
+
+
+def rows(path):
+    out = {}
+    for line in open(os.path.join(O, path)):
+        m = re.match(r'(.*?)\s+(\w+)\s+n=\s*(\d+)\s+mean=\s*([\d.]+)', line)
+        if m:
+            out[(m.group(1).strip(), m.group(2))] = (int(m.group(3)), float(m.group(4)))
+    return out
+
+
+def find(table, needle, counter):
+    hits = [(k, v) for k, v in table.items() if needle in k[0] and k[1] == counter]
+    assert len(hits) == 1, (needle, counter, hits)
+    return hits[0][1]
+
+
+sha = open(os.path.join(O, 'kernel_source_sha16.txt')).read().strip()
+commit = open(os.path.join(O, 'commit.txt')).read().strip()
+if 'no-git' in commit:        # the GPU box receives a snapshot without .git: the session ran at the tree it was sent from
+    commit = subprocess.run(['git', 'rev-parse', 'HEAD'], cwd=R, capture_output=True, text=True).stdout.strip() + \
+        ' (HEAD of the authoring tree when the snapshot was sent)'
+STAMP = f'# measured by scripts/measure_r04.sh at commit {commit}; kernel-source sha16 {sha}\n'
+
+
+def stamped(src, dst, header=''):
+    with open(os.path.join(P, dst), 'w') as f:
+        f.write(STAMP + header + open(os.path.join(O, src)).read())
+
+
+for src, dst in (('parity_r04.json', 'parity_r04.json'), ('bench_fp16x3.json', 'bench_r04_fp16x3.json'), ('bench_bf16x3.json', 'bench_r04_bf16x3.json'),
+                 ('bench_fp32.json', 'bench_r04_fp32.json'), ('bench_bf16.json', 'bench_r04_bf16.json'),
+                 ('bench_fp16x3_batch5.json', 'bench_r04_fp16x3_batch5.json'),
+                 ('bench_fp16x3_batch5_hipgraph.json', 'bench_r04_fp16x3_batch5_hipgraph.json'),
+                 ('bench_fp16x3_batch32.json', 'bench_r04_fp16x3_batch32.json'),
+                 ('bench_c4_batch4.json', 'bench_r04_c4_batch4.json'), ('bench_c4_batch16.json', 'bench_r04_c4_batch16.json'),
+                 ('bench_c5_batch4.json', 'bench_r04_c5_batch4.json'), ('bench_c5_batch16.json', 'bench_r04_c5_batch16.json'),
+                 ('bench_c4_batch4_hipgraph.json', 'bench_r04_c4_batch4_hipgraph.json'),
+                 ('bench_c5_batch4_hipgraph.json', 'bench_r04_c5_batch4_hipgraph.json'),
+                 ('bench_c2_under_rocprofv3.json', 'bench_r04_fp16x3_under_rocprofv3.json'),
+                 ('splat_bench.json', 'r04_splat_bench.json')):
+    if os.path.exists(os.path.join(O, src)):
+        shutil.copy(os.path.join(O, src), os.path.join(P, dst))
+
+under = json.loads(open(os.path.join(O, 'bench_c2_under_rocprofv3.json')).read().strip().splitlines()[-1])
+stats = open(os.path.join(O, 'kernel_stats_c2.txt')).read()
+dom_line = next(l for l in stats.splitlines() if DOM in l)
+dom_avg = float(dom_line.split()[2])
+stamped('kernel_stats_c2.txt', 'r04_a_kernel_stats.txt',
+        '# rocprofv3 --kernel-trace --output-format rocpd -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline '
+        '--no-extras   (13 steps traced; per-step = total/13)\n'
+        f'# bench line printed by the same run: profiles/bench_r04_fp16x3_under_rocprofv3.json '
+        f'(roofline.avg_launch_ms {under["roofline"]["avg_launch_ms"]} vs {dom_avg} us below)\n')
+for w in ('c4', 'c5'):
+    stamped(f'kernel_stats_{w}.txt', f'r04_a_kernel_stats_{w}.txt',
+            f'# rocprofv3 --kernel-trace -- python bench.py --workload {w} --batch 16 --steps 10 --warmup 3 --no-cpu-baseline '
+            f'--batch 16 --no-extras (per-GPU batch 16; 13 steps traced)\n')
+stamped('blur_bench.txt', 'r04_d_blur_bench.txt')
+stamped('conv_layers.txt', 'r04_f_conv_layers.txt', '# scripts/conv_bench.py, fp16x3 (forward launches: binary16 limbs; the wgrad column: bf16 limbs), batch 16, ITERS=20\n')
+if os.path.exists(os.path.join(O, 'conv_layers_bf16x3.txt')):
+    stamped('conv_layers_bf16x3.txt', 'r04_f_conv_layers_bf16x3.txt', '# scripts/conv_bench.py "G ", bf16x3, batch 16, ITERS=20\n')
+stamped('determinism.txt', 'r04_determinism.txt',
+        '# scripts/check_determinism.py: two runs of two training iterations from the same seeds, compared bit for bit\n')
+stamped('pytest_gpu.txt', 'r04_pytest_gpu.txt', '# python -m pytest tests -m gpu -q (tail)\n')
+
+cal = {**rows('cal_fetch.txt'), **rows('cal_write.txt')}
+cal_f = find(cal, 'fused_bias_act_kernel', 'FETCH_SIZE')[1]
+cal_w = find(cal, 'fused_bias_act_kernel', 'WRITE_SIZE')[1]
+fetch, write = rows('pmc_fetch.txt'), rows('pmc_write.txt')
+with open(os.path.join(P, 'r04_b_pmc_hbm_traffic.txt'), 'w') as f:
+    f.write(STAMP + '# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 '
+            '--warmup 1 --no-cpu-baseline --no-extras\n# mean counter value per kernel (KB); calibration kernel (512 MiB in, '
+            '512 MiB out):\n')
+    for k, (n, v) in sorted(cal.items()):
+        if 'fused_bias_act_kernel' in k[0]:
+            f.write(f'{k[0]:70s} {k[1]:28s} n={n:4d} mean={v:16.1f}\n')
+    f.write('# kernels of the step:\n')
+    for k, (n, v) in sorted({**fetch, **write}.items()):
+        f.write(f'{k[0]:70s} {k[1]:28s} n={n:4d} mean={v:16.1f}\n')
+    f.write('# splat2d stress (scripts/splat_bench.py under the same two passes):\n')
+    for name in ('splat_fetch.txt', 'splat_write.txt'):
+        if os.path.exists(os.path.join(O, name)):
+            f.write(open(os.path.join(O, name)).read())
+stamped('pmc_sq.txt', 'r04_c_pmc_sq.txt', '# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- python bench.py '
+        '--steps 2 --warmup 1 --no-cpu-baseline --no-extras\n')
+
+fn, fv = find(fetch, DOM, 'FETCH_SIZE')
+wn, wv = find(write, DOM, 'WRITE_SIZE')
+scale_f = 512 * 1024 / cal_f
+fetch_b, write_b = int(fv * 1024 * round(scale_f)), int(wv * 1024)
+json.dump({
+    'kernel': 'conv3x3_patch_kernel<2, true, 256, 2, false, 1, true>', 'precision': 'fp16x3', 'workload': 'c2', 'batch': 16,
+    'kernel_source_sha16': sha, 'commit': commit,
+    'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python bench.py --steps 2 '
+               '--warmup 1 --no-cpu-baseline --no-extras',
+    'launches_averaged': fn, 'FETCH_SIZE_KB_per_launch': fv, 'WRITE_SIZE_KB_per_launch': wv,
+    'calibration': f'fused_bias_act on a 512 MiB tensor (scripts/pmc_calibrate.py) in the same session: FETCH_SIZE {cal_f} KB '
+                   f'= 1/{round(scale_f)} of the 512 MiB read (gfx950 under-count of 16 B/lane streaming reads, '
+                   f'MI355X_MICROARCH.md HBM section) -> x{round(scale_f)}; WRITE_SIZE {cal_w} KB = exact',
+    'fetch_bytes_per_launch': fetch_b, 'write_bytes_per_launch': write_b, 'hbm_bytes_per_launch': fetch_b + write_b,
+    'algorithmic_bytes_per_launch': {
+        'activations_in': 313174698, 'activations_out': 313174698,
+        'note': 'mean over the 6 forward launches per step: 512->512@64^2, 256->256@128^2, 128->128@256^2 (x2 generator '
+                'passes), batch 16, fp32'},
+    'reading': f'reads = {fetch_b / 313174698:.2f}x the input tensor (tile halos), writes = {write_b / 313174698:.2f}x the output',
+}, open(os.path.join(P, 'r04_pmc_traffic.json'), 'w'), indent=1)
+print(open(os.path.join(P, 'r04_pmc_traffic.json')).read())

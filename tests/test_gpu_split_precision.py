@@ -284,12 +284,17 @@ def test_fp16_block_exponent_any_magnitude(spec, scale, cuda, precision):
     precision('fp32')
     ref = run(xs)
     assert bool(torch.isfinite(ref).all()) and float(ref.abs().max()) > 0
+    from gangealing_amd.op import conv_mfma as cm
     precision('fp16x3')
     for grad in (False, True):
         out = run(xs, grad)
         assert bool(torch.isfinite(out).all())
         err = float((out - ref).abs().max() / ref.abs().max())
-        assert err <= 1e-5, (grad, err)
+        # gradient launches of shapes served by the generic re-gathering kernel keep bf16 limbs (conv_mfma.limb_code):
+        # the two-bf16-limb bound, at any magnitude as well
+        n, cin, cout, (hh, ww), k, stride, pad, mode, scaled = spec
+        bf16 = grad and cm.limb_code(True, cm._generic_shape(k, stride, pad, mode, ww)) == 2
+        assert err <= (3e-5 if bf16 else 1e-5), (grad, err)
 
 
 @pytest.mark.parametrize('spec', RANGE_CASES[:6], ids=lambda s: 'x'.join(map(str, s)))
@@ -305,7 +310,7 @@ def test_fp16_block_exponent_grows_inside_a_tile(spec, cuda, precision):
     quadrant = torch.ones_like(x[:1, :1])
     quadrant[..., : x.shape[-2] // 2, : x.shape[-1] // 2] = 1e6
     for name, xs in (('ascending', x * ramp), ('descending', x * ramp.flip(1)), ('quadrant', x * quadrant),
-                     ('zero-chunks', x * (ramp > 1.0))):
+                     ('zero-chunks', x * (ramp >= 1.0))):
         precision('fp32')
         ref = run(xs)
         precision('fp16x3')
