@@ -262,7 +262,7 @@ def _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile)
         if survey and not (workload_is_c2 and wl['batch'] >= 8):
             dominant = survey[0]['kernel']
         barrier()
-    prof = conv_mfma.LaunchProfiler(only=dominant) if dominant else conv_mfma.LaunchProfiler()
+    prof = conv_mfma.LaunchProfiler(only=dominant, names=sv.names) if dominant else conv_mfma.LaunchProfiler()
     if profile and not graphed:
         conv_mfma.PROFILER = prof        # HIP events around the dominant kernel's launches inside the timed region
     if world > 1:

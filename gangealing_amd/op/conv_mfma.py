@@ -22,10 +22,18 @@ class LaunchProfiler:
     kernel dominates another workload (C4: the transposed tile / the 513^2 blur; C5: the STN / VGG tiles).  only=name
     keeps the records of that kernel alone (the timed region of those workloads)."""
 
-    def __init__(self, every=False, only=None):
+    def __init__(self, every=False, only=None, names=None):
         self.records = []          # (start_event, end_event, work, kernel name, unit of work)
         self.every = bool(every) or only is not None
         self.only = only
+        # launch signature -> kernel name, learned while every launch is timed (the survey); with only=name the timed
+        # region then records events for the matching launches alone - an event pair around EVERY launch costs host time
+        # that a launch-bound step (small batches) cannot hide
+        self.names = {} if names is None else names
+
+    def wants(self, sig):
+        """Record this launch?  (survey: yes; only=name: when the survey saw this signature run that kernel)"""
+        return self.only is None or self.names.get(sig) == self.only
 
     def begin(self):
         start = torch.cuda.Event(enable_timing=True)
@@ -317,8 +325,11 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
         code = limb_code(grad, grad and _generic_shape(k, stride, pad, mode, w))
         limbs = code & 15
         use_split = limbs > 0 and isinstance(wmat, PackedWeight) and wmat.split_ok()
-        prof = PROFILER if (PROFILER is not None and PROFILER.every) else None
-        if prof is None and PROFILER is not None and k == 3 and mode == 0 and cout_g > 64:
+        prof = sig = None
+        if PROFILER is not None and PROFILER.every:
+            sig = (k, stride, pad, mode, batch, groups, cin_g, cout_g, h, w, in_scale is None, act is None, code)
+            prof = PROFILER if PROFILER.wants(sig) else None
+        if prof is None and PROFILER is not None and not PROFILER.every and k == 3 and mode == 0 and cout_g > 64:
             if use_split:
                 # exactly the launches that run conv3x3_patch_kernel<2, true, 256> (csrc/conv_mfma.hip: patch_geometry
                 # + the 256-pixel-tile rule): the generator's style-scaled 3x3 stride-1 layers that fill the chip
@@ -354,8 +365,11 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
         if prof is not None:
             # algorithmic FLOPs: a transposed stride-2 convolution does its multiply-adds at the INPUT positions
             pos = oh * ow if mode == 0 else h * w
-            prof.end(start, 2.0 * batch * groups * cout_g * cin_g * k * k * pos,
-                     last_conv_kernel() if prof.every else 'dominant')
+            name = 'dominant'
+            if prof.every:
+                name = last_conv_kernel()
+                prof.names[sig] = name
+            prof.end(start, 2.0 * batch * groups * cout_g * cin_g * k * k * pos, name)
     return y
 
 

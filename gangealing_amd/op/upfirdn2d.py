@@ -31,21 +31,21 @@ def _launch(x, kernel, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
     kernel = kernel.to(dtype=torch.float32 if x.dtype == torch.float16 else x.dtype).contiguous()
     out = torch.empty((n, c, max(out_h, 0), max(out_w, 0)), dtype=x.dtype, device=x.device)
     if out.numel():
-        prof = _profiler()
+        name = f'upfirdn2d<{kh}x{kw},up{up_x},down{down_x}>'
+        prof = _profiler(name)
         start = prof.begin() if prof is not None else None
         _lib.call('gg_upfirdn2d_' + _SUFFIX[x.dtype], out, x, kernel, n * c, in_h, in_w, kh, kw,
                   up_x, up_y, down_x, down_y, px0, px1, py0, py1)
         if prof is not None:      # algorithmic bytes: every input and output element once
-            prof.end(start, x.element_size() * (x.numel() + out.numel()),
-                     f'upfirdn2d<{kh}x{kw},up{up_x},down{down_x}>', 'byte')
+            prof.end(start, x.element_size() * (x.numel() + out.numel()), name, 'byte')
     return out
 
 
-def _profiler():
-    """bench.py's per-kernel timing (conv_mfma.LaunchProfiler with every=True), or None."""
+def _profiler(name):
+    """bench.py's per-kernel timing (conv_mfma.LaunchProfiler with every=True) when it wants launches of `name`."""
     from . import conv_mfma
     prof = conv_mfma.PROFILER
-    return prof if (prof is not None and prof.every) else None
+    return prof if (prof is not None and prof.every and (prof.only is None or prof.only == name)) else None
 
 
 _FLIPPED = {}
@@ -142,7 +142,7 @@ class _BlurNoiseAct(Function):
         n, c, in_h, in_w = x.shape
         p0, p1 = pad
         out = torch.empty((n, c, in_h + p0 + p1 - 3, in_w + p0 + p1 - 3), dtype=x.dtype, device=x.device)
-        prof = _profiler()
+        prof = _profiler('blur4_fused<noise+bias+lrelu>')
         start = prof.begin() if prof is not None else None
         _lib.call('gg_blur4_fused_f32', out, x, kernel, n, c, in_h, in_w, p0, p1, p0, p1, noise.contiguous(),
                   noise_weight.contiguous(), bias.contiguous(), None, negative_slope, scale)
@@ -162,7 +162,7 @@ class _BlurNoiseAct(Function):
         n, c, h, w = grad_output.shape
         g0, g1 = ctx.g_pad
         dx = torch.empty((n, c, h + g0 + g1 - 3, w + g0 + g1 - 3), dtype=grad_output.dtype, device=grad_output.device)
-        prof = _profiler()
+        prof = _profiler('blur4_fused<lrelu mask>')
         start = prof.begin() if prof is not None else None
         _lib.call('gg_blur4_fused_f32', dx, grad_output, _flipped(kernel), n, c, h, w,
                   g0, g1, g0, g1, None, None, None, out, negative_slope, scale)
