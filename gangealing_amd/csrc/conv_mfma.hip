@@ -1034,6 +1034,11 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       for (int chunk = chunk0; chunk < chunk1; ++chunk) {
         // here: every wave is past the barrier that followed its last LDS fetch of the previous chunk (or at kernel
         // start); registers hold this chunk's patch and its tap-0 slab
+        if (F16 && MASK && chunk > chunk0) {
+          prep_patch(chunk);
+          __syncthreads();
+          amax_next = read_block_amax<NT / 64>(sAmax);
+        }
         begin_chunk(chunk);
         store_w(0);
         load_w(chunk, 1);
@@ -1056,18 +1061,18 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
           // (the scheduler otherwise sinks each fetch down to its first use to shorten the live ranges, which puts
           // the LDS round trip back in front of the MFMAs)
           __builtin_amdgcn_sched_barrier(0);
-          // binary16 limbs: the next chunk's patch arrives in registers over taps 0 .. 5 - its channels are finished
-          // (mask, style, running maximum) a third per tap over taps 6 .. 8, next to the MFMAs, and the block's magnitude
-          // is published behind tap 8's barrier
-          // (the masked variant also holds the chunk's 32 mask references: it finishes each slice two taps after it was
-          // issued, which frees those registers early instead of keeping all 64 prefetch registers alive to tap 8)
-          if (F16 && more && !MASK && t >= 6) prep_patch_part(chunk + 1, 12 * (t - 6), t == 8 ? BKS : 12 * (t - 5), t == 8);
-          if (F16 && more && MASK && t >= 2)
-            prep_patch_part(chunk + 1, 6 * (t - 2) < BKS ? 6 * (t - 2) : BKS, 6 * (t - 1) < BKS ? 6 * (t - 1) : BKS, t == 8);
+          // binary16 limbs: the next chunk's patch is complete in registers (issued over taps 0 .. 5) - finish it (style,
+          // running maximum) next to tap 8's MFMAs and publish the block's magnitude behind this tap's barrier.
+          // Measured alternatives (same box, profiles/r04_e_block_exponent_placement_ab.txt): a third of the chunk per
+          // tap over taps 6 .. 8: +1 % on this kernel (longer live ranges); at the chunk top behind an extra barrier: +1 %.
+          // The MASKED variant (64 prefetch registers: values + mask references) spills with any early form - it does
+          // the work at the chunk top, behind one extra barrier per chunk (-0.26 ms per step against the spilling form).
+          if (F16 && more && !MASK && t == 8) prep_patch(chunk + 1);
+
           mma(fa0, fb0);
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();
-          if (F16 && more && t == 8) amax_next = read_block_amax<NT / 64>(sAmax);   // (lands under the next 12 MFMAs)
+          if (F16 && !MASK && more && t == 8) amax_next = read_block_amax<NT / 64>(sAmax);   // (lands under the next 12 MFMAs)
           if (t < 8) {
             const int t1 = t + 1, ky1 = t1 / 3, kx1 = t1 - ky1 * 3;
             read_frag(fa0, fb0, buf ^ 1, (ky1 * PW + kx1) * ROWB, 0);

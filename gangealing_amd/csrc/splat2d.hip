@@ -266,10 +266,13 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(
       // lane -> one point of this batch of 64
       Footprint f;
       f.t = 1; f.b = 0; f.l = 1; f.r = 0; f.xc = f.yc = f.normalizer = 0.f;        // an empty box for idle lanes
-      int idx = 0;
+      float pv[CG] = {0.f, 0.f, 0.f, 0.f};                                          // the point's values of this pass
       if (lane < m) {
-        idx = lists[beg + base + lane];
+        const int idx = lists[beg + base + lane];
         footprint(coords, sigma, idx, num_points, height, width, f);               // (a listed point always has a box)
+        const float* val = values + (size_t)idx * channels + c0;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) pv[c] = c < nc ? val[c] : 0.f;
       }
       // does any of the 64 boxes reach this wave's rows?  (most batches of most waves: no)
       const bool mine = f.b >= wrow0 && f.t <= wrow0 + 7;
@@ -283,17 +286,19 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(
         const float xc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f.xc), i));
         const float yc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f.yc), i));
         const float nz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f.normalizer), i));
-        const float* val = values + (size_t)__builtin_amdgcn_readlane(idx, i) * channels + c0;
+        // (the values travel with the box in the owning lane's registers: a load inside this loop put one memory
+        // latency on every visited point - 0.3 us x ~2000 points per wave was the whole kernel)
         float v[CG];
 #pragma unroll
-        for (int c = 0; c < CG; ++c) v[c] = c < nc ? val[c] : 0.f;
+        for (int c = 0; c < CG; ++c)
+          v[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[c]), i));
         const float fy = (float)py - yc;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int px = px0 + e;
           if (px < l || px > r) continue;
           const float fx = (float)px - xc;
-          const float alpha = expf(nz * (fx * fx + fy * fy));
+          const float alpha = __expf(nz * (fx * fx + fy * fy));       // v_exp_f32 (argument <= 0; results below 1e-12 do not matter)
           acc_a[e] += alpha;
 #pragma unroll
           for (int c = 0; c < CG; ++c) acc_v[c][e] += alpha * v[c];
