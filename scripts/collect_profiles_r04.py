@@ -71,6 +71,10 @@ for w in ('c4', 'c5'):
             f'# rocprofv3 --kernel-trace -- python bench.py --workload {w} --batch 16 --steps 10 --warmup 3 --no-cpu-baseline '
             f'--batch 16 --no-extras (per-GPU batch 16; 13 steps traced)\n')
 stamped('blur_bench.txt', 'r04_d_blur_bench.txt')
+if os.path.exists(os.path.join(O, 'splat_kernel_stats.txt')):
+    stamped('splat_kernel_stats.txt', 'r04_g_splat_kernel_stats.txt', '# rocprofv3 --kernel-trace -- python scripts/splat_bench.py (the reference kernel SplatForward runs in the same process as the checker)\n')
+if os.path.exists(os.path.join(O, 'pytest_reference.txt')):
+    stamped('pytest_reference.txt', 'r04_pytest_reference_dropin.txt', '# python -m pytest tests/test_gpu_reference_dropin.py tests/test_gpu_rccl_single_rank.py -q -m gpu (tail)\n')
 stamped('conv_layers.txt', 'r04_f_conv_layers.txt', '# scripts/conv_bench.py, fp16x3 (forward launches: binary16 limbs; the wgrad column: bf16 limbs), batch 16, ITERS=20\n')
 if os.path.exists(os.path.join(O, 'conv_layers_bf16x3.txt')):
     stamped('conv_layers_bf16x3.txt', 'r04_f_conv_layers_bf16x3.txt', '# scripts/conv_bench.py "G ", bf16x3, batch 16, ITERS=20\n')

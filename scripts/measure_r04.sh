@@ -58,6 +58,9 @@ sec_bench() {
 sec_layers() {
   python scripts/blur_bench.py > $O/blur_bench.txt 2>&1
   python scripts/splat_bench.py $O/splat_bench.json > $O/splat_bench.txt 2>&1
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $O/trace_splat -o trace --output-format rocpd -- python $R/scripts/splat_bench.py > /dev/null 2>&1 )
+  python scripts/rocpd_stats.py $(find $O/trace_splat -name "*.db" | head -1) 20 > $O/splat_kernel_stats.txt 2>&1
+  rm -rf $O/trace_splat
   GANGEALING_CONV_PRECISION=fp16x3 ITERS=20 python scripts/conv_bench.py > $O/conv_layers.txt 2>&1
   GANGEALING_CONV_PRECISION=bf16x3 ITERS=20 python scripts/conv_bench.py "G " > $O/conv_layers_bf16x3.txt 2>&1
 }
