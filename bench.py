@@ -229,11 +229,8 @@ def _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile)
     workload_is_c2 = (wl['gen_size'], wl['flow_size'], wl['num_heads'], wl['flips']) == (256, 128, 1, False)
     from gangealing_amd.train_step import GangealingTrainer
     conv_mfma.set_precision(precision)
-    # overlap_update: the STN's Adam + EMA + weight re-pack (HBM-bound) on a second stream, beside the next iteration's
-    # generator passes (matrix-pipe bound); every forward sees the same parameters as in the serial order
     trainer = GangealingTrainer(device, perturb_heads=0.02, seed=0, use_graph=graph and world == 1,
-                                stn_lr=SYNTHETIC_LR, ll_lr=SYNTHETIC_LR, allow_random_loss=True,
-                                overlap_update=os.environ.get('GANGEALING_OVERLAP_UPDATE', '1') != '0', **wl)
+                                stn_lr=SYNTHETIC_LR, ll_lr=SYNTHETIC_LR, allow_random_loss=True, **wl)
 
     def barrier():
         torch.cuda.synchronize()

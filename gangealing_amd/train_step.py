@@ -75,9 +75,6 @@ class FlatArena:
 
     def zero_grad(self):
         self.grad.zero_()
-        self.repoint_grads()
-
-    def repoint_grads(self):
         off = 0
         for p in self.params:          # autograd may have replaced .grad; re-point it at the arena
             n = p.numel()
@@ -177,19 +174,13 @@ class GangealingTrainer:
                  flow_identity_weight=1.0, stn_lr=1e-3, ll_lr=1e-2, sample_from_full_res=False, freeze_ll=False,
                  loss_fn='vgg_ssl', seed=0, perturb_heads=0.0, pipeline_update=None, anneal_psi=150000,
                  anneal_fn='cosine', period=37500, decay=0.9, tm=2, perceptual_weights=None, use_graph=False,
-                 graph_warmup=3, allow_random_loss=None, perceptual_trunk_weights=None, collectives=None,
-                 overlap_update=None):
+                 graph_warmup=3, allow_random_loss=None, perceptual_trunk_weights=None, collectives=None):
         """allow_random_loss: run on a seeded RANDOM perceptual trunk when the weight files are missing (synthetic
         benchmark / parity runs).  Default None = only when GANGEALING_SYNTHETIC=1 is set; training otherwise raises
         FileNotFoundError instead of silently optimising a meaningless objective.
         collectives: issue the gradient all-reduces (default: when the process group has more than one rank).  True
         on a ONE-rank group runs the exact multi-GPU call sequence - async all-reduce of the flat arena on RCCL's
-        stream, work.wait(), deferred Adam / EMA / re-pack - on a single-GPU box (tests/test_gpu_rccl_single_rank.py).
-        overlap_update: run the STN half of the optimizer step (Adam + EMA + weight re-pack: 1.5 GB of HBM traffic,
-        no matrix work) on a second HIP stream, concurrently with the NEXT iteration's two generator passes (matrix-pipe
-        bound, and they never touch the STN); the STN's next forward waits for it through an event.  Off by default:
-        after `step()` the parameters / EMA / moments are then still being written by the other stream - call `flush()`
-        before reading them (`state_dict()` and the STN's forward do).  bench.py switches it on."""
+        stream, work.wait(), deferred Adam / EMA / re-pack - on a single-GPU box (tests/test_gpu_rccl_single_rank.py)."""
         self.device = device
         self._pending = None
         # optional timing of the gradient exchange (bench.py --gpus N): list of (event before, event after) pairs
@@ -247,8 +238,6 @@ class GangealingTrainer:
         # is a collective to hide
         self.collectives = (world > 1) if collectives is None else bool(collectives)
         self.pipeline_update = self.collectives if pipeline_update is None else bool(pipeline_update)
-        self.overlap_update = bool(overlap_update) and not use_graph
-        self._update_stream = None
         self.stn.register_forward_pre_hook(lambda module, inputs: self.flush())
         # whole-iteration hipGraph (single process): after `graph_warmup` eager iterations the step - zeroing the
         # gradient arenas, loss forward, backward, both optimizers, EMA, weight re-pack: ~900 launches - is captured
@@ -363,23 +352,7 @@ class GangealingTrainer:
         stn_lr = self.stn_lr if stn_lr is None else stn_lr
         if not self.freeze_ll:
             adam_ema_step(self.ll_arena, self.ll_lr if ll_lr is None else ll_lr, grad_scale=scale)
-        if self.overlap_update:
-            # the STN update on the second stream: it waits for this stream's backward (and for the collective), then
-            # runs beside whatever this stream does next - the next iteration's generator passes
-            if self._update_stream is None:
-                self._update_stream = torch.cuda.Stream(device=self.device)
-            side, cur = self._update_stream, torch.cuda.current_stream()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                if work is not None:
-                    ev = self._comm_mark()
-                    work.wait()                  # `side` waits for the collective; the host and `cur` do not
-                    self._comm_mark(ev)
-                self._apply_stn_update(scale, stn_lr)
-            done = torch.cuda.Event()
-            done.record(side)
-            self._pending = ('event', done)
-        elif self.pipeline_update:
+        if self.pipeline_update:
             self._pending = (work, scale, stn_lr)
         else:
             self._apply_stn_update(scale, stn_lr)
@@ -466,12 +439,7 @@ class GangealingTrainer:
 
     def flush(self):
         """Apply a deferred STN update (no-op when nothing is pending)."""
-        if self._pending is not None and self._pending[0] == 'event':
-            done = self._pending[1]
-            self._pending = None
-            torch.cuda.current_stream().wait_event(done)     # the second stream's Adam / EMA / re-pack
-            self.stn_arena.zero_grad()
-        elif self._pending is not None:
+        if self._pending is not None:
             work, scale, lr = self._pending
             self._pending = None
             if work is not None:

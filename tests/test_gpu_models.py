@@ -514,36 +514,6 @@ def test_trainer_schedule_and_checkpoint_round_trip(cuda):
     assert float((da * db).sum() / (da.norm() * db.norm())) > 0.5 and 0.5 < float(da.norm() / db.norm()) < 2.0
 
 
-def test_overlapped_optimizer_update_is_bitwise_the_serial_one(cuda):
-    """overlap_update=True: the STN's Adam + EMA + re-pack run on a second stream beside the next iteration's generator
-    passes; after flush() every arena equals the serial trainer's bit for bit, and `state_dict()` sees the finished
-    update."""
-    from gangealing_amd.train_step import GangealingTrainer
-    kw = dict(gen_size=64, flow_size=64, batch=2, transform=('similarity', 'flow'), inject=3, ndirs=2,
-              perturb_heads=0.02, seed=21, stn_lr=1e-4, ll_lr=1e-4)
-    runs = {}
-    for overlap in (False, True):
-        tr = GangealingTrainer(cuda, overlap_update=overlap, **kw)
-        assert tr.overlap_update == overlap
-        hist = []
-        for i in range(4):
-            torch.manual_seed(70 + i)
-            parts = tr.step(psi=0.5)
-            if overlap:
-                assert tr._pending is not None and tr._pending[0] == 'event'
-            tr.flush()
-            assert tr._pending is None
-            hist.append((tr.stn_arena.param.clone(), tr.ema_arena.param.clone(), tr.stn_arena.exp_avg.clone(),
-                         tr.ll_arena.param.clone(), float(parts['p'])))
-        torch.manual_seed(99)
-        tr.step(psi=0.5)                             # left pending: state_dict() has to finish it
-        sd = tr.state_dict()
-        runs[overlap] = (hist, sd['t'][next(iter(sd['t']))].clone())
-    for a, b in zip(runs[False][0], runs[True][0]):
-        assert all(torch.equal(x, y) for x, y in zip(a[:4], b[:4])) and a[4] == b[4]
-    assert torch.equal(runs[False][1], runs[True][1])
-
-
 def test_graph_replay_trainer(cuda):
     """use_graph: the whole iteration captured in a hipGraph after the eager warm-up iterations.  Replays must train
     (finite losses, parameters move, EMA follows), the device-resident scalars must be live (a zero learning rate
