@@ -35,12 +35,9 @@ struct Footprint {
 };
 
 // the reference's box: splat_gpu_impl.cu:74-81
-__device__ __forceinline__ bool footprint(const float* __restrict__ coords, const float* __restrict__ sigma,
-                                          long long index, int num_points, int height, int width, Footprint& f) {
-  const int n = (int)(index / num_points);
-  f.xc = coords[2 * (size_t)index];
-  f.yc = coords[2 * (size_t)index + 1];
-  const float stdev = sigma[n];
+__device__ __forceinline__ bool footprint_xy(float xc, float yc, float stdev, int height, int width, Footprint& f) {
+  f.xc = xc;
+  f.yc = yc;
   if (!(f.xc >= 0.f && f.xc < (float)width && f.yc >= 0.f && f.yc < (float)height)) return false;
   const float length = 2.f * stdev;
   f.normalizer = -(1.f / (2.f * stdev * stdev));
@@ -49,6 +46,11 @@ __device__ __forceinline__ bool footprint(const float* __restrict__ coords, cons
   f.l = (int)fmaxf(0.f, floorf(f.xc - length));
   f.r = (int)fminf((float)(width - 1), ceilf(f.xc + length));
   return f.r >= f.l && f.b >= f.t;
+}
+__device__ __forceinline__ bool footprint(const float* __restrict__ coords, const float* __restrict__ sigma,
+                                          long long index, int num_points, int height, int width, Footprint& f) {
+  return footprint_xy(coords[2 * (size_t)index], coords[2 * (size_t)index + 1], sigma[(int)(index / num_points)], height,
+                      width, f);
 }
 __device__ __forceinline__ bool binned(const Footprint& f) {
   return f.r - f.l + 1 <= kMaxBinBox && f.b - f.t + 1 <= kMaxBinBox;
@@ -261,19 +263,38 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(
     for (int c = 0; c < CG; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc_v[c][e] = 0.f;
-    for (int base = 0; base < len; base += 64) {
-      const int m = len - base < 64 ? len - base : 64;
-      // lane -> one point of this batch of 64
-      Footprint f;
-      f.t = 1; f.b = 0; f.l = 1; f.r = 0; f.xc = f.yc = f.normalizer = 0.f;        // an empty box for idle lanes
-      float pv[CG] = {0.f, 0.f, 0.f, 0.f};                                          // the point's values of this pass
-      if (lane < m) {
-        const int idx = lists[beg + base + lane];
-        footprint(coords, sigma, idx, num_points, height, width, f);               // (a listed point always has a box)
+    // three batches in flight: the list indices of batch b + 2 and the coordinates / values of batch b + 1 are being
+    // fetched while batch b is visited (two dependent memory round trips per batch, hidden instead of paid 61 times)
+    const float stdev = sigma[n];
+    auto fetch_idx = [&](int base) { return (base + lane < len) ? lists[beg + base + lane] : -1; };
+    struct Raw { float xc, yc, v[CG]; };
+    auto fetch_raw = [&](int idx) {
+      Raw r;
+      r.xc = r.yc = -1.f;                                     // outside the image: an empty box
+#pragma unroll
+      for (int c = 0; c < CG; ++c) r.v[c] = 0.f;
+      if (idx >= 0) {
+        r.xc = coords[2 * (size_t)idx];
+        r.yc = coords[2 * (size_t)idx + 1];
         const float* val = values + (size_t)idx * channels + c0;
 #pragma unroll
-        for (int c = 0; c < CG; ++c) pv[c] = c < nc ? val[c] : 0.f;
+        for (int c = 0; c < CG; ++c) r.v[c] = c < nc ? val[c] : 0.f;
       }
+      return r;
+    };
+    int idx1 = fetch_idx(64);
+    Raw raw0 = fetch_raw(fetch_idx(0));
+    for (int base = 0; base < len; base += 64) {
+      const Raw raw1 = fetch_raw(idx1);
+      const int idx2 = fetch_idx(base + 128);
+      // lane -> one point of this batch of 64
+      Footprint f;
+      if (!footprint_xy(raw0.xc, raw0.yc, stdev, height, width, f)) { f.t = 1; f.b = 0; f.l = 1; f.r = 0; }
+      float pv[CG];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) pv[c] = raw0.v[c];
+      raw0 = raw1;
+      idx1 = idx2;
       // does any of the 64 boxes reach this wave's rows?  (most batches of most waves: no)
       const bool mine = f.b >= wrow0 && f.t <= wrow0 + 7;
       unsigned long long todo = __ballot(mine);
