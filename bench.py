@@ -17,6 +17,9 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL's buffer registration fails with the legacy mode:
+# hipIpcGetMemHandle: invalid argument); the environment normally carries it already
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import torch  # noqa: E402
 
