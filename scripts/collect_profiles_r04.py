@@ -63,13 +63,13 @@ dom_line = next(l for l in stats.splitlines() if DOM in l)
 dom_avg = float(dom_line.split()[2])
 stamped('kernel_stats_c2.txt', 'r04_a_kernel_stats.txt',
         '# rocprofv3 --kernel-trace --output-format rocpd -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline '
-        '--no-extras   (13 steps traced; per-step = total/13)\n'
+        '--no-extras   (15 steps traced: 3 warm-up, the 2 steps of the kernel survey, 10 timed; per-step = total/15)\n'
         f'# bench line printed by the same run: profiles/bench_r04_fp16x3_under_rocprofv3.json '
         f'(roofline.avg_launch_ms {under["roofline"]["avg_launch_ms"]} vs {dom_avg} us below)\n')
 for w in ('c4', 'c5'):
     stamped(f'kernel_stats_{w}.txt', f'r04_a_kernel_stats_{w}.txt',
             f'# rocprofv3 --kernel-trace -- python bench.py --workload {w} --batch 16 --steps 10 --warmup 3 --no-cpu-baseline '
-            f'--batch 16 --no-extras (per-GPU batch 16; 13 steps traced)\n')
+            f'--batch 16 --no-extras (per-GPU batch 16; 15 steps traced)\n')
 stamped('blur_bench.txt', 'r04_d_blur_bench.txt')
 if os.path.exists(os.path.join(O, 'splat_kernel_stats.txt')):
     stamped('splat_kernel_stats.txt', 'r04_g_splat_kernel_stats.txt', '# rocprofv3 --kernel-trace -- python scripts/splat_bench.py (the reference kernel SplatForward runs in the same process as the checker)\n')
