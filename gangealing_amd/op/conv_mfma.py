@@ -114,13 +114,19 @@ def limb_code(grad=False, generic=False):
     return limbs | 16 if PRECISION in (_F16_GRAD if grad else _F16_FORWARD) else limbs
 
 
-def _generic_shape(k, stride, pad, mode, w):
+_S2_PATCH = _os.environ.get('GG_S2_PATCH', '1') != '0'      # (the library reads the same switch)
+
+
+def _generic_shape(k, stride, pad, mode, w, h=None):
     """True when csrc/conv_mfma.hip::conv_dispatch sends this split-precision launch to conv_split_kernel (neither the
-    3x3 / stride-1 patch tile nor the transposed 3x3 / stride-2 tile serves it).  A performance hint only: either limb
-    format is valid on every kernel."""
+    3x3 / stride-1 patch tile, the transposed 3x3 / stride-2 tile nor the 3x3 / stride-2 patch tile of
+    conv_s2_patch.hip serves it).  A performance hint only: either limb format is valid on every kernel."""
     pow2 = (w & (w - 1)) == 0
     if mode == 1:
         return not (k == 3 and pad <= 1 and w >= 4 and pow2)
+    if k == 3 and stride == 2 and pad == 0 and _S2_PATCH:
+        ow, oh = (w - 3) // 2 + 1, ((w if h is None else h) - 3) // 2 + 1
+        return not (ow >= 32 and ow % 32 == 0 and oh >= 4 and oh % 4 == 0)
     return not (k == 3 and stride == 1 and pad == 1 and w >= 16 and pow2)
 
 
@@ -322,7 +328,7 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             oh, ow = out_hw
     y = torch.empty((batch, groups * cout_g, oh, ow), dtype=torch.float32, device=x.device)
     if y.numel():
-        code = limb_code(grad, grad and _generic_shape(k, stride, pad, mode, w))
+        code = limb_code(grad, grad and _generic_shape(k, stride, pad, mode, w, h))
         limbs = code & 15
         use_split = limbs > 0 and isinstance(wmat, PackedWeight) and wmat.split_ok()
         prof = sig = None

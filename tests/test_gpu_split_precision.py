@@ -34,6 +34,12 @@ CASES = [
     (1, 256, 256, (16, 16), 3, 2, 0, 1, True),    # split-K + atomics
     (2, 64, 96, (4, 4), 3, 2, 0, 1, True),        # 4-wide image: one tile covers the whole q-grid
     (3, 64, 64, (7, 8), 3, 2, 1, 1, False),       # 8-wide, pad 1
+    # 3x3 / stride 2 / pad 0 patch-reuse tile (conv_s2_patch.hip: output width a multiple of 32, height of 4)
+    (2, 64, 96, (65, 65), 3, 2, 0, 0, True),      # 32^2 outputs, ragged cout, style + demodulation scales
+    (3, 96, 160, (17, 129), 3, 2, 0, 0, False),   # 8 x 64 outputs, 6 chunks of 16 channels, two cout tiles (one ragged)
+    (1, 512, 256, (9, 65), 3, 2, 0, 0, True),     # a single pixel tile: split-K over the channel chunks
+    (2, 64, 64, (66, 130), 3, 2, 0, 0, False),    # even input sizes (the last input row / column is never read)
+    (5, 32, 128, (33, 193), 3, 2, 0, 0, True),    # 16 x 96 outputs: three tile columns, two chunks
 ]
 
 
@@ -256,6 +262,7 @@ RANGE_CASES = [
     (4, 64, 128, (128, 128), 3, 2, 0, 1, True),    # convT3x3s2_patch_kernel, 128-q tile
     (2, 96, 128, (21, 32), 3, 2, 0, 1, False),     # convT3x3s2_patch_kernel, 64-q tile
     (1, 512, 512, (4, 4), 3, 1, 1, 0, True),       # split-K: every split carries its own exponent
+    (2, 64, 96, (65, 67), 3, 2, 0, 0, True),       # conv3x3s2_patch_kernel (conv_s2_patch.hip): 32 x 32 outputs
 ]
 
 
@@ -293,11 +300,11 @@ def test_fp16_block_exponent_any_magnitude(spec, scale, cuda, precision):
         # gradient launches of shapes served by the generic re-gathering kernel keep bf16 limbs (conv_mfma.limb_code):
         # the two-bf16-limb bound, at any magnitude as well
         n, cin, cout, (hh, ww), k, stride, pad, mode, scaled = spec
-        bf16 = grad and cm.limb_code(True, cm._generic_shape(k, stride, pad, mode, ww)) == 2
+        bf16 = grad and cm.limb_code(True, cm._generic_shape(k, stride, pad, mode, ww, hh)) == 2
         assert err <= (3e-5 if bf16 else 1e-5), (grad, err)
 
 
-@pytest.mark.parametrize('spec', RANGE_CASES[:6], ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('spec', RANGE_CASES[:6] + RANGE_CASES[7:], ids=lambda s: 'x'.join(map(str, s)))
 def test_fp16_block_exponent_grows_inside_a_tile(spec, cuda, precision):
     """Chunks of 32 input channels (and image regions) of very different magnitude inside ONE launch: the tile's exponent
     has to grow while it accumulates (accumulators rescaled by an exact power of two) or stay put when a later chunk is
@@ -354,3 +361,28 @@ def test_fp16_masked_dgrad_tiny_gradients(cuda, precision):
         assert dx is not None
         err = float((dx - ref).abs().max() / ref.abs().max())
         assert err <= 1e-5, err
+
+
+@pytest.mark.parametrize('mode_name,tol', [('bf16x3', 3e-5), ('fp16x3', 1e-5)])
+@pytest.mark.parametrize('spec', [(2, 4, 32, 48, (33, 65)), (16, 16, 32, 48, (65, 65)), (1, 2, 64, 200, (9, 129))],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_s2_patch_grouped_vs_float64(spec, mode_name, tol, cuda, precision):
+    """The stride-2 patch tile with groups (the reference's per-sample-weight formulation reaches it with groups = N:
+    the data gradient of conv_transpose2d(groups = N), networks.py:268-272), forward and gradient launches, against
+    float64 F.conv2d on the host.  The third case has one pixel tile per image: split-K."""
+    import torch.nn.functional as F
+    from gangealing_amd.op import conv_mfma as cm
+    n, groups, cin_g, cout_g, (hh, ww) = spec
+    g = torch.Generator(device='cpu').manual_seed(4321)
+    x = torch.randn(n, groups * cin_g, hh, ww, generator=g)
+    w = torch.randn(groups * cout_g, cin_g, 3, 3, generator=g) / (cin_g * 9) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), stride=2, groups=groups)
+    pw = cm.PackedWeight(w.to(cuda), groups, cout_g, cin_g, 3, 0, 0, 1.0)
+    precision(mode_name)
+    for grad in (False, True):
+        out = cm.conv_forward(x.to(cuda), pw, n, groups, cin_g, cout_g, 3, 2, 0, 0, grad=grad)
+        assert out.shape == ref.shape
+        err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert err < tol, (grad, err)
+        if cm._S2_PATCH and pw.split_ok():
+            assert cm.last_conv_kernel().startswith('conv3x3s2_patch'), cm.last_conv_kernel()
