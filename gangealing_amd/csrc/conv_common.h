@@ -229,6 +229,34 @@ __device__ __forceinline__ unsigned short f16_limb_rn(float v) {
   return __builtin_bit_cast(unsigned short, (_Float16)fminf(fmaxf(v, -65504.f), 65504.f));
 }
 
+// launch descriptor of the weight-gradient kernels
+struct WgradArgs {
+  float* dw;
+  const float* x;
+  const float* dy;
+  int batch, groups, cin_g, cout_g, h, w, oh, ow, stride, pad;
+  int jtot;                     // cin_g * KS*KS
+  int tiles_co, tiles_j;
+  long long ktot;               // batch*oh*ow
+  long long k_per_split;
+  float scale;
+  // optional (row-streaming kernel): dy is the gradient w.r.t. a leaky-ReLU OUTPUT; the activation's backward
+  // dy * (mask_ref > 0 ? 1 : mask_alpha) * mask_gain is applied while dy is staged, and its per-channel sum (the
+  // bias gradient) is accumulated into dbias
+  const float* mask_ref;
+  float mask_alpha, mask_gain;
+  float* dbias;
+  // generic kernels: K-splits write their raw tiles to part[(split * groups + g) * cout_g * jtot + ...] (summed in
+  // split order by a reduce pass - no float atomics); null: a single split stores (or adds, `accumulate`) into dw
+  float* part;
+  int accumulate;
+};
+
+// conv_s2_wgrad.hip: 3x3 / stride 2 / pad 0 weight gradient, row-streaming (workspace layout and reduce pass of
+// conv3x3_wgrad_rows_kernel); tco x tci = 128 x 32 or 64 x 64
+void s2_wgrad_rows_launch(const WgradArgs& a, int limbs, bool narrow, int segs, int rblocks, int rows_per_block,
+                          int units_per_block, float* ws, dim3 grid, hipStream_t st);
+
 // conv_s2_patch.hip: 3x3 / stride 2 / pad 0 correlation with input-patch reuse (tpix = 128 or 256 output pixels per
 // block, 128 output channels; a.tiles_co / tiles_pix / nslabs (16-channel chunks) / slabs_per_split / part set by the caller)
 constexpr int kS2MaxCin = 1024;            // the image-group's in_scale vector is kept in LDS

@@ -1646,27 +1646,7 @@ constexpr int WBK = 32;
 constexpr int WT = 128;          // tile edge (co and j)
 constexpr int WLD = WT + 1;
 
-struct WgradArgs {
-  float* dw;
-  const float* x;
-  const float* dy;
-  int batch, groups, cin_g, cout_g, h, w, oh, ow, stride, pad;
-  int jtot;                     // cin_g * KS*KS
-  int tiles_co, tiles_j;
-  long long ktot;               // batch*oh*ow
-  long long k_per_split;
-  float scale;
-  // optional (row-streaming kernel): dy is the gradient w.r.t. a leaky-ReLU OUTPUT; the activation's backward
-  // dy * (mask_ref > 0 ? 1 : mask_alpha) * mask_gain is applied while dy is staged, and its per-channel sum (the
-  // bias gradient) is accumulated into dbias
-  const float* mask_ref;
-  float mask_alpha, mask_gain;
-  float* dbias;
-  // generic kernels: K-splits write their raw tiles to part[(split * groups + g) * cout_g * jtot + ...] (summed in
-  // split order by a reduce pass - no float atomics); null: a single split stores (or adds, `accumulate`) into dw
-  float* part;
-  int accumulate;
-};
+// (struct WgradArgs: conv_common.h)
 
 template <int KS>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
@@ -3014,7 +2994,8 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     // vs 0.075: profiles/r04_h_s2_patch_ab.txt).  GG_S2_PATCH = 128 / 256 forces one of them, 1 = this rule.
     const long long tiles256 = (long long)a.batch * a.oh * a.ow / 256 * ((a.cout_g + 127) / 128) * a.groups;
     int tpix = s2_patch_tpix() == 256 ? 256 : 128;
-    if (s2_patch_tpix() == 1) tpix = (tiles256 >= gg::kNumCu && a.cin_g >= 256) ? 256 : 128;
+    if (s2_patch_tpix() == 1)
+      tpix = ((tiles256 >= gg::kNumCu && a.cin_g >= 256) || (tiles256 >= 2 * gg::kNumCu && a.cin_g >= 128)) ? 256 : 128;
     if (tpix == 256 && !s2_patch_serves(a, 256)) tpix = 128;
     if (s2_patch_serves(a, tpix)) return launch_conv_s2_patch(a, tpix, st);
   }
@@ -3356,6 +3337,55 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
         wgrad_reduce_kernel<1><<<gg::stream_grid(total, 256), 256, 0, st>>>(
             dw, workspace, groups, cout_g, cin_g, a.tiles_co, a.tiles_j, tco, tci, (int)splits, scale, accumulate ? 1 : 0,
             dbias, dbws);
+      return gg::launch_status("wgrad_reduce");
+    }
+  }
+  static const bool s2_rows = env_int("GG_S2_WGRAD", 1) != 0;           // measurement switch: 0 = the generic kernel
+  if (s2_rows && limbs && ksize == 3 && stride == 2 && pad == 0 && !mask_ref && a.ow >= 16 &&
+      (long long)cin_g * h * w * 4 < (1LL << 31)) {
+    // row-streaming stride-2 kernel (conv_s2_wgrad.hip): the plan of the stride-1 kernel over the OUTPUT rows / columns
+    const bool narrow = cout_g <= 64;
+    const int tco = narrow ? 64 : 128, tci = narrow ? 64 : 32;
+    a.tiles_co = (cout_g + tco - 1) / tco;
+    a.tiles_j = (cin_g + tci - 1) / tci;
+    const int segs = (a.ow + 31) / 32;
+    const long long tiles = (long long)a.tiles_co * a.tiles_j * groups;
+    const long long units = (long long)batch * segs;
+    long long rblocks = (2LL * gg::kNumCu + tiles * units - 1) / (tiles * units);
+    const long long max_rb = (a.oh + 7) / 8;                            // >= 8 rows per block
+    if (rblocks > max_rb) rblocks = max_rb;
+    if (rblocks < 1) rblocks = 1;
+    const int rows_per_block = (int)((a.oh + rblocks - 1) / rblocks);
+    rblocks = (a.oh + rows_per_block - 1) / rows_per_block;
+    const long long total_units = units * rblocks;
+    long long upb = tiles * total_units / (2LL * gg::kNumCu);
+    if (upb < 1) upb = 1;
+    if (upb > 8) upb = 8;
+    constexpr long long kMaxPartialBytes = 1LL << 30;
+    while (upb < total_units &&
+           tiles * ((total_units + upb - 1) / upb) * 9LL * 4096 * (long long)sizeof(float) > kMaxPartialBytes)
+      upb *= 2;
+    const long long splits = (total_units + upb - 1) / upb;
+    const long long need = tiles * splits * 9LL * 4096 * (long long)sizeof(float);
+    if ((!workspace || workspace_bytes < need) && need < (2LL << 30)) {
+      workspace = reinterpret_cast<float*>(gg::scratch(st, (size_t)need));
+      if (!workspace) return -3;
+      workspace_bytes = need;
+    }
+    if (workspace && workspace_bytes >= need && splits <= 65535 && (long long)a.tiles_co * a.tiles_j < (1LL << 31)) {
+      dim3 grid((unsigned)(a.tiles_co * a.tiles_j), (unsigned)splits, (unsigned)groups);
+      s2_wgrad_rows_launch(a, limbs, narrow, segs, (int)rblocks, rows_per_block, (int)upb, workspace, grid, st);
+      int rc = gg::launch_status("conv3x3s2_wgrad_rows");
+      if (rc) return rc;
+      const long long total = tiles * 9LL * 4096;
+      if (splits >= 64)
+        wgrad_reduce_kernel<8><<<gg::stream_grid(total * 8, 256), 256, 0, st>>>(
+            dw, workspace, groups, cout_g, cin_g, a.tiles_co, a.tiles_j, tco, tci, (int)splits, scale, accumulate ? 1 : 0,
+            nullptr, nullptr);
+      else
+        wgrad_reduce_kernel<1><<<gg::stream_grid(total, 256), 256, 0, st>>>(
+            dw, workspace, groups, cout_g, cin_g, a.tiles_co, a.tiles_j, tco, tci, (int)splits, scale, accumulate ? 1 : 0,
+            nullptr, nullptr);
       return gg::launch_status("wgrad_reduce");
     }
   }

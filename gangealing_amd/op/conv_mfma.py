@@ -853,6 +853,33 @@ def style_demod(latent, weight, bias, w_scale, b_scale, wsq=None, eps=1e-8):
     return style, demod
 
 
+class _StyleDemodGrad(Function):
+    """style_demod for a W+ slot that needs a gradient (the latent learner's slots) while the modulation layer itself is
+    frozen: the same single launch forward (instead of F.linear + mul + mm + add + rsqrt), one matrix product backward.
+    The demodulation is returned non-differentiable: _ModulatedConv's backward already carries d demod / d style in the
+    style gradient it returns (gg_modconv_style_grad_f32)."""
+
+    @staticmethod
+    def forward(ctx, latent, weight, bias, w_scaled, w_scale, b_scale, wsq, eps):
+        style, demod = style_demod(latent, weight, bias, w_scale, b_scale, wsq, eps)
+        ctx.save_for_backward(w_scaled)
+        if demod is None:
+            demod = style.new_empty(0)
+        ctx.mark_non_differentiable(demod)
+        return style, demod
+
+    @staticmethod
+    def backward(ctx, dstyle, _ddemod):
+        (w_scaled,) = ctx.saved_tensors
+        return torch.mm(dstyle.contiguous(), w_scaled), None, None, None, None, None, None, None
+
+
+def style_demod_grad(latent, weight, bias, w_scaled, w_scale, b_scale, wsq=None, eps=1e-8):
+    """(style, demod) as style_demod, differentiable w.r.t. `latent` (w_scaled = weight * w_scale, cached by the caller)."""
+    style, demod = _StyleDemodGrad.apply(latent, weight, bias, w_scaled, w_scale, b_scale, wsq, eps)
+    return style, (demod if wsq is not None else None)
+
+
 def modulated_conv2d(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample=False, demodulate=True, act=None, demod=None,
                      bias=None):
     """act = (noise, noise_weight, act_bias, alpha, gain) fuses the StyledConv tail (3x3, no upsampling, and no

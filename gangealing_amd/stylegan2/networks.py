@@ -218,6 +218,13 @@ class ModulatedConv2d(nn.Module):
             # no gradient wanted for the style: EqualLinear + demodulation in one launch (csrc/modulation.hip)
             return conv_mfma.style_demod(style, mod.weight, mod.bias, mod.scale, mod.lr_mul,
                                          wsq if self.demodulate else None, self.eps)
+        if ('style_demod' not in conv_mfma.DISABLED and 'style_demod_grad' not in conv_mfma.DISABLED and
+                input.dtype == torch.float32 and style.dtype == torch.float32 and mod.activation is None and
+                style.dim() == 2 and not mod.weight.requires_grad and not (mod.bias is not None and mod.bias.requires_grad)):
+            # a learned W+ slot through a frozen modulation layer (the latent learner's slots): the same single launch,
+            # with a gradient for the latent
+            return conv_mfma.style_demod_grad(style, mod.weight, mod.bias, mod._scaled()[0], mod.scale, mod.lr_mul,
+                                              wsq if self.demodulate else None, self.eps)
         return mod(style), None
 
     def bank_entry(self, slot):

@@ -18,7 +18,7 @@ def short(name):
     return name[:110]
 
 
-def main(db, anchor='style_bank_kernel<false>', which=3):
+def main(db, anchor='pack_weight_many_kernel', which=3):
     con = sqlite3.connect(db)
     cur = con.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
@@ -44,4 +44,4 @@ def main(db, anchor='style_bank_kernel<false>', which=3):
 
 if __name__ == '__main__':
     a = sys.argv
-    main(a[1], a[2] if len(a) > 2 else 'style_bank_kernel<false>', int(a[3]) if len(a) > 3 else 3)
+    main(a[1], a[2] if len(a) > 2 else 'pack_weight_many_kernel', int(a[3]) if len(a) > 3 else 3)

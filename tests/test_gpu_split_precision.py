@@ -386,3 +386,33 @@ def test_s2_patch_grouped_vs_float64(spec, mode_name, tol, cuda, precision):
         assert err < tol, (grad, err)
         if cm._S2_PATCH and pw.split_ok():
             assert cm.last_conv_kernel().startswith('conv3x3s2_patch'), cm.last_conv_kernel()
+
+
+@pytest.mark.parametrize('mode_name,tol', [('bf16x3', 3e-5), ('bf16x6', 1e-5), ('fp16x3', 3e-5)])
+@pytest.mark.parametrize('spec', [(2, 64, 128, 65, 65, 1), (3, 96, 64, 33, 129, 1), (1, 128, 160, 17, 33, 1),
+                                  (2, 32, 64, 129, 129, 1), (4, 64, 96, 17, 41, 1), (2, 64, 96, 66, 130, 2),
+                                  (16, 64, 128, 129, 129, 1), (5, 160, 136, 9, 65, 1)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_s2_row_streaming_wgrad_vs_float64(spec, mode_name, tol, cuda, precision):
+    """3x3 / stride 2 / pad 0 weight gradient (conv_s2_wgrad.hip: rolling window of column-parity planes) against the
+    float64 gradient of F.conv2d on the host: 64- and 128-channel tiles, ragged cout / cin tiles, a 16- and a 20-column
+    output (ragged strip), even input sizes, groups, chained K-units (batch 16)."""
+    import torch.nn.functional as F
+    from gangealing_amd.op import conv_mfma as cm
+    n, cin, cout, h, w, groups = spec
+    g = torch.Generator(device='cpu').manual_seed(77)
+    x = torch.randn(n, cin * groups, h, w, generator=g)
+    oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    dy = torch.randn(n, cout * groups, oh, ow, generator=g)
+    wd = torch.zeros(cout * groups, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wd, stride=2, groups=groups).backward(dy.double())
+    ref = 0.5 * wd.grad
+    precision(mode_name)
+    out = cm.conv_wgrad(x.to(cuda), dy.to(cuda), n, groups, cin, cout, 3, 2, 0, 0.5)
+    assert out.shape == ref.shape
+    err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < tol, err
+    slot = torch.full_like(out, 2.0)
+    cm.conv_wgrad(x.to(cuda), dy.to(cuda), n, groups, cin, cout, 3, 2, 0, 0.5, into=slot)
+    err = float((slot.cpu().double() - 2.0 - ref).abs().max() / ref.abs().max())
+    assert err < tol + 2e-6, err
