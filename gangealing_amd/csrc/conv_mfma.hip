@@ -2845,6 +2845,74 @@ __global__ __launch_bounds__(256) void conv1x1_fewout_kernel(float* __restrict__
   }
 }
 
+// 1x1 convolution with <= 4 INPUT channels (the data gradient of the last ToRGB layer: 3 -> 128 channels at the output
+// resolution): every output element is a 3-term dot product - a write-only stream (537 MB at 256^2, batch 16) that the
+// 32-wide MFMA tile served at 2.7 TB/s with K = 3 of its 16 reduction slots in use.  One block = 1024 pixels x 16 output
+// channels of one image; x is re-read from L2 by the blocks of the other channel groups (12 MB in all).
+constexpr int FEWIN_CO = 16;
+template <int NCI>
+__global__ __launch_bounds__(256) void conv1x1_fewin_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                            const float* __restrict__ wmat,
+                                                            const float* __restrict__ in_scale,
+                                                            const float* __restrict__ out_scale,
+                                                            const float* __restrict__ bias, int cout, long long hw,
+                                                            int nt) {
+  __shared__ float sw[FEWIN_CO][NCI + 1];                  // [co][ci] style-scaled weights, [co][NCI] = bias
+  __shared__ float ssc[FEWIN_CO];
+  const int n = blockIdx.z, co0 = blockIdx.y * FEWIN_CO, tid = threadIdx.x;
+  if (tid < FEWIN_CO * NCI) {
+    const int j = tid / NCI, ci = tid - j * NCI, co = co0 + j;
+    sw[j][ci] = co < cout ? wmat[ci * cout + co] * (in_scale ? in_scale[(size_t)n * NCI + ci] : 1.f) : 0.f;
+  }
+  if (tid < FEWIN_CO) {
+    const int co = co0 + tid;
+    sw[tid][NCI] = (bias && co < cout) ? bias[co] : 0.f;
+    ssc[tid] = (out_scale && co < cout) ? out_scale[(size_t)n * cout + co] : 1.f;
+  }
+  __syncthreads();
+  const long long p = ((long long)blockIdx.x * 256 + tid) * 4;
+  if (p >= hw) return;                                      // hw % 4 == 0
+  float4 v[NCI];
+#pragma unroll
+  for (int ci = 0; ci < NCI; ++ci) v[ci] = *reinterpret_cast<const float4*>(x + ((size_t)n * NCI + ci) * hw + p);
+  const int jn = cout - co0 < FEWIN_CO ? cout - co0 : FEWIN_CO;
+  for (int j = 0; j < jn; ++j) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ci = 0; ci < NCI; ++ci) {
+      const float wj = sw[j][ci];
+      r.x += v[ci].x * wj; r.y += v[ci].y * wj; r.z += v[ci].z * wj; r.w += v[ci].w * wj;
+    }
+    const float sc = ssc[j], bi = sw[j][NCI];
+    r.x = r.x * sc + bi; r.y = r.y * sc + bi; r.z = r.z * sc + bi; r.w = r.w * sc + bi;
+    float* dst = y + ((size_t)n * cout + co0 + j) * hw + p;
+    if (nt) __builtin_nontemporal_store(f32x4{r.x, r.y, r.z, r.w}, reinterpret_cast<f32x4*>(dst));
+    else *reinterpret_cast<float4*>(dst) = r;
+  }
+}
+
+bool fewin_serves(const ConvArgs& a, int stride, int pad, int mode) {
+  const long long hw = (long long)a.h * a.w;
+  static const bool off = getenv("GG_NO_FEWIN") != nullptr;       // measurement switch
+  return !off && mode == 0 && stride == 1 && pad == 0 && a.groups == 1 && a.cin_g >= 1 && a.cin_g <= 4 && a.cout_g >= 16 &&
+         a.wmat && hw % 4 == 0 && hw >= 4096 && !a.act && !a.mask_ref && a.batch <= 65535 &&
+         (a.cout_g + FEWIN_CO - 1) / FEWIN_CO <= 65535 &&
+         (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
+}
+
+int launch_conv1x1_fewin(const ConvArgs& a, hipStream_t st) {
+  NOTE_KERNEL("conv1x1_fewin");
+  const long long hw = (long long)a.h * a.w;
+  dim3 grid((unsigned)((hw / 4 + 255) / 256), (unsigned)((a.cout_g + FEWIN_CO - 1) / FEWIN_CO), (unsigned)a.batch);
+  switch (a.cin_g) {
+    case 1: conv1x1_fewin_kernel<1><<<grid, 256, 0, st>>>(a.y, a.x, a.wmat, a.in_scale, a.out_scale, a.bias, a.cout_g, hw, a.nt_store); break;
+    case 2: conv1x1_fewin_kernel<2><<<grid, 256, 0, st>>>(a.y, a.x, a.wmat, a.in_scale, a.out_scale, a.bias, a.cout_g, hw, a.nt_store); break;
+    case 3: conv1x1_fewin_kernel<3><<<grid, 256, 0, st>>>(a.y, a.x, a.wmat, a.in_scale, a.out_scale, a.bias, a.cout_g, hw, a.nt_store); break;
+    default: conv1x1_fewin_kernel<4><<<grid, 256, 0, st>>>(a.y, a.x, a.wmat, a.in_scale, a.out_scale, a.bias, a.cout_g, hw, a.nt_store); break;
+  }
+  return gg::launch_status("conv1x1_fewin");
+}
+
 bool fewout_serves(const ConvArgs& a, int stride, int pad, int mode) {
   const long long hw = (long long)a.h * a.w;
   static const bool off = getenv("GG_NO_FEWOUT") != nullptr;      // measurement switch
@@ -2974,6 +3042,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     return kNotFused;
   }
   if (KS == 1 && limbs == 0 && fewout_serves(a, stride, pad, mode)) return launch_conv1x1_fewout(a, st);
+  if (KS == 1 && limbs == 0 && fewin_serves(a, stride, pad, mode)) return launch_conv1x1_fewin(a, st);
   if (KS == 3 && limbs == 0 && fewout3_serves(a, stride, pad, mode)) return launch_conv3x3_fewout(a, st);
   if (!a.act && limbs && KS == 3 && mode == 1 && pad <= 1 && a.w >= 4 && (a.w & (a.w - 1)) == 0 &&
       (long long)a.cin_g * a.h * a.w * 4 < (1LL << 31) && (long long)a.cout_g * a.oh * a.ow * 4 < (1LL << 31))

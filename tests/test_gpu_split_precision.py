@@ -416,3 +416,30 @@ def test_s2_row_streaming_wgrad_vs_float64(spec, mode_name, tol, cuda, precision
     cm.conv_wgrad(x.to(cuda), dy.to(cuda), n, groups, cin, cout, 3, 2, 0, 0.5, into=slot)
     err = float((slot.cpu().double() - 2.0 - ref).abs().max() / ref.abs().max())
     assert err < tol + 2e-6, err
+
+
+@pytest.mark.parametrize('spec', [(2, 3, 128, 64, 64, True), (3, 1, 40, 64, 80, False), (16, 3, 128, 256, 256, True),
+                                  (2, 4, 17, 128, 32, True)], ids=lambda s: 'x'.join(map(str, s)))
+def test_conv1x1_few_input_channels(spec, cuda, precision):
+    """1x1 convolution with <= 4 input channels (conv1x1_fewin_kernel: the data gradient of the last ToRGB layer, a
+    write-only stream) against float64: style / demodulation scales, bias, ragged channel groups; every precision mode
+    sends this shape to the same exact-fp32 kernel."""
+    from gangealing_amd.op import conv_mfma as cm
+    n, cin, cout, h, w, scaled = spec
+    g = torch.Generator(device='cpu').manual_seed(31)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g)
+    s_in = torch.rand(n, cin, generator=g) + 0.5 if scaled else None
+    s_out = torch.rand(n, cout, generator=g) + 0.5 if scaled else None
+    bias = torch.randn(cout, generator=g) if scaled else None
+    ref = torch.einsum('nihw,oi->nohw', (x * s_in.view(n, cin, 1, 1) if scaled else x).double(), wt[:, :, 0, 0].double() * 0.7)
+    if scaled:
+        ref = ref * s_out.view(n, cout, 1, 1).double() + bias.view(1, cout, 1, 1).double()
+    pw = cm.PackedWeight(wt.to(cuda), 1, cout, cin, 1, 0, 0, 0.7)
+    for mode in ('fp32', 'fp16x3'):
+        precision(mode)
+        out = cm.conv_forward(x.to(cuda), pw, n, 1, cin, cout, 1, 1, 0, 0, in_scale=None if s_in is None else s_in.to(cuda),
+                              out_scale=None if s_out is None else s_out.to(cuda), bias=None if bias is None else bias.to(cuda))
+        assert cm.last_conv_kernel() == 'conv1x1_fewin', cm.last_conv_kernel()
+        err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, err
