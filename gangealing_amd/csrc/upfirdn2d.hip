@@ -416,6 +416,114 @@ __global__ __launch_bounds__(256) void upfirdn2d_direct(
   }
 }
 
+// 4x4 FIR, up 1, down 2 as a row walk (the ResBlock skip's blur evaluated only where its 1x1 / stride-2 convolution
+// reads, networks.py:455-480 + 508-515).  upfirdn2d_direct<.., 1> issues 16 four-byte loads per output (1.3 TB/s on
+// 64 -> 64 channels @128^2); here a wave owns a strip of output rows, a lane one output column (narrow images: several
+// planes side by side in a wave), and the 4 x 4 input window slides down two rows per output row: two 8-byte loads
+// per new input row = four load instructions per output.  Rows / columns outside the image are exact zeros (buffer
+// range check for the rows, a select for the columns); the sum runs in the order of the generic kernel (rows outer,
+// columns inner), so the results are bit-identical to it.
+constexpr int D2_ROWS = 8;                    // output rows per wave
+__global__ __launch_bounds__(256) void upfirdn2d_fir4_down2_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                                   const float* __restrict__ kernel, int major, int in_h,
+                                                                   int in_w, int out_h, int out_w, int pad_x0, int pad_y0,
+                                                                   int w2_log2, int strips, int cchunks,
+                                                                   long long nunits) {
+  const int lane = threadIdx.x & 63;
+  const long long unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= nunits) return;                               // whole wave leaves (no barriers in this kernel)
+  // unit -> (plane group, row strip, column chunk); lane -> (plane of the group, column)
+  const int cc = (int)(unit % cchunks);
+  const long long u2 = unit / cchunks;
+  const int strip = (int)(u2 % strips);
+  const int pg = (int)(u2 / strips);
+  const int w2 = 1 << w2_log2;                              // columns per plane inside a wave (<= 64)
+  const int ppw = 64 >> w2_log2;                            // planes per wave
+  const int plane = pg * ppw + (lane >> w2_log2);
+  const int ox = cc * 64 + (lane & (w2 - 1));
+  const bool lane_ok = plane < major && ox < out_w;
+  float kv[4][4];                                           // flipped taps (upfirdn2d_kernel.cu:149-206)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) kv[a][b] = kernel[(3 - a) * 4 + (3 - b)];
+  const int ix0 = 2 * ox - pad_x0;
+  bool cok[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) cok[b] = lane_ok && (unsigned)(ix0 + b) < (unsigned)in_w;
+  const __amdgpu_buffer_rsrc_t rs = gg::uniform_rsrc(in, (int)((long long)major * in_h * in_w * 4));
+  // The row's four columns ix0 .. ix0 + 3 as 8-byte loads that start on EVEN columns (ix0's parity is that of the
+  // padding: uniform).  A pair that starts left of the image is wholly outside it (columns -2, -1), so an offset that
+  // wraps below zero - out of range as unsigned, reads 0 - only ever stands for zeros; everything else is selected by
+  // the per-column validity.  Odd ix0: scalar, pair, scalar.
+  const bool odd = (pad_x0 & 1) != 0;
+  const long long pbase = (long long)plane * in_h * in_w + ix0;         // element index of (row 0, column ix0)
+  const int y_begin = strip * D2_ROWS;
+  int y_end = y_begin + D2_ROWS;
+  if (y_end > out_h) y_end = out_h;
+  float win[4][4];
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  auto load_row = [&](float (&r)[4], int iy) {
+    if ((unsigned)iy < (unsigned)in_h) {                    // uniform: rows are per wave
+      const long long e = pbase + (long long)iy * in_w;
+      float c0, c1, c2, c3;
+      if (odd) {
+        const unsigned v0 = cok[0] ? (unsigned)(e * 4) : gg::kOobOffset;
+        const unsigned v1 = lane_ok ? (unsigned)((e + 1) * 4) : gg::kOobOffset;
+        const unsigned v3 = cok[3] ? (unsigned)((e + 3) * 4) : gg::kOobOffset;
+        c0 = gg::buffer_load_f32(rs, v0, 0);
+        const f2 mid = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)v1, 0, 0));
+        c3 = gg::buffer_load_f32(rs, v3, 0);
+        c1 = mid[0]; c2 = mid[1];
+      } else {
+        // (each pair has its own lane offset: the range check sees the lane offset only, and with ix0 = -2 the first
+        // pair lies in front of the row while the second one is columns 0, 1)
+        const unsigned v0 = lane_ok ? (unsigned)(e * 4) : gg::kOobOffset;
+        const unsigned v2 = lane_ok ? (unsigned)((e + 2) * 4) : gg::kOobOffset;
+        const f2 lo = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)v0, 0, 0));
+        const f2 hi = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)v2, 0, 0));
+        c0 = lo[0]; c1 = lo[1]; c2 = hi[0]; c3 = hi[1];
+      }
+      r[0] = cok[0] ? c0 : 0.f; r[1] = cok[1] ? c1 : 0.f; r[2] = cok[2] ? c2 : 0.f; r[3] = cok[3] ? c3 : 0.f;
+    } else {
+      r[0] = r[1] = r[2] = r[3] = 0.f;
+    }
+  };
+  const int iy_first = 2 * y_begin - pad_y0;
+  load_row(win[0], iy_first);
+  load_row(win[1], iy_first + 1);
+  for (int oy = y_begin; oy < y_end; ++oy) {
+    const int iy0 = 2 * oy - pad_y0;
+    load_row(win[2], iy0 + 2);
+    load_row(win[3], iy0 + 3);
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc += win[a][b] * kv[a][b];
+    if (lane_ok) out[((size_t)plane * out_h + oy) * out_w + ox] = acc;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { win[0][b] = win[2][b]; win[1][b] = win[3][b]; }
+  }
+}
+
+// true when the row-walk kernel took the launch
+bool launch_fir4_down2(float* out, const float* in, const float* kernel, int major, int in_h, int in_w, int out_h,
+                       int out_w, int pad_x0, int pad_y0, hipStream_t st) {
+  static const bool off = getenv("GG_NO_FIR4_DOWN2") != nullptr;          // measurement switch
+  if (off || (long long)major * in_h * in_w * 4 >= (1LL << 31) || out_w < 4) return false;
+  int w2_log2 = 0;
+  while ((1 << w2_log2) < out_w && w2_log2 < 6) ++w2_log2;
+  const int ppw = 64 >> w2_log2;
+  const int cchunks = (out_w + 63) / 64, strips = (out_h + D2_ROWS - 1) / D2_ROWS;
+  const long long nunits = (long long)((major + ppw - 1) / ppw) * strips * cchunks;
+  const long long blocks = (nunits + 3) / 4;
+  if (blocks >= (1LL << 31)) return false;
+  upfirdn2d_fir4_down2_kernel<<<(unsigned)blocks, 256, 0, st>>>(out, in, kernel, major, in_h, in_w, out_h, out_w, pad_x0,
+                                                               pad_y0, w2_log2, strips, cchunks, nunits);
+  return true;
+}
+
 // grid: x covers one plane's outputs, y strides over planes (<= 64 planes per thread)
 template <typename T, typename K>
 int launch_direct(T* out, const T* in, const K* kernel, const T* addend, int major, int in_h, int in_w, int out_h,
@@ -431,6 +539,10 @@ int launch_direct(T* out, const T* in, const K* kernel, const T* addend, int maj
   if (gy > 65535u) gy = 65535u;
   const dim3 grid(gx, gy);
   const bool fir4 = kh == 4 && kw == 4 && up_x == up_y && down_x == down_y;
+  if (fir4 && up_x == 1 && down_x == 2 && !addend && sizeof(T) == 4 && sizeof(K) == 4 &&
+      launch_fir4_down2(reinterpret_cast<float*>(out), reinterpret_cast<const float*>(in),
+                        reinterpret_cast<const float*>(kernel), major, in_h, in_w, out_h, out_w, pad_x0, pad_y0, st))
+    return gg::launch_status("upfirdn2d_fir4_down2");
   if (fir4 && up_x == 1 && down_x == 2)
     upfirdn2d_direct<T, K, 1><<<grid, 256, 0, st>>>(out, in, kernel, major, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y,
                                                      down_x, down_y, pad_x0, pad_y0, addend);

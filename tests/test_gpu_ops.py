@@ -104,7 +104,11 @@ def test_upfirdn2d_resampling_paths_vs_oracle(cuda):
     for (shape, up, down, pad) in [((2, 3, 16, 16), 2, 1, (2, 1)), ((1, 2, 17, 13), 2, 1, (2, 1)), ((1, 1, 1, 1), 2, 1, (2, 1)),
                                    ((2, 5, 32, 32), 1, 2, (1, 1)), ((1, 3, 33, 21), 1, 2, (1, 1)), ((1, 2, 15, 64), 1, 2, (2, 2)),
                                    ((1, 2, 16, 16), 1, 2, (0, 0)), ((3, 700, 8, 8), 1, 2, (1, 1)), ((3, 700, 4, 4), 2, 1, (2, 1)),
-                                   ((1, 2, 9, 11), 2, 2, (2, 1))]:
+                                   ((1, 2, 9, 11), 2, 2, (2, 1)),
+                                   # row-walk kernel of the 4x4 / down-2 FIR (upfirdn2d_fir4_down2_kernel): even and odd
+                                   # left pads, pads beyond the taps' reach, a C2-sized plane set, tiny planes
+                                   ((2, 5, 64, 64), 1, 2, (2, 1)), ((1, 3, 31, 130), 1, 2, (3, 2)), ((4, 64, 128, 128), 1, 2, (1, 1)),
+                                   ((1, 2, 7, 9), 1, 2, (1, 1)), ((3, 9, 20, 12), 1, 2, (4, 4)), ((2, 130, 32, 32), 1, 2, (1, 1))]:
         x = rs.randn(*shape).astype(np.float32)
         kk = k * (up * up)
         out = upfirdn2d(T(x, cuda), T(kk, cuda), up=up, down=down, pad=pad)
