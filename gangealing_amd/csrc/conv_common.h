@@ -261,6 +261,6 @@ void s2_wgrad_rows_launch(const WgradArgs& a, int limbs, bool narrow, int segs, 
 // block, 128 output channels; a.tiles_co / tiles_pix / nslabs (16-channel chunks) / slabs_per_split / part set by the caller)
 constexpr int kS2MaxCin = 1024;            // the image-group's in_scale vector is kept in LDS
 bool s2_patch_serves(const ConvArgs& a, int tpix);
-void s2_patch_launch(const ConvArgs& a, int tpix, dim3 grid, hipStream_t st);
+void s2_patch_launch(const ConvArgs& a, int stride, int tpix, dim3 grid, hipStream_t st);
 
 }  // namespace gg_conv

@@ -2691,7 +2691,7 @@ static int s2_patch_tpix() {
   static const int v = env_int("GG_S2_PATCH", 1);
   return v;
 }
-int launch_conv_s2_patch(ConvArgs a, int tpix, hipStream_t st) {
+int launch_conv_s2_patch(ConvArgs a, int stride, int tpix, hipStream_t st) {
   a.mh = a.oh; a.mw = a.ow;
   a.tile_pixels = tpix;
   a.tiles_co = (a.cout_g + 127) / 128;
@@ -2713,8 +2713,8 @@ int launch_conv_s2_patch(ConvArgs a, int tpix, hipStream_t st) {
     if (int rc = splitk_prepare(a, a.splitk, false, st)) return rc;
   }
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
-  NOTE_KERNEL("conv3x3s2_patch<limbs2,%dpx,%s>", tpix, a.f16 ? "f16" : "bf16");
-  s2_patch_launch(a, tpix, grid, st);
+  NOTE_KERNEL("conv3x3s%d_patch16<limbs2,%dpx,%s>", stride, tpix, a.f16 ? "f16" : "bf16");
+  s2_patch_launch(a, stride, tpix, grid, st);
   const int rc = gg::launch_status("conv3x3s2_patch");
   if (rc || a.splitk <= 1) return rc;
   return splitk_reduce(a, a.splitk, st);                    // + out_scale / bias / fused activation
@@ -3053,6 +3053,12 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     const long long tiles256 = (long long)a.batch * a.oh * a.ow / 256 * ((a.cout_g + 127) / 128) * a.groups;
     if (limbs <= 2 && tiles256 >= 2 * gg::kNumCu && a.cin_g > patch256_min_cin() && patch_geometry(a, 256, tw_log2))
       return launch_conv_patch(a, limbs, tw_log2, 256, st);
+    // GG_C16_S1 (measurement switch): the 16-channel-chunk tile of conv_s2_patch.hip in its stride-1 form instead of the
+    // 128-pixel variant of conv3x3_patch_kernel, for layers with more than 64 output channels
+    static const int c16_s1 = env_int("GG_C16_S1", 0);
+    if (c16_s1 && limbs == 2 && a.cout_g > 64 && s2_patch_serves(a, 128) &&
+        (!a.act || (!a.act_noise || (reinterpret_cast<uintptr_t>(a.act_noise) & 15) == 0)))
+      return launch_conv_s2_patch(a, 1, 128, st);
     if (patch_geometry(a, 128, tw_log2, limbs)) return launch_conv_patch(a, limbs, tw_log2, 128, st);
   }
   if (limbs == 2 && KS == 3 && mode == 0 && stride == 2 && pad == 0 && s2_patch_tpix() > 0 &&
@@ -3066,7 +3072,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     if (s2_patch_tpix() == 1)
       tpix = ((tiles256 >= gg::kNumCu && a.cin_g >= 256) || (tiles256 >= 2 * gg::kNumCu && a.cin_g >= 128)) ? 256 : 128;
     if (tpix == 256 && !s2_patch_serves(a, 256)) tpix = 128;
-    if (s2_patch_serves(a, tpix)) return launch_conv_s2_patch(a, tpix, st);
+    if (s2_patch_serves(a, tpix)) return launch_conv_s2_patch(a, 2, tpix, st);
   }
   if (a.act) {            // no other kernel carries the activation in its epilogue
     ConvArgs plain = a;

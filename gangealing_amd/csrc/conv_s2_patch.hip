@@ -32,16 +32,20 @@ using namespace gg_conv;
 constexpr int S2_CH = 16;             // input channels per chunk = K of one MFMA step
 constexpr int S2_RB = 32;             // bytes per LDS row
 constexpr int S2_TW = 32;             // output tile width
-constexpr int S2_PLW = S2_TW + 1;     // row pitch of a column-parity plane (even plane: 33 columns, odd: 32)
-constexpr int S2_PC = 2 * S2_TW + 1;  // patch columns
 
-template <bool IN_SCALE, int TPIX, bool F16>
-__global__ __launch_bounds__(TPIX * 2, TPIX == 128 ? 2 : 1) void conv3x3s2_patch_kernel(const ConvArgs a) {
+// S = stride: 2 = the stride-2 / pad-0 correlation described above; 1 = the same tile for 3x3 / stride 1 / pad 1 (one
+// plane, a (TH + 2) x 34 patch: 1.59 input pixels per output where the 2 x 64 tile of conv3x3_patch_kernel's 128-pixel
+// variant stages 2.06, 42 KB of LDS: three blocks per CU) - see launch_conv_s2_patch's notes for where it is used.
+template <int S, bool IN_SCALE, int TPIX, bool F16>
+__global__ __launch_bounds__(TPIX * 2, TPIX == 128 ? (S == 1 ? 3 : 2) : 1) void conv3x3s2_patch_kernel(const ConvArgs a) {
   using L = Limb<F16>;
   constexpr int LIMBS = 2, MI = 2, NJ = 2, TCO = 128, NT = TPIX * 2, PWAVES = TPIX / 64, TPI = 3;
-  constexpr int TH = TPIX / S2_TW, PH = 2 * TH + 1;
+  constexpr int S2_PLW = S == 2 ? S2_TW + 1 : S2_TW + 2;     // row pitch of a plane (stride 2: even plane 33 columns, odd 32)
+  constexpr int S2_PC = S == 2 ? 2 * S2_TW + 1 : S2_TW + 2;  // patch columns
+  constexpr int PAD = S == 2 ? 0 : 1;
+  constexpr int TH = TPIX / S2_TW, PH = S == 2 ? 2 * TH + 1 : TH + 2;
   constexpr int NPIX = PH * S2_PC, NITEMS = 2 * NPIX, ROUNDS = (NITEMS + NT - 1) / NT;
-  constexpr int PLROWS = PH * S2_PLW, PLANE_BYTES = PLROWS * S2_RB, LIMB_BYTES = 2 * PLANE_BYTES;
+  constexpr int PLROWS = PH * S2_PLW, PLANE_BYTES = PLROWS * S2_RB, LIMB_BYTES = S * PLANE_BYTES;
   constexpr int W_BYTES = TCO * S2_RB;                                   // one (tap, limb) weight slab
   constexpr int MAIN_BYTES = LIMBS * LIMB_BYTES + TPI * LIMBS * W_BYTES;
   constexpr int STAGE_BYTES = (NT / 64) * 32 * 64 * 4, EPI_BYTES = (3 * TCO + TPIX) * 4;
@@ -82,10 +86,10 @@ __global__ __launch_bounds__(TPIX * 2, TPIX == 128 ? 2 : 1) void conv3x3s2_patch
     const int half = item >= NPIX ? 1 : 0;
     const int pix = item - half * NPIX;
     const int pr = pix / S2_PC, pc = pix - pr * S2_PC;
-    const int iy = 2 * y0 + pr, ix = 2 * x0 + pc;
-    const bool inb = ok & (iy < a.h) & (ix < a.w);
+    const int iy = S * y0 + pr - PAD, ix = S * x0 + pc - PAD;
+    const bool inb = ok & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
     gvo[r] = inb ? (unsigned)(half * 8 * hw + iy * a.w + ix) * 4u : kOobOffset;
-    const int plane = pc & 1, row = pr * S2_PLW + (pc >> 1);
+    const int plane = S == 2 ? (pc & 1) : 0, row = pr * S2_PLW + (S == 2 ? (pc >> 1) : pc);
     lo[r] = ok ? (plane * PLROWS + row) * S2_RB + (((half ^ (row >> 3) ^ plane) & 1) << 4) : -1;
     halfmask |= (unsigned)half << r;
   }
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(TPIX * 2, TPIX == 128 ? 2 : 1) void conv3x3s2_patch
   // lane's output pixel of sub-tile j = (row wpix * NJ + j, column l31): plane row of its (ky = 0, kx = 0) input pixel
   int rbase[NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) rbase[j] = 2 * (wpix * NJ + j) * S2_PLW + l31;
+  for (int j = 0; j < NJ; ++j) rbase[j] = S * (wpix * NJ + j) * S2_PLW + l31;
   const int abase = ((wco * MI) * 32 + l31) * S2_RB + (((kh ^ (l31 >> 3)) & 1) << 4);
 
   auto rescale_acc = [&](float f) {
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(TPIX * 2, TPIX == 128 ? 2 : 1) void conv3x3s2_patch
   };
   // one tap (ky = iv, kx = u) of the chunk in LDS
   auto tap = [&](int iv, int u) {
-    const int plane = u & 1, dcol = u >> 1;
+    const int plane = S == 2 ? (u & 1) : 0, dcol = S == 2 ? (u >> 1) : u;       // kx = u
     bf16x8 fa[LIMBS][MI], fb[LIMBS][NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -383,16 +387,19 @@ bool s2_patch_serves(const ConvArgs& a, int tpix) {
          (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 && (!a.in_scale || (reinterpret_cast<uintptr_t>(a.in_scale) & 3) == 0);
 }
 
-#define S2_LAUNCH(SC, TP, F) conv3x3s2_patch_kernel<SC, TP, F><<<grid, TP * 2, 0, st>>>(a)
-#define S2_LAUNCH_F(SC, TP) do { if (a.f16) S2_LAUNCH(SC, TP, true); else S2_LAUNCH(SC, TP, false); } while (0)
-void s2_patch_launch(const ConvArgs& a, int tpix, dim3 grid, hipStream_t st) {
+#define S2_LAUNCH(ST, SC, TP, F) conv3x3s2_patch_kernel<ST, SC, TP, F><<<grid, TP * 2, 0, st>>>(a)
+#define S2_LAUNCH_F(ST, SC, TP) do { if (a.f16) S2_LAUNCH(ST, SC, TP, true); else S2_LAUNCH(ST, SC, TP, false); } while (0)
+void s2_patch_launch(const ConvArgs& a, int stride, int tpix, dim3 grid, hipStream_t st) {
   const bool sc = a.in_scale != nullptr;
-  if (tpix == 256) {
-    if (sc) S2_LAUNCH_F(true, 256);
-    else S2_LAUNCH_F(false, 256);
+  if (stride == 1) {                     // (128-pixel tiles only)
+    if (sc) S2_LAUNCH_F(1, true, 128);
+    else S2_LAUNCH_F(1, false, 128);
+  } else if (tpix == 256) {
+    if (sc) S2_LAUNCH_F(2, true, 256);
+    else S2_LAUNCH_F(2, false, 256);
   } else {
-    if (sc) S2_LAUNCH_F(true, 128);
-    else S2_LAUNCH_F(false, 128);
+    if (sc) S2_LAUNCH_F(2, true, 128);
+    else S2_LAUNCH_F(2, false, 128);
   }
 }
 

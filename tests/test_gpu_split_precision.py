@@ -385,7 +385,7 @@ def test_s2_patch_grouped_vs_float64(spec, mode_name, tol, cuda, precision):
         err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
         assert err < tol, (grad, err)
         if cm._S2_PATCH and pw.split_ok():
-            assert cm.last_conv_kernel().startswith('conv3x3s2_patch'), cm.last_conv_kernel()
+            assert cm.last_conv_kernel().startswith('conv3x3s2_patch16'), cm.last_conv_kernel()
 
 
 @pytest.mark.parametrize('mode_name,tol', [('bf16x3', 3e-5), ('bf16x6', 1e-5), ('fp16x3', 3e-5)])
