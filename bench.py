@@ -55,7 +55,8 @@ KERNEL_NAME = {
               'algorithmic product)',
     'fp16x3': 'conv3x3_patch_kernel<2, true, 256, 2, false, 1, true> (the bf16x3 tile with binary16 limbs: '
               'v_mfma_f32_32x32x16_f16, 2 limbs per fp32 operand = 3 MFMA products per algorithmic product, weights '
-              'pre-scaled by 2^8 in the pack; gradient convolutions keep bf16 limbs)',
+              'pre-scaled by 2^8 in the pack, a power-of-two block exponent per tile; data gradients the same, weight '
+              'gradients on bf16 limbs)',
     'bf16': 'conv3x3_patch_kernel<1, true, 256, 2, false, 3> (same tile as bf16x3, one bf16 limb per operand = one MFMA '
             'product per algorithmic product, fp32 accumulate; three tap slabs staged per barrier interval)',
     'bf16x6': 'conv3x3_patch_kernel<3, true, 128, 2, false, 1> (same layers, 128co x 128pix tile, 3 bf16 limbs per fp32 operand '
@@ -69,7 +70,8 @@ def kernel_source_hash():
     profile was taken with."""
     import hashlib
     h = hashlib.sha256()
-    for rel in ('gangealing_amd/csrc/conv_mfma.hip', 'gangealing_amd/csrc/gg_common.h', 'include/gangealing_hip.h'):
+    for rel in ('gangealing_amd/csrc/conv_mfma.hip', 'gangealing_amd/csrc/conv_common.h', 'gangealing_amd/csrc/conv_s2_patch.hip',
+                'gangealing_amd/csrc/conv_s2_wgrad.hip', 'gangealing_amd/csrc/gg_common.h', 'include/gangealing_hip.h'):
         with open(os.path.join(REPO, rel), 'rb') as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -96,8 +98,8 @@ def pmc_traffic(precision, workload, batch):
 
 DTYPE = {'fp32': 'f32', 'bf16': 'bf16 (convolution operands rounded to bf16, fp32 accumulate, fp32 activations)', 'bf16x3': 'bf16x3 (fp32 operands split into 2 bf16 limbs, fp32 accumulate)',
          'bf16x6': 'bf16x6 (fp32 operands split into 3 bf16 limbs, fp32 accumulate)',
-         'fp16x3': 'fp16x3 (fp32 operands split into 2 sixteen-bit limbs, 3 MFMA products, fp32 accumulate: binary16 limbs on '
-                   'the forward convolutions, bf16 limbs on the gradient convolutions)'}
+         'fp16x3': 'fp16x3 (fp32 operands split into 2 sixteen-bit limbs, 3 MFMA products, fp32 accumulate: binary16 limbs with '
+                   'a per-tile block exponent on the forward and data-gradient convolutions, bf16 limbs on the weight gradients)'}
 
 
 def _reference_step_fn(wl):
