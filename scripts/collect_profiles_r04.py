@@ -78,6 +78,11 @@ if os.path.exists(os.path.join(O, 'pytest_reference.txt')):
 stamped('conv_layers.txt', 'r04_f_conv_layers.txt', '# scripts/conv_bench.py, fp16x3 (forward launches: binary16 limbs; the wgrad column: bf16 limbs), batch 16, ITERS=20\n')
 if os.path.exists(os.path.join(O, 'conv_layers_bf16x3.txt')):
     stamped('conv_layers_bf16x3.txt', 'r04_f_conv_layers_bf16x3.txt', '# scripts/conv_bench.py "G ", bf16x3, batch 16, ITERS=20\n')
+if os.path.exists(os.path.join(O, 'timeline_c2.txt')):
+    stamped('timeline_c2.txt', 'r04_j_step_timeline_under_rocprofv3.txt',
+            '# one training step of the trace behind r04_a_kernel_stats.txt in launch order (scripts/rocpd_timeline.py): start, '
+            'duration, idle gap before the launch.  Under rocprofv3 the host is slower than the GPU (gaps of 5 - 11 us in front of '
+            'most library launches); untraced, the step is GPU-bound (bench: kernel time ~ step time)\n')
 stamped('determinism.txt', 'r04_determinism.txt',
         '# scripts/check_determinism.py: two runs of two training iterations from the same seeds, compared bit for bit\n')
 stamped('pytest_gpu.txt', 'r04_pytest_gpu.txt', '# python -m pytest tests -m gpu -q (tail)\n')

@@ -47,20 +47,24 @@ sec_bench() {
   $B --steps 30 --warmup 5 --precision bf16 > $O/bench_bf16.json 2>/dev/null
   $B --steps 30 --warmup 5 --batch 5 > $O/bench_fp16x3_batch5.json 2>/dev/null
   $B --steps 30 --warmup 5 --batch 5 --graph > $O/bench_fp16x3_batch5_hipgraph.json 2>/dev/null
-  $B --steps 20 --warmup 5 --batch 32 > $O/bench_fp16x3_batch32.json 2>/dev/null
+  [ -z "${QUICK:-}" ] && $B --steps 20 --warmup 5 --batch 32 > $O/bench_fp16x3_batch32.json 2>/dev/null
   for w in c4 c5; do for b in 4 16; do
     $B --workload $w --batch $b --steps 10 --warmup 3 > $O/bench_${w}_batch$b.json 2>/dev/null
   done; done
-  $B --workload c4 --batch 4 --steps 20 --warmup 5 --graph > $O/bench_c4_batch4_hipgraph.json 2>/dev/null
-  $B --workload c5 --batch 4 --steps 20 --warmup 5 --graph > $O/bench_c5_batch4_hipgraph.json 2>/dev/null
+  if [ -z "${QUICK:-}" ]; then
+    $B --workload c4 --batch 4 --steps 20 --warmup 5 --graph > $O/bench_c4_batch4_hipgraph.json 2>/dev/null
+    $B --workload c5 --batch 4 --steps 20 --warmup 5 --graph > $O/bench_c5_batch4_hipgraph.json 2>/dev/null
+  fi
   head -c 600 $O/bench_fp16x3.json; echo
 }
 sec_layers() {
   python scripts/blur_bench.py > $O/blur_bench.txt 2>&1
-  python scripts/splat_bench.py $O/splat_bench.json > $O/splat_bench.txt 2>&1
-  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $O/trace_splat -o trace --output-format rocpd -- python $R/scripts/splat_bench.py > /dev/null 2>&1 )
-  python scripts/rocpd_stats.py $(find $O/trace_splat -name "*.db" | head -1) 20 > $O/splat_kernel_stats.txt 2>&1
-  rm -rf $O/trace_splat
+  if [ -z "${QUICK:-}" ]; then        # (QUICK=1: the splat2d kernels did not change since the last full session)
+    python scripts/splat_bench.py $O/splat_bench.json > $O/splat_bench.txt 2>&1
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $O/trace_splat -o trace --output-format rocpd -- python $R/scripts/splat_bench.py > /dev/null 2>&1 )
+    python scripts/rocpd_stats.py $(find $O/trace_splat -name "*.db" | head -1) 20 > $O/splat_kernel_stats.txt 2>&1
+    rm -rf $O/trace_splat
+  fi
   GANGEALING_CONV_PRECISION=fp16x3 ITERS=20 python scripts/conv_bench.py > $O/conv_layers.txt 2>&1
   GANGEALING_CONV_PRECISION=bf16x3 ITERS=20 python scripts/conv_bench.py "G " > $O/conv_layers_bf16x3.txt 2>&1
 }
@@ -71,7 +75,8 @@ sec_trace() {
     CMD="python $R/bench.py --workload $w $BATCH --steps 10 --warmup 3 --no-cpu-baseline --no-extras"
     timeout 900 rocprofv3 --kernel-trace -d $O/trace_$w -o trace --output-format rocpd -- $CMD > $O/bench_${w}_under_rocprofv3.json 2>/dev/null
     DB=$(find $O/trace_$w -name "*.db" | head -1)
-    python $R/scripts/rocpd_stats.py $DB 120 > $O/kernel_stats_$w.txt 2>&1
+    python $R/scripts/rocpd_stats.py $DB 130 > $O/kernel_stats_$w.txt 2>&1
+    [ $w = c2 ] && python $R/scripts/rocpd_timeline.py $DB > $O/timeline_c2.txt 2>&1
     rm -rf $O/trace_$w
   done
   cd $R
@@ -85,8 +90,10 @@ sec_pmc() {
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch -- python $R/scripts/pmc_calibrate.py > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/cal_write -- python $R/scripts/pmc_calibrate.py > /dev/null 2>&1
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -- $SHORT > /dev/null 2>&1
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/splat_fetch -- python $R/scripts/splat_bench.py > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/splat_write -- python $R/scripts/splat_bench.py > /dev/null 2>&1
+  if [ -z "${QUICK:-}" ]; then
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/splat_fetch -- python $R/scripts/splat_bench.py > /dev/null 2>&1
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/splat_write -- python $R/scripts/splat_bench.py > /dev/null 2>&1
+  fi
   cd $R
   for d in pmc_fetch pmc_write cal_fetch cal_write pmc_sq; do
     python scripts/pmc_kernel.py $O/$d "" > $O/$d.txt 2>&1
