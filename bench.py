@@ -312,14 +312,14 @@ def _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile)
     return res
 
 
-def measure_reference_dropin(device, wl, precision, steps, warmup):
+def measure_reference_dropin(device, wl, precision, steps, warmup, modules=False):
     """The literal drop-in route: the REFERENCE's own modules (networks.py with its per-sample-weight / groups = N
     modulated convolutions, spatial_transformer.py, warping_heads.py, latent_learner.py, loss.py, lpips.py),
     imported unmodified through gangealing_amd.launch.inject (oracle/pyref.hip_api), run the iteration of
     train.py:106-134 on the HIP operators with torch.optim.Adam and models.accumulate - what a user of
     `python -m gangealing_amd.launch train.py` gets.  None when no reference Python is on this box."""
     from oracle import pyref                        # checker-side loader; the timed modules are the reference's
-    api = pyref.hip_api()
+    api = pyref.hip_api(modules=modules)        # modules=True: `python -m gangealing_amd.launch --modules train.py`
     if api is None:
         return None
     from gangealing_amd.op import conv_mfma
@@ -537,6 +537,21 @@ def main():
                                f'gangealing_amd.launch.inject, torch.optim.Adam, models.accumulate'}
         except Exception as e:                 # noqa: BLE001
             extras['dropin_route'] = {'error': str(e)[:300]}
+        # ... and the launcher's --modules route: the same training glue (the reference's models/__init__.py,
+        # latent_learner.py, torch.optim.Adam, models.accumulate), this package's generator / STN / loss modules bound
+        # under the reference's module names (shared-weight modulated convolutions instead of groups = N)
+        try:
+            with contextlib.redirect_stdout(sys.stderr):
+                r = measure_reference_dropin(device, wl, args.precision, args.steps, args.warmup, modules=True)
+            if r is not None:
+                extras['dropin_modules'] = {
+                    'value': round(r['images'] / r['elapsed'], 3), 'ms_per_step': round(1e3 * r['elapsed'] / args.steps, 3),
+                    'dtype': DTYPE[args.precision], 'launch': 'eager', 'loss': r['loss'],
+                    'modules': 'python -m gangealing_amd.launch --modules: gangealing_amd.stylegan2.networks / '
+                               'spatial_transformers / losses under the reference\'s module names; the reference\'s own '
+                               f'models/__init__.py, latent_learner.py (from {r["source"]}), torch.optim.Adam, models.accumulate'}
+        except Exception as e:                 # noqa: BLE001
+            extras['dropin_modules'] = {'error': str(e)[:300]}
         out['extras'] = extras
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -11,6 +11,15 @@ models/__init__.py:6) resolve to the HIP implementations.  The reference's own o
 CUDA at import time (upfirdn2d.py:12-18, fused_act.py:11-17) and are therefore never imported.
 Optional python dependencies that are absent offline (torchvision, lmdb, tensorboard) are stubbed
 only when missing.
+
+    python -m gangealing_amd.launch --modules /path/to/gangealing/train.py ...      (or GANGEALING_LAUNCH_MODULES=1)
+
+additionally stands this package's MODULES in for the reference's generator, spatial transformer and loss modules
+(models.stylegan2.networks, models.spatial_transformers.{spatial_transformer, warping_heads}, models.losses.{loss,
+lpips}): same class names, constructor arguments and state_dict layouts (reference checkpoints load), but the modulated
+convolutions run in their shared-weight form instead of materialising (N*Cout, Cin, k, k) weights for a grouped
+convolution (networks.py:233-282) - the script, its optimizers, schedules, checkpoints and logging stay the reference's.
+Measured: bench.py `extras.dropin_modules` beside `extras.dropin_route`.
 """
 import importlib
 import os
@@ -27,6 +36,19 @@ OP_MODULES = {
     'utils.splat2d_cuda.functional': 'gangealing_amd.splat2d_cuda.functional',
     'utils.splat2d_cuda.splat': 'gangealing_amd.splat2d_cuda.splat',
     'models.spatial_transformers.antialiased_sampling': 'gangealing_amd.spatial_transformers.antialiased_sampling',
+}
+
+
+# --modules: the reference's model modules -> this package's (a module of ours, or a dict of names taken from one)
+_LOSS_NAMES = ('total_variation_loss', 'flow_identity_loss', 'sample_gan_supervised_pairs', 'gangealing_loss',
+               'assign_fake_images_to_clusters', 'gangealing_cluster_loss')
+_LPIPS_NAMES = ('get_perceptual_loss', 'LPIPS', 'ScalingLayer', 'NetLinLayer', 'vgg16')
+MODEL_MODULES = {
+    'models.stylegan2.networks': 'gangealing_amd.stylegan2.networks',
+    'models.spatial_transformers.spatial_transformer': 'gangealing_amd.spatial_transformers.spatial_transformer',
+    'models.spatial_transformers.warping_heads': 'gangealing_amd.spatial_transformers.warping_heads',
+    'models.losses.loss': ('gangealing_amd.losses', _LOSS_NAMES),
+    'models.losses.lpips': ('gangealing_amd.losses', _LPIPS_NAMES),
 }
 
 
@@ -54,8 +76,9 @@ def stub_missing(names=('torchvision', 'torchvision.models', 'torchvision.datase
                 setattr(sys.modules[parent], leaf, m)
 
 
-def inject(reference_root):
-    """Make `reference_root` importable with the HIP operator modules standing in for its own."""
+def inject(reference_root, modules=False):
+    """Make `reference_root` importable with the HIP operator modules standing in for its own; modules=True: also this
+    package's generator / STN / loss modules for the reference's (see the module docstring)."""
     reference_root = os.path.abspath(reference_root)
     if reference_root not in sys.path:
         sys.path.insert(0, reference_root)
@@ -63,15 +86,30 @@ def inject(reference_root):
     # parent packages must exist as real packages of the reference so that sibling modules import normally
     for target, ours in OP_MODULES.items():
         sys.modules[target] = importlib.import_module(ours)
-    return sorted(OP_MODULES)
+    done = sorted(OP_MODULES)
+    if modules:
+        for target, ours in MODEL_MODULES.items():
+            if isinstance(ours, str):
+                sys.modules[target] = importlib.import_module(ours)
+            else:                                  # one module of ours holds what the reference keeps in two files
+                src = importlib.import_module(ours[0])
+                shim = types.ModuleType(target, f'{target}: names of {ours[0]} (gangealing_amd.launch --modules)')
+                for name in ours[1]:
+                    setattr(shim, name, getattr(src, name))
+                sys.modules[target] = shim
+        done += sorted(MODEL_MODULES)
+    return done
 
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
+    modules = os.environ.get('GANGEALING_LAUNCH_MODULES', '0') not in ('', '0')
+    if argv and argv[0] == '--modules':
+        modules, argv = True, argv[1:]
     if not argv:
         raise SystemExit(__doc__)
     script = os.path.abspath(argv[0])
-    inject(os.path.dirname(script))
+    inject(os.path.dirname(script), modules=modules)
     sys.argv = [script] + list(argv[1:])
     runpy.run_path(script, run_name='__main__')
 

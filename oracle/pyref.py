@@ -70,13 +70,23 @@ def _namespace():
                                  accumulate=accumulate, root=os.path.dirname(os.path.dirname(models.__file__)))
 
 
-def hip_api(root=None):
-    """The reference's modules with the HIP operators standing in for its CUDA extensions (the launcher's route)."""
+def purge_models():
+    """Forget every `models*` module so that the next import resolves them afresh (a process can hold the reference's
+    model modules OR the launcher's --modules bindings, and the two routes are measured one after the other)."""
+    for name in [k for k in sys.modules if k == 'models' or k.startswith('models.')]:
+        del sys.modules[name]
+
+
+def hip_api(root=None, modules=False):
+    """The reference's modules with the HIP operators standing in for its CUDA extensions (the launcher's route);
+    modules=True: the launcher's `--modules` route (this package's generator / STN / loss modules under the reference's
+    names, the reference's own models/__init__.py, latent_learner.py and training glue)."""
     root = root or find_root()
     if root is None:
         return None
     from gangealing_amd import launch
-    launch.inject(root)
+    purge_models()
+    launch.inject(root, modules=modules)
     return _namespace()
 
 

