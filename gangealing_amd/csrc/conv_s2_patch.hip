@@ -145,11 +145,9 @@ __global__ __launch_bounds__(TPIX * 2, TPIX == 128 ? (S == 1 ? 3 : 2) : 1) void 
   BlockExp bexp;
   unsigned pk[ROUNDS][LIMBS][4];       // the chunk's items as packed limbs
   auto split_round = [&](int r) {
-    const bool rescale = F16 && bexp.e != 0;               // uniform: most tiles never leave E = 0
-    const float ps = rescale ? exp2i(-bexp.e) : 1.f;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = rescale ? xa[r][j] * ps : xa[r][j];
+    for (int j = 0; j < 8; ++j) v[j] = xa[r][j];
 #pragma unroll
     for (int l = 0; l < LIMBS; ++l) {
 #pragma unroll
@@ -163,6 +161,13 @@ __global__ __launch_bounds__(TPIX * 2, TPIX == 128 ? (S == 1 ? 3 : 2) : 1) void 
     }
   };
   auto split_patch = [&]() {
+    if (F16 && bexp.e != 0) {                     // a uniform BRANCH (most tiles never leave E = 0): as a select the scaling
+      const float ps = exp2i(-bexp.e);            // cost a multiply and a v_cndmask per element and chunk (SQ_INSTS_VALU: -20 %)
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xa[r][j] *= ps;
+    }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) split_round(r);
   };
