@@ -87,6 +87,12 @@ stamped('determinism.txt', 'r04_determinism.txt',
         '# scripts/check_determinism.py: two runs of two training iterations from the same seeds, compared bit for bit\n')
 stamped('pytest_gpu.txt', 'r04_pytest_gpu.txt', '# python -m pytest tests -m gpu -q (tail)\n')
 
+OLD_SPLAT = ''
+_prev = os.path.join(P, 'r04_b_pmc_hbm_traffic.txt')
+if os.path.exists(_prev):
+    _t = open(_prev).read()
+    _i = _t.find('# splat2d stress')
+    OLD_SPLAT = _t[_i:] if _i >= 0 else ''
 cal = {**rows('cal_fetch.txt'), **rows('cal_write.txt')}
 cal_f = find(cal, 'fused_bias_act_kernel', 'FETCH_SIZE')[1]
 cal_w = find(cal, 'fused_bias_act_kernel', 'WRITE_SIZE')[1]
@@ -101,10 +107,12 @@ with open(os.path.join(P, 'r04_b_pmc_hbm_traffic.txt'), 'w') as f:
     f.write('# kernels of the step:\n')
     for k, (n, v) in sorted({**fetch, **write}.items()):
         f.write(f'{k[0]:70s} {k[1]:28s} n={n:4d} mean={v:16.1f}\n')
-    f.write('# splat2d stress (scripts/splat_bench.py under the same two passes):\n')
-    for name in ('splat_fetch.txt', 'splat_write.txt'):
-        if os.path.exists(os.path.join(O, name)):
-            f.write(open(os.path.join(O, name)).read())
+    fresh = [open(os.path.join(O, name)).read() for name in ('splat_fetch.txt', 'splat_write.txt')
+             if os.path.exists(os.path.join(O, name)) and os.path.getsize(os.path.join(O, name)) > 0]
+    if fresh:
+        f.write('# splat2d stress (scripts/splat_bench.py under the same two passes):\n' + ''.join(fresh))
+    else:          # a QUICK session skipped the (unchanged) splat2d passes: keep the last full session's lines
+        f.write(OLD_SPLAT)
 stamped('pmc_sq.txt', 'r04_c_pmc_sq.txt', '# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- python bench.py '
         '--steps 2 --warmup 1 --no-cpu-baseline --no-extras\n')
 
