@@ -160,42 +160,52 @@ class Strided:
 
 
 def _dev_ptr(t):
+    """-> the tensor's device address as a plain int (ctypes converts it for a c_void_p parameter), or None."""
     if t is None:
         return None
     if isinstance(t, Strided):
-        if t.tensor.device.type != 'cuda':
+        if not t.tensor.is_cuda:
             raise HipLibraryError('gangealing_amd operators run on HIP devices only')
-        return ctypes.c_void_p(t.tensor.data_ptr())
+        return t.tensor.data_ptr()
     if not isinstance(t, torch.Tensor):
         raise TypeError(f'expected a tensor or None, got {type(t)}')
-    if t.device.type != 'cuda':
+    if not t.is_cuda:
         raise HipLibraryError('gangealing_amd operators run on HIP devices only (got a %s tensor); '
                               'the CPU restatement is test infrastructure under oracle/' % t.device.type)
     if not t.is_contiguous():
         raise HipLibraryError('internal error: non-contiguous tensor passed to the C ABI')
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
+
+
+_ENTRY = {}          # name -> (ctypes function, prototype string, argument count): resolved once per entry point
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def _current_stream_handle():
+    # the raw handle of torch's current stream without building a torch.cuda.Stream object per launch (the step issues
+    # ~450 library calls; at per-GPU batch 5 the eager step is bound by the host)
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def call(name, *args, allow=()):
     """Invoke a C-ABI entry point on torch's current HIP stream; the trailing stream argument is
     supplied here.  Tensors are passed as raw device pointers.  Returns the status code; codes other than 0 raise
     unless listed in `allow` (e.g. NOT_SERVED = "shape not served, nothing launched" of the optional fused entry points)."""
-    lib = load()
-    proto = _PROTOS[name]
-    if len(args) != len(proto) - 1:
-        raise TypeError(f'{name}: expected {len(proto) - 1} arguments, got {len(args)}')
-    conv = []
-    for a, c in zip(args, proto):
-        if c == 'p':
-            conv.append(_dev_ptr(a))
-        elif c in 'iq':
-            conv.append(int(a))
-        else:
-            conv.append(float(a))
-    conv.append(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    rc = getattr(lib, name)(*conv)
+    ent = _ENTRY.get(name)
+    if ent is None:
+        lib = load()
+        proto = _PROTOS[name]
+        ent = _ENTRY[name] = (getattr(lib, name), proto, len(proto) - 1)
+    fn, proto, n = ent
+    if len(args) != n:
+        raise TypeError(f'{name}: expected {n} arguments, got {len(args)}')
+    conv = [_dev_ptr(a) if c == 'p' else (int(a) if (c == 'i' or c == 'q') else float(a)) for a, c in zip(args, proto)]
+    conv.append(_current_stream_handle())
+    rc = fn(*conv)
     if rc != 0 and rc not in allow:
-        raise HipLibraryError(f'{name} failed (code {rc}): {lib.gg_last_error().decode()}')
+        raise HipLibraryError(f'{name} failed (code {rc}): {load().gg_last_error().decode()}')
     return rc
 
 
