@@ -367,3 +367,42 @@ def test_committed_bench_line_follows_the_contract():
     assert r['traffic'] is None or r['traffic'] > 0
     c = line['cpu_baseline']
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+
+
+def test_limb_format_rule_follows_the_kernel_that_serves_the_shape():
+    """Which limb format a split-precision launch asks for (gangealing_amd/op/conv_mfma.py::limb_code): binary16 limbs
+    (code 2 | 16) on the patch / transposed / stride-2 patch tiles, where the block exponent is free; bf16 limbs (2) for
+    GRADIENT launches of the shapes the generic re-gathering kernel serves.  The shapes are config C2's."""
+    from gangealing_amd.op import conv_mfma as cm
+    saved = cm.PRECISION
+    # (k, stride, pad, mode, w[, h]) -> served by the generic kernel?
+    table = [((3, 1, 1, 0, 64), False),      # G / STN 3x3 at 64^2: stride-1 patch tile
+             ((3, 1, 1, 0, 16), False),
+             ((3, 1, 1, 0, 8), True),        # below 16^2
+             ((3, 1, 1, 0, 48), True),       # not a power of two
+             ((3, 2, 0, 1, 64), False),      # up-convolution 64 -> 129: transposed tile
+             ((3, 2, 0, 1, 4), False),
+             ((3, 2, 0, 0, 129), not cm._S2_PATCH),     # its data gradient 129 -> 64: stride-2 patch tile
+             ((3, 2, 0, 0, 65), not cm._S2_PATCH),      # 65 -> 32
+             ((3, 2, 0, 0, 129, 9), not cm._S2_PATCH),  # 4 output rows x 64 columns: one tile row
+             ((3, 2, 0, 0, 129, 7), True),              # 3 output rows
+             ((3, 2, 0, 0, 33), True),       # 33 -> 16: narrower than the tile's 32 columns
+             ((1, 1, 0, 0, 64), True),       # 1x1 (ToRGB, ResBlock skips)
+             ((1, 2, 0, 0, 127), True)]
+    for shape, generic in table:
+        assert cm._generic_shape(*shape) is generic, shape
+    try:
+        cm.set_precision('fp16x3')
+        assert cm.limb_code() == 18 and cm.limb_code(grad=True) == (18 if cm._F16_GRAD else 2)
+        assert cm.limb_code(grad=True, generic=True) == (18 if cm._F16_GRAD_GENERIC else 2)
+        assert cm.limb_code(grad=False, generic=True) == 18        # forward launches carry the range guarantee everywhere
+        cm.set_precision('bf16x3')
+        assert cm.limb_code() == 2 and cm.limb_code(grad=True) == 2
+        cm.set_precision('bf16x6')
+        assert cm.limb_code() == 3
+        cm.set_precision('fp32')
+        assert cm.limb_code() == 0
+        with pytest.raises(ValueError):
+            cm.set_precision('fp8')
+    finally:
+        cm.set_precision(saved)
