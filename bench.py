@@ -71,7 +71,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
     for rel in ('gangealing_amd/csrc/conv_mfma.hip', 'gangealing_amd/csrc/conv_common.h', 'gangealing_amd/csrc/conv_s2_patch.hip',
-                'gangealing_amd/csrc/conv_s2_wgrad.hip', 'gangealing_amd/csrc/gg_common.h', 'include/gangealing_hip.h'):
+                'gangealing_amd/csrc/conv_s2_wgrad.hip', 'gangealing_amd/csrc/conv_t_c16.hip', 'gangealing_amd/csrc/gg_common.h', 'include/gangealing_hip.h'):
         with open(os.path.join(REPO, rel), 'rb') as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -120,7 +120,8 @@ def load():
 
 # The library's scratch (partial results of split reductions) comes out of torch's caching allocator: no hipMalloc
 # outside torch's accounting (which fails once torch has reserved most of HBM), and growth while a stream is being
-# captured is legal (torch serves it from the graph's private pool).  The tensors are kept alive here until the library
+# captured is legal (torch serves it from the graph's private pool; the stream's ticket page is the exception: the
+# library refuses to create it inside a capture - `reserve_scratch(0)` or one eager step first).  The tensors are kept alive here until the library
 # hands the pointer back (gg_scratch_release); allocation happens on torch's current stream = the stream `call` launches on.
 _ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_longlong)
 _FREE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
@@ -211,3 +212,10 @@ def call(name, *args, allow=()):
 
 def available():
     return os.path.exists(LIB_PATH)
+
+
+def reserve_scratch(nbytes=0):
+    """Create the current stream's scratch buffer (>= nbytes) and its ticket page now.  The library refuses to create a
+    ticket page inside a hipGraph capture (its clearing memset would only be recorded): call this - or run the step once
+    eagerly - on every stream a capture will launch library kernels on."""
+    return call('gg_scratch_reserve', int(nbytes))

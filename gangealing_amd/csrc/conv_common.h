@@ -263,4 +263,10 @@ constexpr int kS2MaxCin = 1024;            // the image-group's in_scale vector 
 bool s2_patch_serves(const ConvArgs& a, int tpix);
 void s2_patch_launch(const ConvArgs& a, int stride, int tpix, dim3 grid, hipStream_t st);
 
+// conv_t_c16.hip: 3x3 / stride 2 transposed convolution, all four parity classes per pass, 16-channel chunks (two
+// limbs; tco = 64: four waves, two blocks per CU; 128: eight waves); geometry arguments as convT3x3s2_patch_kernel's,
+// a.tiles_co / tiles_pix / nslabs (16-channel chunks) / slabs_per_split / part set by the caller
+bool t16_serves(const ConvArgs& a);
+void t16_launch(const ConvArgs& a, int tco, int tw_log2, int tiles_y, int edge, int pad, dim3 grid, hipStream_t st);
+
 }  // namespace gg_conv

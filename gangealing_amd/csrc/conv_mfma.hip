@@ -2735,6 +2735,52 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   int tiles_y, edge;
   int tq = 128;
   long long tp = tiles_for(tq, tiles_y, edge);
+  // Round 5: the 16-channel-chunk tile of conv_t_c16.hip (64 co x 128 q on four waves, two blocks per CU) wherever the
+  // layer gives every CU its two blocks.  GG_CONVT16: measurement switch (0 = the 32-channel-chunk tiles below as in
+  // round 4 (default until measured), 1 = per launch, 64 / 128 = that tile's 64 / 128 co form on every two-limb launch it can serve).
+  static const int t16_mode = env_int("GG_CONVT16", 0);
+  static const int t16_tw = env_int("GG_CONVT16_TW", 64);             // measurement override: tile width (power of two)
+  if (t16_mode != 0 && limbs == 2 && t16_serves(a)) {
+    const int tco = t16_mode == 128 ? 128 : 64;
+    const int tiles_co = (a.cout_g + tco - 1) / tco;
+    int tw16_log2 = tw_log2;
+    while ((1 << tw16_log2) > t16_tw && tw16_log2 > 2) --tw16_log2;
+    const int tw_keep = tw_log2;
+    tw_log2 = tw16_log2;
+    int ty16, edge16;
+    const long long tp16 = tiles_for(128, ty16, edge16);
+    tw_log2 = tw_keep;
+    const long long blocks16 = tp16 * tiles_co * a.groups;
+    if (t16_mode != 1 || blocks16 >= 2 * gg::kNumCu) {
+      if (tp16 * tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
+      a.tiles_co = tiles_co;
+      a.tiles_pix = (int)tp16;
+      a.nslabs = a.cin_g / 16;                   // 16-channel chunks
+      int splitk = 1;
+      if (blocks16 < split_at_convt()) {
+        splitk = (int)((gg::kNumCu + blocks16 - 1) / blocks16);
+        const int max_split = a.nslabs / 2 > 0 ? a.nslabs / 2 : 1;      // >= 32 channels x 9 taps per split
+        if (splitk > max_split) splitk = max_split;
+        if (splitk < 1) splitk = 1;
+      }
+      a.slabs_per_split = (a.nslabs + splitk - 1) / splitk;
+      a.splitk = (a.nslabs + a.slabs_per_split - 1) / a.slabs_per_split;
+      const bool covered16 = a.oh - 1 <= 2 * a.h + 1 - pad && a.ow - 1 <= 2 * a.w + 1 - pad;
+      if (a.splitk > 1) {
+        if (int rc = splitk_prepare(a, a.splitk, !covered16, st)) return rc;
+      } else if (!covered16) {
+        const size_t out_elems = (size_t)a.batch * a.groups * a.cout_g * a.oh * a.ow;
+        hipError_t e = hipMemsetAsync(a.y, 0, sizeof(float) * out_elems, st);
+        if (e != hipSuccess) return gg::fail((int)e, "conv2d: memset failed");
+      }
+      dim3 grid16((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
+      NOTE_KERNEL("convT3x3s2_c16<limbs2,%dco,128q,%s>", tco, a.f16 ? "f16" : "bf16");
+      t16_launch(a, tco, tw16_log2, ty16, edge16, pad, grid16, st);
+      const int rc = gg::launch_status("convT3x3s2_c16");
+      if (rc || a.splitk <= 1) return rc;
+      return splitk_reduce(a, a.splitk, st);
+    }
+  }
   static const bool force64 = getenv("GG_CONVT_TQ64") != nullptr;     // measurement switch
   if (force64 || limbs > 2 || tp * a.tiles_co * a.groups < 2 * gg::kNumCu) {
     tq = 64;

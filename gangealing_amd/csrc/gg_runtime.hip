@@ -106,13 +106,30 @@ unsigned* tickets(hipStream_t st) {
   ScratchEntry* e = scratch_entry(st);
   if (!e) { fail(-3, "tickets: no current device"); return nullptr; }
   if (e->tickets) return e->tickets;
+  // The page must be ZERO before the first kernel that takes a ticket runs.  Inside a hipGraph capture a memset on the
+  // capturing stream is only recorded, not executed: an eager launch before the first replay would count arrivals on
+  // uninitialised memory (and a replay would clear a page that eager kernels rely on).  So the first use of a stream's
+  // ticket page may not happen inside a capture - only the scratch buffer may grow there (gg_set_allocator).
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+  if (cap != hipStreamCaptureStatusNone) {
+    fail(-4, "tickets: the ticket page of this stream would be created inside a hipGraph capture; call "
+         "gg_scratch_reserve(0, stream) (or run the step once eagerly) on this stream before capturing");
+    return nullptr;
+  }
   hipError_t err;
   void* p = dev_alloc(sizeof(unsigned) * kTickets, &err);
-  // cleared on the stream whose kernels will use them (stream-ordered, and legal inside a capture)
-  if (p) err = hipMemsetAsync(p, 0, sizeof(unsigned) * kTickets, st);
-  if (err != hipSuccess || !p) {
+  if (!p) {
     (void)hipGetLastError();
     fail((int)err, "tickets: allocation failed: %s", hipGetErrorString(err));
+    return nullptr;
+  }
+  // cleared on the stream whose kernels will use them (stream-ordered: executed before any later launch on it)
+  err = hipMemsetAsync(p, 0, sizeof(unsigned) * kTickets, st);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    dev_free(p);
+    fail((int)err, "tickets: clearing the ticket page failed: %s", hipGetErrorString(err));
     return nullptr;
   }
   e->tickets = reinterpret_cast<unsigned*>(p);

@@ -16,9 +16,13 @@
  *   - reproducibility: no floating-point atomics on the training path.  Split reductions (split-K convolutions,
  *     K-split weight gradients, grid-wide sums, scatter-shaped gradients) keep their partial results in a
  *     per-(device, stream) SCRATCH buffer owned by the library and add them in a fixed order, so results are
- *     bitwise identical run to run.  The scratch grows on demand with hipMalloc (a few times, during the first
- *     calls at the largest shapes); hipMalloc is not legal while a stream is being captured into a hipGraph, so run
- *     the step eagerly once before capturing it (or call gg_scratch_reserve).  Exceptions, documented at the entry
+ *     bitwise identical run to run.  The scratch grows on demand (a few times, during the first calls at the
+ *     largest shapes) out of the allocator installed with gg_set_allocator (ABI 3; a caching allocator may serve it
+ *     during a hipGraph capture) or, without one, with hipMalloc - which is not legal while a stream is being
+ *     captured.  The stream's TICKET PAGE (zero-initialised arrival counters of the grid-wide sums) is different: it
+ *     must exist before a capture begins - its clearing memset would only be recorded - so the entry points fail
+ *     (code -4) when its first use falls inside a capture: run the step eagerly once on that stream, or call
+ *     gg_scratch_reserve(0, stream), before capturing.  Exceptions to the reproducibility rule, documented at the entry
  *     points: the IMAGE gradient of the warp (gg_mipmap_warp_bwd_f32 with grad_pyr*, gg_mip_downsample2x_bwd_f32) and
  *     gg_splat_forward_f32 / gg_splat2d_f32 for points whose box exceeds 33 pixels scatter with float atomics -
  *     neither is on the training path.
@@ -36,8 +40,9 @@ extern "C" {
 /* 2: library-owned scratch (gg_scratch_*), gg_lpips_tail_bwd_f32 gained `accumulate`
  * 3: gg_set_allocator; binary16 limbs (format code 18) accepted by the data-gradient entry points */
 int gg_abi_version(void);
-/* Pre-size the scratch buffer of `stream` on the current device to at least `bytes` (and create its ticket page).
- * Optional: the entry points grow it on demand. */
+/* Pre-size the scratch buffer of `stream` on the current device to at least `bytes` and create its ticket page.
+ * Optional for eager use (the entry points grow the scratch on demand); REQUIRED once per stream before a hipGraph
+ * capture whose kernels take tickets, unless the step already ran eagerly on that stream.  Not legal during a capture. */
 int gg_scratch_reserve(long long bytes, void* stream);
 /* Free every scratch buffer (synchronises the device).  Graphs captured earlier must not be replayed afterwards. */
 int gg_scratch_release(void);

@@ -71,7 +71,9 @@ CONFIGS = {
 # BASELINE configs[3] / [4] at the batch bench.py runs them with (4: `bench.py --workload c4|c5`) and at the per-GPU batch
 # of the reference's own recipes on 8 GPUs (scripts/training/celeba.sh:4-6, lsun_cars.sh:4-7: 16): the batch decides
 # which tile variant of each convolution kernel is launched, so these are the variants the bench lines time
-for _base, _batch in (('c4', 4), ('c5', 4), ('c4', 16), ('c5', 8)):     # (c5 at 16 needs > 62 GB on the CPU in float64)
+# (c5 at 16 needs > 62 GB on the CPU in float64: cfg_c5b8 carries float32 + float64, cfg_c5b16 - the batch
+# `bench.py --workload c5 --batch 16` and the recipe run - the reference's float32 run alone)
+for _base, _batch in (('c4', 4), ('c5', 4), ('c4', 16), ('c5', 8), ('c5', 16)):
     CONFIGS[f'{_base}b{_batch}'] = dict(CONFIGS[_base], batch=_batch)
 
 
