@@ -86,7 +86,7 @@ class HipLibraryError(RuntimeError):
 
 def exported_symbols():
     return ['gg_abi_version', 'gg_last_error', 'gg_build_arch', 'gg_scratch_release', 'gg_set_allocator',
-            'gg_last_conv_kernel'] + sorted(_PROTOS)
+            'gg_last_conv_kernel', 'gg_set_tuning'] + sorted(_PROTOS)
 
 
 def load():
@@ -219,3 +219,15 @@ def reserve_scratch(nbytes=0):
     ticket page inside a hipGraph capture (its clearing memset would only be recorded): call this - or run the step once
     eagerly - on every stream a capture will launch library kernels on."""
     return call('gg_scratch_reserve', int(nbytes))
+
+
+TUNING_RESET = -2147483648      # GG_TUNING_RESET: back to the environment's / built-in setting
+
+
+def set_tuning(name, value):
+    """Measurement aid (gg_set_tuning): flip a kernel-selection switch of the convolution dispatcher at run time."""
+    lib = load()
+    lib.gg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    rc = lib.gg_set_tuning(name.encode(), int(value))
+    if rc != 0:
+        raise HipLibraryError(f'gg_set_tuning({name}) failed: {lib.gg_last_error().decode()}')

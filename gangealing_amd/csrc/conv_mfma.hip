@@ -36,6 +36,7 @@
 //   pack_weight*_kernel          GEMM / limb-plane weight layouts (single, or all trainable weights in one launch)
 #include "../../include/gangealing_hip.h"
 #include "gg_common.h"
+#include <string.h>
 #include "conv_common.h"
 
 namespace {
@@ -2565,6 +2566,22 @@ static int env_int(const char* name, int dflt) {
 // 256-pixel (8-wave, one block per CU) tiles halve the weight stream per output, which pays once the reduction is
 // deep; with <= 64 input channels a tile's main loop is two chunks long and two co-resident 128-pixel blocks hide
 // each other's prologue / epilogue instead (64 -> 64 @128^2, batch 16: 80 vs 69 us)
+// switches that tests and A/B sessions flip at run time (gg_set_tuning); initialised from the environment
+enum { kTunConvT16 = 0, kTunConvT16Tw, kTunCount };
+struct Tunable {
+  const char* name;
+  int dflt, value;
+  bool init;
+};
+static Tunable g_tunables[kTunCount] = {{"GG_CONVT16", 0, 0, false}, {"GG_CONVT16_TW", 64, 0, false}};
+static int tuning(int idx) {
+  Tunable& t = g_tunables[idx];
+  if (!t.init) {
+    t.value = env_int(t.name, t.dflt);
+    t.init = true;
+  }
+  return t.value;
+}
 static int patch256_min_cin() {
   static const int v = env_int("GG_PATCH256_MIN_CIN", 64);
   return v;
@@ -2738,8 +2755,8 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   // Round 5: the 16-channel-chunk tile of conv_t_c16.hip (64 co x 128 q on four waves, two blocks per CU) wherever the
   // layer gives every CU its two blocks.  GG_CONVT16: measurement switch (0 = the 32-channel-chunk tiles below as in
   // round 4 (default until measured), 1 = per launch, 64 / 128 = that tile's 64 / 128 co form on every two-limb launch it can serve).
-  static const int t16_mode = env_int("GG_CONVT16", 0);
-  static const int t16_tw = env_int("GG_CONVT16_TW", 64);             // measurement override: tile width (power of two)
+  const int t16_mode = tuning(kTunConvT16);
+  const int t16_tw = tuning(kTunConvT16Tw);                           // measurement override: tile width (power of two)
   if (t16_mode != 0 && limbs == 2 && t16_serves(a)) {
     const int tco = t16_mode == 128 ? 128 : 64;
     const int tiles_co = (a.cout_g + tco - 1) / tco;
@@ -3190,6 +3207,17 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
 }  // namespace
 
 extern "C" const char* gg_last_conv_kernel(void) { return g_last_kernel; }
+
+extern "C" int gg_set_tuning(const char* name, int value) {
+  if (!name) return gg::fail(-2, "set_tuning: null name");
+  for (int i = 0; i < kTunCount; ++i)
+    if (strcmp(name, g_tunables[i].name) == 0) {
+      g_tunables[i].value = value;
+      g_tunables[i].init = value != GG_TUNING_RESET;      // reset: environment / built-in default at the next use
+      return 0;
+    }
+  return gg::fail(-2, "set_tuning: unknown switch %s", name);
+}
 
 extern "C" int gg_conv_pack_weight_f32(float* wmat, const float* w, int groups, int cout_g, int cin_g, int kh,
                                        int kw, int transpose_io, int flip, float scale, void* stream) {

@@ -57,6 +57,12 @@ int gg_set_allocator(gg_alloc_fn alloc, gg_free_fn free_fn);
 /* Name of the kernel instantiation the calling thread's last convolution entry point launched (tile shape, limb format;
  * "" before the first call): measurement aid - bench.py keys its per-kernel HIP-event timing on it. */
 const char* gg_last_conv_kernel(void);
+/* Measurement aid: override a kernel-selection switch of the convolution dispatcher at run time (same names and values
+ * as the GG_* environment switches it reads at first use: "GG_CONVT16" 0 | 1 | 64 | 128, "GG_CONVT16_TW").  Results do
+ * not depend on these switches beyond rounding order; tests use it to run the same shapes through every tile.
+ * value = GG_TUNING_RESET restores the environment's / built-in setting. */
+#define GG_TUNING_RESET (-2147483647 - 1)
+int gg_set_tuning(const char* name, int value);
 const char* gg_last_error(void);
 /* Name of the gfx target the device code was built for ("gfx950"). */
 const char* gg_build_arch(void);
