@@ -47,6 +47,7 @@ METRIC = {'c2': 'train-step images/sec, LSUN-Cats 256^2 STN+StyleGAN2',
 
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks
 MFMA_PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0, 'bf16x6': 2500.0, 'fp16x3': 2500.0}
+# descriptions only (roofline.kernel_detail); roofline.kernel is the name the dispatcher reports at run time
 KERNEL_NAME = {
     'fp32': 'conv_igemm_kernel<3,0,2,2,2,2,*> (3x3 correlation, 128co x 128pix tile, v_mfma_f32_32x32x2_f32)',
     'bf16x3': 'conv3x3_patch_kernel<2, true, 256, 2, false, 1> (3x3 stride-1 modulated conv + fused noise/bias/lrelu epilogue, '
@@ -83,7 +84,7 @@ def pmc_traffic(precision, workload, batch):
     whenever the recorded kernel-source hash differs from the tree's (a profile of another version of the kernel says
     nothing about this one)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             with open(os.path.join(here, 'profiles', name)) as f:
                 rec = json.load(f)
@@ -304,7 +305,9 @@ def _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile)
                          devices=sorted({torch.cuda.current_device()}))
     loss = float(parts['p'])
     assert loss == loss and abs(loss) != float('inf'), 'non-finite loss'
+    reported = sorted({r[3] for r in prof.records}) if (profile and not graphed) else None
     res = dict(elapsed=elapsed, loss=loss, graphed=graphed, prof=prof.summary() if (profile and not graphed) else None,
+               reported=reported,
                images=world * wl['batch'] * steps, dist=dist_info, survey=survey, dominant=dominant,
                dominant_unit=(prof.records[0][4] if (dominant and prof.records) else 'flop'))
     del trainer
@@ -382,6 +385,64 @@ def measure_reference_dropin(device, wl, precision, steps, warmup, modules=False
                 source=os.path.relpath(root, REPO) if root.startswith(REPO) else root)
 
 
+def roofline_of(run, precision, workload, batch):
+    """The `roofline` object of one measured run (measure()): the workload's dominant kernel, timed with HIP events over
+    the timed region on the stream it is launched on.  `kernel` is what the library's dispatcher REPORTED for the timed
+    launches (gg_last_conv_kernel), never a name kept in this file: a dispatch change shows up here."""
+    psum = run['prof']
+    if psum is None:
+        return None
+    if run.get('dominant'):
+        # another workload than C2 at its benchmark batch: the kernel the survey found on top
+        name, unit = run['dominant'], run['dominant_unit']
+        rate = psum['total_flops'] / (psum['total_ms'] * 1e-3) / 1e12 if psum['total_ms'] > 0 else 0.0
+        if unit == 'byte':
+            bound, peak, u = 'hbm', 8.0, 'TB/s'
+        else:
+            bound, peak, u = 'mfma', (MFMA_PEAK_TFLOPS['fp32'] if 'fp32' in name else MFMA_PEAK_TFLOPS[precision]), 'TFLOP/s'
+        roof = {
+            'bound': bound, 'achieved': round(rate, 3), 'peak': peak, 'unit': u, 'frac': round(rate / peak, 4),
+            'traffic': None, 'kernel': name,
+            'note': 'the kernel instantiation with the largest share of this workload\'s GPU time (survey below: two '
+                    'un-timed steps with HIP events around every convolution / FIR launch, keyed by '
+                    'gg_last_conv_kernel); achieved = algorithmic FLOPs (2*N*Cin*Cout*k*k*positions) or algorithmic '
+                    'bytes (4 B per input and output element) of its launches / their HIP-event time over the timed '
+                    'region; peak = dense MFMA peak of the instruction used / 8 TB/s HBM',
+            'launches': psum['launches'],
+            'avg_launch_ms': round(psum['total_ms'] / max(psum['launches'], 1), 4),
+        }
+        if unit != 'byte' and 'fp32' not in name:
+            roof['mfma_products_per_flop'] = MFMA_PRODUCTS[precision]
+            roof['mfma_issue_frac'] = round(rate * MFMA_PRODUCTS[precision] / peak, 4)
+    else:
+        achieved = psum['total_flops'] / (psum['total_ms'] * 1e-3) / 1e12 if psum['total_ms'] > 0 else 0.0
+        peak = MFMA_PEAK_TFLOPS[precision]
+        reported = run.get('reported') or []
+        roof = {
+            'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
+            'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+            'traffic': pmc_traffic(precision, workload, batch),
+            'kernel': ' + '.join(reported) if reported else 'unknown',
+            'kernel_detail': KERNEL_NAME[precision],
+            'mfma_products_per_flop': MFMA_PRODUCTS[precision],
+            'mfma_issue_frac': round(achieved * MFMA_PRODUCTS[precision] / peak, 4),
+            'note': 'kernel = the instantiation(s) the dispatcher reported (gg_last_conv_kernel) for the timed launches: '
+                    'the generator\'s style-scaled 3x3 stride-1 layers that fill the chip; achieved = algorithmic conv '
+                    'FLOPs (2*N*Cin*Cout*9*OH*OW per launch) / HIP-event time over '
+                    'the timed region; peak = dense MFMA peak of the instruction used; mfma_issue_frac = share of '
+                    'that peak the matrix pipe actually executes (split precision issues 3 or 6 MFMA products '
+                    'per algorithmic product); traffic = HBM bytes per launch from the committed rocprofv3 PMC '
+                    'passes (profiles/*pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), null '
+                    'when the run is not the profiled configuration',
+            'launches': psum['launches'],
+            'avg_launch_ms': round(psum['total_ms'] / max(psum['launches'], 1), 4),
+            'avg_launch_gflop': round(psum['total_flops'] / max(psum['launches'], 1) / 1e9, 3),
+        }
+    if run.get('survey'):
+        roof['kernels'] = run['survey']
+    return roof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -430,7 +491,6 @@ def main():
     main_run = measure(device, wl, args.precision, args.graph, args.steps, args.warmup, world, gdist)
 
     if rank == 0:
-        psum = main_run['prof']
         elapsed = main_run['elapsed']
         out = {
             'metric': METRIC.get(args.workload, METRIC['c2']),
@@ -454,50 +514,9 @@ def main():
         }
         if main_run.get('dist'):
             out['distributed'] = main_run['dist']
-        if psum is not None and main_run.get('dominant'):
-            # another workload than C2 at its benchmark batch: the kernel the survey found on top, timed with HIP
-            # events over the timed region
-            name, unit = main_run['dominant'], main_run['dominant_unit']
-            rate = psum['total_flops'] / (psum['total_ms'] * 1e-3) / 1e12 if psum['total_ms'] > 0 else 0.0
-            if unit == 'byte':
-                bound, peak, u = 'hbm', 8.0, 'TB/s'
-            else:
-                bound, peak, u = 'mfma', (MFMA_PEAK_TFLOPS['fp32'] if 'fp32' in name else MFMA_PEAK_TFLOPS[args.precision]), 'TFLOP/s'
-            out['roofline'] = {
-                'bound': bound, 'achieved': round(rate, 3), 'peak': peak, 'unit': u, 'frac': round(rate / peak, 4),
-                'traffic': None, 'kernel': name,
-                'note': 'the kernel instantiation with the largest share of this workload\'s GPU time (survey below: two '
-                        'un-timed steps with HIP events around every convolution / FIR launch, keyed by '
-                        'gg_last_conv_kernel); achieved = algorithmic FLOPs (2*N*Cin*Cout*k*k*positions) or algorithmic '
-                        'bytes (4 B per input and output element) of its launches / their HIP-event time over the timed '
-                        'region; peak = dense MFMA peak of the instruction used / 8 TB/s HBM',
-                'launches': psum['launches'],
-                'avg_launch_ms': round(psum['total_ms'] / max(psum['launches'], 1), 4),
-            }
-            if unit != 'byte' and 'fp32' not in name:
-                out['roofline']['mfma_products_per_flop'] = MFMA_PRODUCTS[args.precision]
-        elif psum is not None:
-            achieved = psum['total_flops'] / (psum['total_ms'] * 1e-3) / 1e12 if psum['total_ms'] > 0 else 0.0
-            peak = MFMA_PEAK_TFLOPS[args.precision]
-            out['roofline'] = {
-                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
-                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                'traffic': pmc_traffic(args.precision, args.workload, wl['batch']),
-                'kernel': KERNEL_NAME[args.precision],
-                'mfma_products_per_flop': MFMA_PRODUCTS[args.precision],
-                'mfma_issue_frac': round(achieved * MFMA_PRODUCTS[args.precision] / peak, 4),
-                'note': 'achieved = algorithmic conv FLOPs (2*N*Cin*Cout*9*OH*OW per launch) / HIP-event time over '
-                        'the timed region; peak = dense MFMA peak of the instruction used; mfma_issue_frac = share of '
-                        'that peak the matrix pipe actually executes (split precision issues 3 or 6 MFMA products '
-                        'per algorithmic product); traffic = HBM bytes per launch from the committed rocprofv3 PMC '
-                        'passes (profiles/*pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), null '
-                        'when the run is not the profiled configuration',
-                'launches': psum['launches'],
-                'avg_launch_ms': round(psum['total_ms'] / max(psum['launches'], 1), 4),
-                'avg_launch_gflop': round(psum['total_flops'] / max(psum['launches'], 1) / 1e9, 3),
-            }
-        if main_run.get('survey') and 'roofline' in out:
-            out['roofline']['kernels'] = main_run['survey']
+        roof = roofline_of(main_run, args.precision, args.workload, wl['batch'])
+        if roof is not None:
+            out['roofline'] = roof
     if world == 1 and rank == 0 and not args.no_extras and not args.graph:
         # further measurements of the same workload in the same process (each with its own trainer); `value` above
         # stays the eager, parity-preserving run whose dominant kernel was timed with HIP events
@@ -521,6 +540,23 @@ def main():
                                                  'conv2d / conv_transpose2d with groups = N')
             except Exception as e:             # noqa: BLE001 - an extra must never take the headline line down
                 extras[name] = {'error': str(e)[:200]}
+        # BASELINE configs[3] / [4] at the per-GPU batch of the reference's own 8-GPU recipes (scripts/training/celeba.sh,
+        # lsun_cars.sh: 16), each with the roofline of ITS dominant kernel (parity at these batches: tests/golden/
+        # cfg_c4b16.npz, cfg_c5b16.npz)
+        if args.workload == 'c2' and not args.batch:
+            for name, key in (('c4_batch16', 'c4'), ('c5_batch16', 'c5')):
+                try:
+                    wlx = dict(WORKLOADS[key], batch=16)
+                    nsteps = min(args.steps, 10)
+                    r = measure(device, wlx, args.precision, False, nsteps, 2, world, gdist, profile=True)
+                    extras[name] = {'metric': METRIC[key], 'value': round(r['images'] / r['elapsed'], 3), 'unit': 'images/sec',
+                                    'ms_per_step': round(1e3 * r['elapsed'] / nsteps, 3), 'steps': nsteps, 'warmup': 2,
+                                    'dtype': DTYPE[args.precision], 'launch': 'eager', 'loss': r['loss'],
+                                    'config': {'workload': f'{key}: gen {wlx["gen_size"]}^2, STN @ {wlx["flow_size"]}^2, per-GPU '
+                                                           f'batch 16, heads {wlx["num_heads"]}, flips {wlx["flips"]}'},
+                                    'roofline': roofline_of(r, args.precision, key, 16)}
+                except Exception as e:         # noqa: BLE001
+                    extras[name] = {'error': str(e)[:300]}
         # the literal drop-in route: the reference's OWN modules on the HIP operators (last: it binds `models.*`)
         try:
             import contextlib

@@ -179,12 +179,22 @@ struct BlockExp {
   int e = 0;          // current exponent
   int set = 0;        // a non-zero chunk has been seen
 };
+// Exponent range: a finite fp32 amax has floor(log2) in [-149, 127], so E = floor(log2 amax) - 6 lies in [-155, 121]; it is
+// clamped to [-120, 121] so that 2^-E and 2^E are normal fp32 numbers (round 4 clamped to +-100: operands above 2^111 =
+// 2.6e33 saturated limb 0).  Below 2^-120 * 2^6 the operand keeps fewer than 22 bits - of values that are denormal or
+// within 2^6 of it.  exp2i saturates outside [-126, 127]: a rescale factor 2^(E_old - E_new) below 2^-126 (a tile whose
+// chunks differ by more than 126 binades) flushes the older, negligible, accumulators to zero instead of producing
+// garbage bits.
 __device__ __forceinline__ int f16_block_exp(float amax) {          // amax > 0, uniform
   if (amax >= 0.125f && amax <= 2048.f) return 0;
   int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127 - 6;
-  return e < -100 ? -100 : (e > 100 ? 100 : e);
+  return e < -120 ? -120 : (e > 121 ? 121 : e);
 }
-__device__ __forceinline__ float exp2i(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
+__device__ __forceinline__ float exp2i(int e) {
+  if (e < -126) return 0.f;
+  if (e > 127) e = 127;
+  return __builtin_bit_cast(float, (unsigned)(127 + e) << 23);
+}
 // -> factor for the accumulators (1 = leave them), updates `b` for a chunk whose largest magnitude is `amax`
 __device__ __forceinline__ float block_exp_update(BlockExp& b, float amax) {
   if (!(amax > 0.f)) return 1.f;

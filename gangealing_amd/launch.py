@@ -61,7 +61,13 @@ class _Stub(types.ModuleType):
 
 def stub_missing(names=('torchvision', 'torchvision.models', 'torchvision.datasets', 'torchvision.datasets.utils',
                         'torchvision.transforms', 'torchvision.utils', 'lmdb', 'tensorboard',
-                        'torch.utils.tensorboard')):
+                        'torch.utils.tensorboard', 'moviepy', 'moviepy.editor', 'plotly', 'plotly.graph_objects',
+                        'plotly.colors', 'ray', 'cv2')):
+    """Packages of the reference's environment that are absent here become empty stand-in modules (any attribute is a
+    do-nothing class), except for the three things the TRAINING script really calls through them, which get working
+    stand-ins (gangealing_amd/_standins.py): the VGG16 feature stack, make_grid and a scalar-logging SummaryWriter.
+    Installed packages are never touched."""
+    from gangealing_amd import _standins
     for name in names:
         if name in sys.modules:
             continue
@@ -74,6 +80,26 @@ def stub_missing(names=('torchvision', 'torchvision.models', 'torchvision.datase
             parent, _, leaf = name.rpartition('.')
             if isinstance(sys.modules.get(parent), _Stub):        # `from torchvision import models` must find the stub
                 setattr(sys.modules[parent], leaf, m)
+            if name == 'torchvision.models':
+                m.vgg16 = _standins.vgg16
+            elif name == 'torchvision.utils':
+                m.make_grid, m.save_image = _standins.make_grid, _standins.save_image
+            elif name == 'torch.utils.tensorboard':
+                m.SummaryWriter = _standins.SummaryWriter
+
+
+def _reference_module(root, target):
+    """The reference's OWN module `target` (e.g. models.losses.lpips), loaded from its file under a private name - what a
+    `--modules` shim falls back to for names this package does not provide."""
+    import importlib.util
+    key = '_gangealing_reference.' + target
+    if key not in sys.modules:
+        path = os.path.join(root, *target.split('.')) + '.py'
+        spec = importlib.util.spec_from_file_location(key, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[key] = mod
+        spec.loader.exec_module(mod)
+    return sys.modules[key]
 
 
 def inject(reference_root, modules=False):
@@ -96,6 +122,9 @@ def inject(reference_root, modules=False):
                 shim = types.ModuleType(target, f'{target}: names of {ours[0]} (gangealing_amd.launch --modules)')
                 for name in ours[1]:
                     setattr(shim, name, getattr(src, name))
+                # everything else the reference's file exposes (normalize_tensor, spatial_average, upsample, the
+                # backbones module `pn`, ...) resolves to the reference's own code, loaded on first use
+                shim.__getattr__ = (lambda name, _t=target: getattr(_reference_module(reference_root, _t), name))
                 sys.modules[target] = shim
         done += sorted(MODEL_MODULES)
     return done

@@ -295,6 +295,10 @@ def packed(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0):
             ent = reg.entries[key] = [PackedWeight(weight.detach(), groups, cout_g, cin_g, k, transpose_io, flip, scale),
                                       weight._version]
         return ent[0]
+    if weight.is_inference():
+        # a tensor made under torch.inference_mode (the reference's training visuals, training_vis.py:18-19, compute
+        # `scale * weight * style` there): no version counter to key a cache on, and nothing to keep - pack per call
+        return PackedWeight(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale)
     key = (weight.data_ptr(), weight._version, groups, cout_g, cin_g, k, int(transpose_io), int(flip), float(scale))
     pw = _FROZEN_PACKS.get(key)
     if pw is None:
@@ -371,9 +375,8 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
         if prof is not None:
             # algorithmic FLOPs: a transposed stride-2 convolution does its multiply-adds at the INPUT positions
             pos = oh * ow if mode == 0 else h * w
-            name = 'dominant'
+            name = last_conv_kernel()          # what the library's dispatcher actually launched for this call
             if prof.every:
-                name = last_conv_kernel()
                 prof.names[sig] = name
             prof.end(start, 2.0 * batch * groups * cout_g * cin_g * k * k * pos, name)
     return y

@@ -53,12 +53,15 @@ _FLIPPED = {}
 
 def _flipped(kernel):
     """torch.flip(kernel, [0, 1]), cached per (storage, version): the FIR taps are module buffers."""
+    if kernel.is_inference():               # made under torch.inference_mode: no version counter to key the cache on
+        return torch.flip(kernel, [0, 1]).contiguous()
     key = (kernel.data_ptr(), kernel._version, tuple(kernel.shape), kernel.dtype)
     hit = _FLIPPED.get(key)
     if hit is None:
         if len(_FLIPPED) > 256:
             _FLIPPED.clear()
-        hit = _FLIPPED[key] = (torch.flip(kernel, [0, 1]).contiguous(), kernel)    # keep `kernel` alive: stable address
+        with torch.inference_mode(False):      # a cached tensor must be usable by autograd later (see EqualLinear._scaled)
+            hit = _FLIPPED[key] = (torch.flip(kernel, [0, 1]).contiguous(), kernel)    # keep `kernel` alive: stable address
     return hit[0]
 
 

@@ -137,7 +137,10 @@ class EqualLinear(nn.Module):
             return w * self.scale, (None if b is None else b * self.lr_mul)
         key = (w._version, w.data_ptr(), None if b is None else (b._version, b.data_ptr()))
         if getattr(self, '_scaled_cache', None) is None or self._scaled_cache[0] != key:
-            with torch.no_grad():
+            # (inference_mode(False): a cache first filled under torch.inference_mode - the reference's training visuals
+            # run before the first iteration, training_vis.py:128 - would hold inference tensors, which autograd refuses
+            # to save for backward when the training step uses the cache)
+            with torch.inference_mode(False), torch.no_grad():
                 self._scaled_cache = (key, (w * self.scale).contiguous(), None if b is None else b * self.lr_mul)
         return self._scaled_cache[1], self._scaled_cache[2]
 
@@ -197,7 +200,7 @@ class ModulatedConv2d(nn.Module):
             if w.requires_grad and torch.is_grad_enabled():
                 raise NotImplementedError('the fused modulated convolution treats the generator weights as frozen '
                                           '(train.py:64-65); call requires_grad_(False) on the generator')
-            with torch.no_grad():
+            with torch.inference_mode(False), torch.no_grad():        # (see EqualLinear._scaled)
                 w4 = w[0]
                 k, cin, cout = self.kernel_size, self.in_channel, self.out_channel
                 w4 = w4.detach().clone()          # the packs are built lazily per arithmetic mode
@@ -601,7 +604,7 @@ class Generator(nn.Module):
         banks = self.__dict__.setdefault('_banks', {})           # one bank per first_free (pass 1: 0, pass 2: inject)
         cache = banks.get(first_free)
         if cache is None or cache[0] != key:
-            with torch.no_grad():
+            with torch.inference_mode(False), torch.no_grad():
                 bank = conv_mfma.StyleBank([m.bank_entry(slot) for m, slot in layers], latent.device)
             cache = banks[first_free] = (key, bank)
         lat = latent.detach()

@@ -75,6 +75,13 @@ CONFIGS = {
 # `bench.py --workload c5 --batch 16` and the recipe run - the reference's float32 run alone)
 for _base, _batch in (('c4', 4), ('c5', 4), ('c4', 16), ('c5', 8), ('c5', 16)):
     CONFIGS[f'{_base}b{_batch}'] = dict(CONFIGS[_base], batch=_batch)
+# C5 at the benched per-GPU batch 16: the reference's run needs > 62 GB on the CPU even in float32 (the STN and the
+# perceptual loss see 16 x 4 heads x 2 flips = 128 images), so the reference evaluates the batch in two HALVES of 8
+# samples: same name-keyed latents / noise rows as the batch-16 run (`parent` names the tag, `part` the sample range of
+# the `full_batch`).  No operation of the step couples samples (no batch statistics; every loss term is a mean over
+# samples), so activations of the batch-16 run are the halves' rows and its losses / gradients their averages.
+for _k, _part in enumerate(((0, 8), (8, 16))):
+    CONFIGS[f'c5b16h{_k}'] = dict(CONFIGS['c5'], batch=8, parent='c5b16', full_batch=16, part=_part)
 
 
 def T(a, device, dtype=None):
@@ -103,16 +110,22 @@ class NoiseFeeder:
     """Generator front that replaces `noise=None` by explicit, name-keyed noise images: call k of the step gets the
     list noises[k] (loss.py:21-29 calls the generator twice per step with fresh noise each time)."""
 
-    def __init__(self, generator, tag, device, dtype=None):
+    def __init__(self, generator, tag, device, dtype=None, part=None, full=None):
         self.generator, self.tag, self.device, self.dtype = generator, tag, device, dtype
         self.n_latent = generator.n_latent
         self.calls = 0
         self.outputs = []
+        self.part, self.full = part, full        # samples [lo, hi) of a run of `full` samples (see CONFIGS['c5b16h*'])
 
     def noise_for(self, call, batch):
         res = lambda i: 2 ** ((i + 5) // 2)
-        return [T(det_array(f'{self.tag}.noise{call}.{i}', (batch, 1, res(i), res(i))), self.device, self.dtype)
-                for i in range(self.generator.num_layers)]
+        if self.part is None:
+            return [T(det_array(f'{self.tag}.noise{call}.{i}', (batch, 1, res(i), res(i))), self.device, self.dtype)
+                    for i in range(self.generator.num_layers)]
+        lo, hi = self.part
+        m = batch // (hi - lo)                   # rows per sample in this call (sample-major: 1, or num_heads)
+        return [T(det_array(f'{self.tag}.noise{call}.{i}', (self.full * m, 1, res(i), res(i)))[lo * m:hi * m],
+                  self.device, self.dtype) for i in range(self.generator.num_layers)]
 
     def __call__(self, styles, noise=None, **kw):
         batch = styles[0].shape[0]
@@ -136,13 +149,16 @@ class Tap:
 
 
 @contextlib.contextmanager
-def det_randn(tag, batch, dim_latent, dtype=None):
-    """torch.randn(batch, dim_latent, ...) -> the name-keyed z of this configuration (loss.py:24)."""
+def det_randn(tag, batch, dim_latent, dtype=None, part=None, full=None):
+    """torch.randn(batch, dim_latent, ...) -> the name-keyed z of this configuration (loss.py:24); part / full: rows
+    [lo, hi) of the z of a `full`-sample run."""
     real = torch.randn
 
     def fake(*size, **kw):
         shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
         if shape == (batch, dim_latent):
+            if part is not None:
+                return T(det_array(f'{tag}.z', (full, dim_latent))[part[0]:part[1]], kw.get('device', 'cpu'), dtype)
             return T(det_array(f'{tag}.z', shape), kw.get('device', 'cpu'), dtype)
         return real(*size, **kw)
     torch.randn = fake
@@ -192,13 +208,14 @@ def run_config(api, name, device, backward=True, dtype=None):
     """One loss evaluation + backward of configuration `name` (train.py:106-124).  -> dict of tensors / floats:
     unaligned, target, pred, delta_flow (the regularised one), ploss, tv, identity, total, grads {param name: grad}."""
     cfg = CONFIGS[name]
-    tag = f'cfg.{name}'
+    tag = f"cfg.{cfg.get('parent', name)}"
+    part, full = cfg.get('part'), cfg.get('full_batch')
     gen, stn, ll, loss_fn, resize = build_models(api, cfg, tag, device, dtype)
-    feeder = NoiseFeeder(gen, tag, device, dtype)
+    feeder = NoiseFeeder(gen, tag, device, dtype, part, full)
     stn_tap = Tap(stn)
     resize_tap = Tap(resize)
     clustering = cfg['num_heads'] > 1 or cfg['flips']
-    with det_randn(tag, cfg['batch'], 512, dtype):
+    with det_randn(tag, cfg['batch'], 512, dtype, part, full):
         common = dict(sample_from_full_res=cfg['sample_from_full_res'], padding_mode=cfg['padding_mode'])
         if clustering:
             ploss, delta = api.gangealing_cluster_loss(feeder, stn_tap, ll, loss_fn, resize_tap, cfg['psi'], cfg['batch'],
@@ -260,3 +277,18 @@ def smooth_images(tag, n, size, device='cpu'):
 
 def api_namespace(**kw):
     return types.SimpleNamespace(**kw)
+
+
+def sample_rows(t, cfg, part):
+    """Rows of samples [lo, hi) of a tensor of a `cfg` run whose first dimension is batch (sample), batch x heads
+    (sample-major: latent_learner.py:62-63) or flips x batch x heads (loss.py:45-48)."""
+    lo, hi = part
+    b, h = cfg['batch'], cfg['num_heads']
+    n = t.shape[0]
+    if n == b:
+        return t[lo:hi]
+    if n == b * h:
+        return t.reshape(b, h, *t.shape[1:])[lo:hi].reshape(-1, *t.shape[1:])
+    if n == 2 * b * h:
+        return t.reshape(2, b, h, *t.shape[1:])[:, lo:hi].reshape(-1, *t.shape[1:])
+    raise ValueError(f'first dimension {n} is not batch / batch x heads / 2 x batch x heads of {b}, {h}')
