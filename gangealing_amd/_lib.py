@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GANGEALING_HIP_LIB selects another build of the same library (kernel A/B measurements); the ABI check still applies.
 LIB_PATH = os.environ.get('GANGEALING_HIP_LIB') or os.path.join(_HERE, 'lib', 'libgangealing_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 NOT_SERVED = -1000            # GG_NOT_SERVED of the header
 
 # signature alphabet: p device pointer (tensor or None), i int, q long long, f float, d double, s stream
@@ -54,6 +54,8 @@ _PROTOS = {
     'gg_conv_pack_weights_many': 'pis',
     'gg_conv2d_split_f32': 'pppqipppiiiiiiiiiiiis',
     'gg_modconv3x3_act_f32': 'ppppqipppppffiiiiis',
+    'gg_modconv3x3_act_bits_f32': 'ppppqipppppffiiiiips',
+    'gg_conv3x3_masked_dgrad_bits_f32': 'pppffpqippiiiiis',
     'gg_conv2d_wgrad_f32': 'pppiiiiiiiiifs',
     'gg_conv2d_wgrad_split_f32': 'pppiiiiiiiiifis',
     'gg_conv2d_wgrad_acc_f32': 'pppiiiiiiiiifis',
@@ -86,7 +88,7 @@ class HipLibraryError(RuntimeError):
 
 def exported_symbols():
     return ['gg_abi_version', 'gg_last_error', 'gg_build_arch', 'gg_scratch_release', 'gg_set_allocator',
-            'gg_last_conv_kernel', 'gg_set_tuning'] + sorted(_PROTOS)
+            'gg_last_conv_kernel', 'gg_set_tuning', 'gg_last_sign_bits_written'] + sorted(_PROTOS)
 
 
 def load():

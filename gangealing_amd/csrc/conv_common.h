@@ -35,6 +35,14 @@ struct ConvArgs {
   // element x is multiplied by (mask_ref > 0 ? 1 : mask_alpha) * mask_gain, mask_ref = the layer's saved output
   const float* mask_ref;
   float mask_alpha, mask_gain;
+  // round 5: the same mask from ONE BIT per element instead of the saved fp32 output.  sign_bits (forward launches with
+  // the fused activation): the 3x3 patch tile's epilogue additionally writes bit (co & 31) of word
+  // [(n * H * W + pixel) * bit_words + co / 32] = (stored output > 0), bit_words = cout / 32.  mask_bits (data-gradient
+  // launches): that plane in place of mask_ref - a thread of the patch gather (= one patch pixel, the chunk's 32
+  // channels) reads one word where it read 32 floats.
+  unsigned* sign_bits;
+  const unsigned* mask_bits;
+  int bit_words;
   int act;                        // 1: fused bias / noise / leaky-ReLU epilogue
   const float* act_noise;         // (N, 1, OH, OW) or null = no noise term
   const float* act_noise_w;       // device scalar

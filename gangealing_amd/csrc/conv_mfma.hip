@@ -523,7 +523,10 @@ constexpr int patch_pixels(int tpix) { return (tpix / 64 + 2) * 66; }    // (TH+
 // TPI = tap slabs staged per barrier interval.  With two or three limbs a tap already carries 24 / 48 MFMAs per wave
 // between its two barriers; with ONE limb (plain bf16) it carries 8, and the barrier pair costs about as much as the
 // MFMAs - so the single-limb instantiations stage a whole row of taps (ky fixed, kx = 0..2) per interval.
-template <int LIMBS, bool IN_SCALE, int TPIX, int MI = 2, bool MASK = false, int TPI = (LIMBS == 1 ? 3 : 1),
+// MASK: 0 = plain; 1 = leaky-ReLU gradient mask on the gathered input from the layer's saved fp32 output (a second
+// patch: 32 more loads and prefetch registers per lane and chunk); 2 = the same mask from the 1-bit sign plane the
+// forward epilogue wrote (ConvArgs::mask_bits: one word per lane and chunk)
+template <int LIMBS, bool IN_SCALE, int TPIX, int MI = 2, int MASK = 0, int TPI = (LIMBS == 1 ? 3 : 1),
           bool F16 = false>
 __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvArgs a, int tw_log2) {
   using L = Limb<F16>;
@@ -569,7 +572,12 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   // channel offset` (one address VGPR instead of 32 64-bit pointers), and lanes outside the image use an offset
   // beyond num_records, which the hardware range check turns into 0.0 (the zero padding) without a select
   const __amdgpu_buffer_rsrc_t xr = uniform_rsrc(a.x + (size_t)chan0 * hw, a.cin_g * hw * 4);
-  const __amdgpu_buffer_rsrc_t mr = MASK ? uniform_rsrc(a.mask_ref + (size_t)chan0 * hw, a.cin_g * hw * 4) : xr;
+  const __amdgpu_buffer_rsrc_t mr = MASK == 1 ? uniform_rsrc(a.mask_ref + (size_t)chan0 * hw, a.cin_g * hw * 4) : xr;
+  // sign plane of image pn (groups = 1): word (pixel, chunk) at (pixel * bit_words + chunk) * 4
+  const __amdgpu_buffer_rsrc_t br =
+      MASK == 2 ? uniform_rsrc(reinterpret_cast<const float*>(a.mask_bits) + (size_t)pn * hw * a.bit_words,
+                               hw * a.bit_words * 4)
+                : xr;
   const float mpos = a.mask_gain, mneg = a.mask_gain * a.mask_alpha;
 
   // ---- patch gather: thread -> patch pixel `tid` (all 32 channels of the chunk); for TW = 64 the patch has
@@ -582,14 +590,16 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
     const bool pok = pin & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
     pvoff = pok ? (unsigned)(iy * a.w + ix) * 4u : kOobOffset;
   }
+  const unsigned bvoff = (MASK == 2 && pvoff != kOobOffset) ? pvoff * (unsigned)a.bit_words : kOobOffset;
   const int lpp = NT + (tid & 7), lci = (tid >> 3) & (BKS - 1);     // left-over element (128-pixel tile, TW = 64 only)
   const bool lin = (NT == 256) && lpp < PP;
-  unsigned lvoff;
+  unsigned lvoff, lbvoff = kOobOffset;
   {
     const int pr = lpp / PW, pc = lpp - pr * PW;
     const int iy = y0 + pr - 1, ix = x0 + pc - 1;
     const bool lok = lin & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
     lvoff = lok ? (unsigned)(lci * hw + iy * a.w + ix) * 4u : kOobOffset;
+    if (MASK == 2 && lok) lbvoff = (unsigned)(iy * a.w + ix) * 4u * (unsigned)a.bit_words;
   }
   // ---- weight rows
   const int wrow = (tid >> 1) & (TCO - 1), wpart = tid & 1;
@@ -608,19 +618,25 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   if (chunk1 > a.nslabs) chunk1 = a.nslabs;
 
   float xa[BKS], xl = 0.f;
-  float xm[MASK ? BKS : 1], xml = 0.f;           // saved activation output at the same positions (MASK)
+  float xm[MASK == 1 ? BKS : 1], xml = 0.f;      // saved activation output at the same positions (MASK 1)
+  unsigned mb = 0, mlb = 0;                      // sign words of the lane's pixel / of its left-over element (MASK 2)
   U4 wv[TPI][LIMBS][EPT / 8];
 
+  auto load_bits = [&](int chunk) {
+    mb = __builtin_bit_cast(unsigned, buffer_load_f32(br, bvoff, chunk * 4));
+    if (NT == 256) mlb = __builtin_bit_cast(unsigned, buffer_load_f32(br, lbvoff, chunk * 4));
+  };
   auto load_patch = [&](int chunk) {
     const int cbase = __builtin_amdgcn_readfirstlane(chunk * BKS * hw * 4);
 #pragma unroll
     for (int j = 0; j < BKS; ++j) xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
     xl = buffer_load_f32(xr, lvoff, cbase);
-    if (MASK) {
+    if (MASK == 1) {
 #pragma unroll
-      for (int j = 0; j < BKS; ++j) xm[MASK ? j : 0] = buffer_load_f32(mr, pvoff, cbase + j * hw * 4);
+      for (int j = 0; j < BKS; ++j) xm[MASK == 1 ? j : 0] = buffer_load_f32(mr, pvoff, cbase + j * hw * 4);
       xml = buffer_load_f32(mr, lvoff, cbase);
     }
+    if (MASK == 2) load_bits(chunk);
   };
   // The same loads in slices [j0, j1) (+ the left-over element with `tail`): the pipelined tile issues the next chunk's
   // patch a few channels per tap instead of all 33 loads per lane at the top of the chunk.  A CU keeps only a limited
@@ -632,11 +648,12 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
     for (int j = 0; j < BKS; ++j)
       if (j >= j0 && j < j1) {
         xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
-        if (MASK) xm[MASK ? j : 0] = buffer_load_f32(mr, pvoff, cbase + j * hw * 4);
+        if (MASK == 1) xm[MASK == 1 ? j : 0] = buffer_load_f32(mr, pvoff, cbase + j * hw * 4);
       }
     if (tail) {
       xl = buffer_load_f32(xr, lvoff, cbase);
-      if (MASK) xml = buffer_load_f32(mr, lvoff, cbase);
+      if (MASK == 1) xml = buffer_load_f32(mr, lvoff, cbase);
+      if (MASK == 2) load_bits(chunk);
     }
   };
   // prep_patch: the chunk's registers in their final fp32 form (activation mask, style); with binary16 limbs also
@@ -650,7 +667,8 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
 #pragma unroll
     for (int j = 0; j < BKS; ++j)
       if (j >= j0 && j < j1) {
-        if (MASK) xa[j] *= xm[MASK ? j : 0] > 0.f ? mpos : mneg;
+        if (MASK == 1) xa[j] *= xm[MASK == 1 ? j : 0] > 0.f ? mpos : mneg;
+        if (MASK == 2) xa[j] *= ((mb >> j) & 1u) ? mpos : mneg;
       }
     if (IN_SCALE && pin) {
 #pragma unroll
@@ -663,7 +681,8 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
         if (j >= j0 && j < j1) pmax = fmaxf(pmax, fabsf(xa[j]));
     }
     if (last) {
-      if (MASK) xl *= xml > 0.f ? mpos : mneg;
+      if (MASK == 1) xl *= xml > 0.f ? mpos : mneg;
+      if (MASK == 2) xl *= ((mlb >> lci) & 1u) ? mpos : mneg;
       if (IN_SCALE && lin) xl *= sg[chunk * BKS + lci];
       if (F16) publish_wave_amax(fmaxf(pmax, fabsf(xl)), sAmax, wid, lane);
     }
@@ -818,7 +837,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
       for (int chunk = chunk0; chunk < chunk1; ++chunk) {
         // here: every wave is past the barrier that followed its last LDS fetch of the previous chunk (or at kernel
         // start); registers hold this chunk's patch and its tap-0 slab
-        if (F16 && MASK && chunk > chunk0) {
+        if (F16 && MASK == 1 && chunk > chunk0) {
           prep_patch(chunk);
           __syncthreads();
           amax_next = read_block_amax<NT / 64>(sAmax);
@@ -851,12 +870,13 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
           // tap over taps 6 .. 8: +1 % on this kernel (longer live ranges); at the chunk top behind an extra barrier: +1 %.
           // The MASKED variant (64 prefetch registers: values + mask references) spills with any early form - it does
           // the work at the chunk top, behind one extra barrier per chunk (-0.26 ms per step against the spilling form).
-          if (F16 && more && !MASK && t == 8) prep_patch(chunk + 1);
+          // (MASK 2 - the mask from the sign plane, one word per lane - has the plain tile's registers and takes its form)
+          if (F16 && more && MASK != 1 && t == 8) prep_patch(chunk + 1);
 
           mma(fa0, fb0);
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();
-          if (F16 && !MASK && more && t == 8) amax_next = read_block_amax<NT / 64>(sAmax);   // (lands under the next 12 MFMAs)
+          if (F16 && MASK != 1 && more && t == 8) amax_next = read_block_amax<NT / 64>(sAmax);   // (lands under the next 12 MFMAs)
           if (t < 8) {
             const int t1 = t + 1, ky1 = t1 / 3, kx1 = t1 - ky1 * 3;
             read_frag(fa0, fb0, buf ^ 1, (ky1 * PW + kx1) * ROWB, 0);
@@ -994,6 +1014,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
 #pragma unroll
     for (int it = 0; it < 8; ++it)
       v4s[it] = *reinterpret_cast<const float4*>(stage + (it * 4 + (lane >> 4)) * 64 + (lane & 15) * 4);
+    unsigned sgn[4] = {0u, 0u, 0u, 0u};     // sign bits of the lane's 4 pixels x its 8 channels of this 32-channel block
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int idx = it * 64 + lane;
@@ -1011,10 +1032,32 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
           t = v4.z + anw * nz.z + ab; v4.z = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
           t = v4.w + anw * nz.w + ab; v4.w = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
         }
+        if (a.sign_bits) {       // exactly the test the backward applies to the STORED value (fused_act.py:33-38)
+          sgn[0] |= (v4.x > 0.f ? 1u : 0u) << row;
+          sgn[1] |= (v4.y > 0.f ? 1u : 0u) << row;
+          sgn[2] |= (v4.z > 0.f ? 1u : 0u) << row;
+          sgn[3] |= (v4.w > 0.f ? 1u : 0u) << row;
+        }
         float* dst = a.y + (size_t)(ochan0 + co) * hw + (size_t)oy * a.w + ox;
         if (a.nt_store) __builtin_nontemporal_store(f32x4{v4.x, v4.y, v4.z, v4.w}, reinterpret_cast<f32x4*>(dst));
         else *reinterpret_cast<float4*>(dst) = v4;
       }
+    }
+    if (a.sign_bits) {
+      // the four lanes c4, c4 + 16, c4 + 32, c4 + 48 hold channels == 0, 1, 2, 3 (mod 4) of the same four pixels: OR
+      // them together (two butterfly steps), then lane (row-lane r, c4) stores the finished word of pixel 4 c4 + r
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sgn[e] |= (unsigned)__shfl_xor((int)sgn[e], 16, 64);
+        sgn[e] |= (unsigned)__shfl_xor((int)sgn[e], 32, 64);
+      }
+      const int r = lane >> 4;
+      const unsigned word = r == 0 ? sgn[0] : r == 1 ? sgn[1] : r == 2 ? sgn[2] : sgn[3];
+      const int p = wpix * 64 + (lane & 15) * 4 + r;
+      const int oy = y0 + (p >> tw_log2), ox = x0 + (p & (TW - 1));
+      const int cb = (co0 >> 5) + wco * MI + i;
+      if (cb < a.bit_words)
+        a.sign_bits[((size_t)pn * hw + (size_t)oy * a.w + ox) * a.bit_words + cb] = word;
     }
     wave_lds_sync();                // the staging rows are this wave's own
   }
@@ -2422,6 +2465,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ 
 // Which kernel instantiation the last convolution entry point of this thread launched (gg_last_conv_kernel): what
 // bench.py's per-kernel timing keys on, so that its roofline entries name the kernel that actually ran.
 thread_local char g_last_kernel[96] = "";
+thread_local int g_sign_bits_written = 0;      // the last forward launch wrote the sign plane it was handed (BitArgs)
 #define NOTE_KERNEL(...) snprintf(g_last_kernel, sizeof(g_last_kernel), __VA_ARGS__)
 
 // Scratch for `splits` partial copies of the output of `a`; sets a.part / a.part_stride.  zero: clear it first
@@ -2573,7 +2617,7 @@ struct Tunable {
   int dflt, value;
   bool init;
 };
-static Tunable g_tunables[kTunCount] = {{"GG_CONVT16", 0, 0, false}, {"GG_CONVT16_TW", 64, 0, false}};
+static Tunable g_tunables[kTunCount] = {{"GG_CONVT16", 1, 0, false}, {"GG_CONVT16_TW", 64, 0, false}};
 static int tuning(int idx) {
   Tunable& t = g_tunables[idx];
   if (!t.init) {
@@ -2636,9 +2680,27 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
   }
   dim3 grid((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
   const bool sc = a.in_scale != nullptr;
-  NOTE_KERNEL("conv3x3_patch<limbs%d,%dpx,%dco,%s,%s>", limbs, tpix, narrow ? 64 : 128, a.mask_ref ? "masked" : "plain",
-              a.f16 ? "f16" : "bf16");
-  if (a.mask_ref && a.f16) {     // masked data gradient on binary16 limbs (block exponents: any gradient magnitude)
+  // the sign plane is written by the tile's own activation epilogue: not by split-K launches (their reduce pass applies
+  // the activation)
+  if (a.splitk > 1 || !a.act) a.sign_bits = nullptr;
+  g_sign_bits_written = a.sign_bits ? 1 : 0;
+  NOTE_KERNEL("conv3x3_patch<limbs%d,%dpx,%dco,%s,%s>", limbs, tpix, narrow ? 64 : 128,
+              a.mask_bits ? "bitmasked" : a.mask_ref ? "masked" : "plain", a.f16 ? "f16" : "bf16");
+  if (a.mask_bits) {             // masked data gradient, the mask from the 1-bit sign plane (binary16 limbs)
+    if (narrow && tpix == 256) {
+      if (sc) conv3x3_patch_kernel<2, true, 256, 1, 2, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 256, 1, 2, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+    } else if (narrow) {
+      if (sc) conv3x3_patch_kernel<2, true, 128, 1, 2, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 128, 1, 2, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+    } else if (tpix == 256) {
+      if (sc) conv3x3_patch_kernel<2, true, 256, 2, 2, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 256, 2, 2, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
+    } else {
+      if (sc) conv3x3_patch_kernel<2, true, 128, 2, 2, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+      else conv3x3_patch_kernel<2, false, 128, 2, 2, 1, true><<<grid, 256, 0, st>>>(a, tw_log2);
+    }
+  } else if (a.mask_ref && a.f16) {     // masked data gradient on binary16 limbs (block exponents: any gradient magnitude)
     if (narrow && tpix == 256) {
       if (sc) conv3x3_patch_kernel<2, true, 256, 1, true, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
       else conv3x3_patch_kernel<2, false, 256, 1, true, 1, true><<<grid, 512, 0, st>>>(a, tw_log2);
@@ -2752,9 +2814,9 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
   int tiles_y, edge;
   int tq = 128;
   long long tp = tiles_for(tq, tiles_y, edge);
-  // Round 5: the 16-channel-chunk tile of conv_t_c16.hip (64 co x 128 q on four waves, two blocks per CU) wherever the
-  // layer gives every CU its two blocks.  GG_CONVT16: measurement switch (0 = the 32-channel-chunk tiles below as in
-  // round 4 (default until measured), 1 = per launch, 64 / 128 = that tile's 64 / 128 co form on every two-limb launch it can serve).
+  // Round 5: the 16-channel-chunk tile of conv_t_c16.hip (64 co x 128 q on four waves, two blocks per CU).
+  // GG_CONVT16: measurement switch (0 = the 32-channel-chunk tiles below as in round 4, 1 = per launch (default),
+  // 64 / 128 = that tile's 64 / 128 co form on every two-limb launch it can serve).
   const int t16_mode = tuning(kTunConvT16);
   const int t16_tw = tuning(kTunConvT16Tw);                           // measurement override: tile width (power of two)
   if (t16_mode != 0 && limbs == 2 && t16_serves(a)) {
@@ -2768,7 +2830,9 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
     const long long tp16 = tiles_for(128, ty16, edge16);
     tw_log2 = tw_keep;
     const long long blocks16 = tp16 * tiles_co * a.groups;
-    if (t16_mode != 1 || blocks16 >= 2 * gg::kNumCu) {
+    // per launch (measured, profiles/r05_a_convt16_ab.txt): the new tile everywhere except the 4^2 -> 9^2 layer, whose
+    // 25-position q-grid fills a fifth of a 128-q tile (0.063 -> 0.089 ms); 64-q tiles of the round-4 kernel there
+    if (t16_mode != 1 || a.w >= 8) {
       if (tp16 * tiles_co >= (1LL << 31)) return gg::fail(-2, "conv2d: too many tiles");
       a.tiles_co = tiles_co;
       a.tiles_pix = (int)tp16;
@@ -3095,9 +3159,10 @@ constexpr int kNotFused = GG_NOT_SERVED;      // masked-input request that no ke
 
 template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {
-  if (a.mask_ref) {
+  if (a.mask_ref || a.mask_bits) {
     int tw_log2;
     if (!((limbs == 1 || limbs == 2) && KS == 3 && mode == 0 && stride == 1 && pad == 1)) return kNotFused;
+    if (a.mask_bits && !(a.f16 && limbs == 2 && a.groups == 1)) return kNotFused;
     const long long tiles256 = (long long)a.batch * a.oh * a.ow / 256 * ((a.cout_g + 127) / 128) * a.groups;
     if (tiles256 >= 2 * gg::kNumCu && a.cin_g > patch256_min_cin() && patch_geometry(a, 256, tw_log2))
       return launch_conv_patch(a, limbs, tw_log2, 256, st);
@@ -3207,6 +3272,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
 }  // namespace
 
 extern "C" const char* gg_last_conv_kernel(void) { return g_last_kernel; }
+extern "C" int gg_last_sign_bits_written(void) { return g_sign_bits_written; }
 
 extern "C" int gg_set_tuning(const char* name, int value) {
   if (!name) return gg::fail(-2, "set_tuning: null name");
@@ -3234,6 +3300,13 @@ namespace {
 struct MaskArgs {
   const float* ref = nullptr;
   float alpha = 0.f, gain = 1.f;
+  const unsigned* bits = nullptr;      // the mask as a 1-bit sign plane instead of `ref` (ConvArgs::mask_bits)
+};
+
+// sign plane requested from a forward launch with the fused activation (ConvArgs::sign_bits); whether the kernel that
+// served the launch produced it (only the 3x3 patch tile without split-K does): gg_last_sign_bits_written
+struct BitArgs {
+  unsigned* sign = nullptr;
 };
 
 struct ActArgs {
@@ -3247,7 +3320,9 @@ struct ActArgs {
 int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned short* wsplit, long long wsplit_stride,
                  int limbs, const float* in_scale, const float* out_scale, const float* bias, int batch, int groups,
                  int cin_g, int cout_g, int h, int w, int ksize, int stride, int pad, int mode, int out_h, int out_w,
-                 void* stream, const ActArgs& act = ActArgs(), const MaskArgs& mask = MaskArgs()) {
+                 void* stream, const ActArgs& act = ActArgs(), const MaskArgs& mask = MaskArgs(),
+                 const BitArgs& bits = BitArgs()) {
+  g_sign_bits_written = 0;
   if (batch <= 0 || groups <= 0 || cin_g <= 0 || cout_g <= 0) return 0;
   if (!y || !x || (!wmat && !wsplit) || h <= 0 || w <= 0) return gg::fail(-2, "conv2d: bad arguments");
   if (ksize != 1 && ksize != 3) return gg::fail(-2, "conv2d: kernel size %d not supported (1 or 3)", ksize);
@@ -3274,6 +3349,9 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   a.f16 = f16 ? 1 : 0;
   a.acc_scale = f16 ? 1.f / kF16WeightScale : 1.f;
   a.mask_ref = mask.ref; a.mask_alpha = mask.alpha; a.mask_gain = mask.gain;
+  a.mask_bits = mask.bits;
+  a.sign_bits = (act.on && groups == 1 && cout_g % 32 == 0) ? bits.sign : nullptr;
+  a.bit_words = mask.bits ? cin_g / 32 : cout_g / 32;
   a.act = act.on; a.act_noise = act.noise; a.act_noise_w = act.noise_w; a.act_bias = act.bias;
   a.act_alpha = act.alpha; a.act_gain = act.gain;
   a.batch = batch; a.groups = groups; a.cin_g = cin_g; a.cout_g = cout_g; a.h = h; a.w = w;
@@ -3293,7 +3371,9 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   a.nt_store = nt_env >= 0 ? nt_env
                            : ((long long)batch * groups * cout_g * a.oh * a.ow * 4 > kNtStoreBytes ? 1 : 0);
   hipStream_t st = gg::as_stream(stream);
-  return ksize == 3 ? conv_dispatch<3>(a, stride, pad, mode, st, limbs) : conv_dispatch<1>(a, stride, pad, mode, st, limbs);
+  const int rc = ksize == 3 ? conv_dispatch<3>(a, stride, pad, mode, st, limbs) : conv_dispatch<1>(a, stride, pad, mode, st, limbs);
+  if (rc != 0) g_sign_bits_written = 0;
+  return rc;
 }
 }  // namespace
 
@@ -3318,6 +3398,15 @@ extern "C" int gg_modconv3x3_act_f32(float* y, const float* x, const float* wmat
                                      const float* out_scale, const float* noise, const float* noise_weight,
                                      const float* act_bias, float alpha, float gain, int batch, int cin, int cout,
                                      int h, int w, void* stream) {
+  return gg_modconv3x3_act_bits_f32(y, x, wmat, wsplit, limb_stride, limbs, in_scale, out_scale, noise, noise_weight,
+                                    act_bias, alpha, gain, batch, cin, cout, h, w, nullptr, stream);
+}
+
+extern "C" int gg_modconv3x3_act_bits_f32(float* y, const float* x, const float* wmat, const unsigned short* wsplit,
+                                          long long limb_stride, int limbs, const float* in_scale,
+                                          const float* out_scale, const float* noise, const float* noise_weight,
+                                          const float* act_bias, float alpha, float gain, int batch, int cin,
+                                          int cout, int h, int w, unsigned int* sign_bits, void* stream) {
   if (noise && !noise_weight) return gg::fail(-2, "modconv3x3_act: noise without its weight");
   if ((h * w) % 4 != 0 || (reinterpret_cast<uintptr_t>(noise) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
     return gg::fail(-2, "modconv3x3_act: H*W must be a multiple of 4 and y / noise 16-byte aligned");
@@ -3325,8 +3414,10 @@ extern "C" int gg_modconv3x3_act_f32(float* y, const float* x, const float* wmat
   if (limbs != 0 && !wsplit) return gg::fail(-2, "modconv3x3_act: split weights missing");
   ActArgs act;
   act.on = 1; act.noise = noise; act.noise_w = noise_weight; act.bias = act_bias; act.alpha = alpha; act.gain = gain;
+  BitArgs bits;
+  bits.sign = sign_bits;
   return conv2d_entry(y, x, limbs ? nullptr : wmat, limbs ? wsplit : nullptr, limb_stride, limbs, in_scale, out_scale,
-                      nullptr, batch, 1, cin, cout, h, w, 3, 1, 1, 0, 0, 0, stream, act);
+                      nullptr, batch, 1, cin, cout, h, w, 3, 1, 1, 0, 0, 0, stream, act, MaskArgs(), bits);
 }
 
 extern "C" int gg_conv3x3_masked_dgrad_f32(float* y, const float* x, const float* mask_ref, float alpha, float gain,
@@ -3337,6 +3428,18 @@ extern "C" int gg_conv3x3_masked_dgrad_f32(float* y, const float* x, const float
   if (limbs != 1 && limbs != 2 && limbs != 18) return kNotFused;
   MaskArgs mask;
   mask.ref = mask_ref; mask.alpha = alpha; mask.gain = gain;
+  return conv2d_entry(y, x, nullptr, wsplit, limb_stride, limbs, in_scale, out_scale, nullptr, batch, 1, cin, cout, h,
+                      w, 3, 1, 1, 0, 0, 0, stream, ActArgs(), mask);
+}
+
+extern "C" int gg_conv3x3_masked_dgrad_bits_f32(float* y, const float* x, const unsigned int* mask_bits, float alpha,
+                                                float gain, const unsigned short* wsplit, long long limb_stride,
+                                                int limbs, const float* in_scale, const float* out_scale, int batch,
+                                                int cin, int cout, int h, int w, void* stream) {
+  if (!mask_bits) return gg::fail(-2, "conv3x3_masked_dgrad_bits: mask_bits missing");
+  if (limbs != 18 || cin % 32 != 0) return kNotFused;      // the bit-plane gather exists on the binary16-limb tiles
+  MaskArgs mask;
+  mask.bits = mask_bits; mask.alpha = alpha; mask.gain = gain;
   return conv2d_entry(y, x, nullptr, wsplit, limb_stride, limbs, in_scale, out_scale, nullptr, batch, 1, cin, cout, h,
                       w, 3, 1, 1, 0, 0, 0, stream, ActArgs(), mask);
 }

@@ -318,11 +318,14 @@ def pack_weight(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0)
 
 
 def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in_scale=None, out_scale=None,
-                 bias=None, out_hw=None, act=None, grad=False):
+                 bias=None, out_hw=None, act=None, grad=False, want_sign_bits=False):
     """act = (noise (N,1,OH,OW), noise_weight (1,), act_bias (Cout,), alpha, gain): the StyledConv tail
     lrelu(y + noise_weight*noise + act_bias)*gain fused behind a 3x3/stride-1/pad-1 convolution
     (gg_modconv3x3_act_f32).  grad: this launch is a gradient convolution (data gradient): bf16 limbs in every
-    split-precision mode."""
+    split-precision mode.  want_sign_bits (with act): -> (y, bits): the 1-bit sign plane of y (int32
+    (N, OH*OW, Cout/32), gg_modconv3x3_act_bits_f32) for the layer's masked data gradient, or None when the kernel that
+    served the launch does not write it."""
+    sign_bits = None
     h, w = x.shape[-2], x.shape[-1]
     if mode == 0:
         oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
@@ -362,8 +365,15 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             noise, noise_weight, act_bias, alpha, gain = act       # noise / noise_weight / act_bias may be None
             wbuf, stride_l = wmat.split(code) if use_split else (None, 0)
             wm = None if use_split else (wmat.fp32() if isinstance(wmat, PackedWeight) else wmat)
-            _lib.call('gg_modconv3x3_act_f32', y, x, wm, wbuf, stride_l, code if use_split else 0, in_scale, out_scale,
-                      noise, noise_weight, act_bias, alpha, gain, batch, cin_g, cout_g, h, w)
+            if want_sign_bits and use_split and code == 18 and cout_g % 32 == 0 and 'sign_bits' not in DISABLED:
+                sign_bits = torch.empty((batch, oh * ow, cout_g // 32), dtype=torch.int32, device=x.device)
+                _lib.call('gg_modconv3x3_act_bits_f32', y, x, wm, wbuf, stride_l, code, in_scale, out_scale,
+                          noise, noise_weight, act_bias, alpha, gain, batch, cin_g, cout_g, h, w, sign_bits)
+                if not _lib.load().gg_last_sign_bits_written():
+                    sign_bits = None          # split-K / another kernel served the shape: the backward keeps y
+            else:
+                _lib.call('gg_modconv3x3_act_f32', y, x, wm, wbuf, stride_l, code if use_split else 0, in_scale, out_scale,
+                          noise, noise_weight, act_bias, alpha, gain, batch, cin_g, cout_g, h, w)
         elif use_split:
             wbuf, stride_l = wmat.split(code)
             _lib.call('gg_conv2d_split_f32', y, x, wbuf, stride_l, code, in_scale, out_scale, bias, batch, groups,
@@ -379,7 +389,7 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             if prof.every:
                 prof.names[sig] = name
             prof.end(start, 2.0 * batch * groups * cout_g * cin_g * k * k * pos, name)
-    return y
+    return (y, sign_bits) if want_sign_bits else y
 
 
 # Gradient slots: weight storage address -> (the tensor its gradient is ACCUMULATED into, weak reference to the
@@ -562,8 +572,9 @@ class _Conv3x3BiasAct(Function):
         n, cin = x.shape[0], x.shape[1]
         cout = weight.shape[0]
         wmat = packed(weight, 1, cout, cin, 3, 0, 0, wscale)
-        y = conv_forward(x, wmat, n, 1, cin, cout, 3, 1, 1, 0,
-                         act=(None, None, None if bias is None else bias.contiguous(), alpha, gain))
+        y, ctx.sign_bits = conv_forward(x, wmat, n, 1, cin, cout, 3, 1, 1, 0,
+                                        act=(None, None, None if bias is None else bias.contiguous(), alpha, gain),
+                                        want_sign_bits=bool(ctx.needs_input_grad[0]))
         ctx.save_for_backward(x, weight, y)
         ctx.conf = (alpha, gain, wscale, bias is not None)
         ctx.bias_ref = bias          # (the parameter itself: looked up in the gradient-slot registry in backward)
@@ -580,7 +591,7 @@ class _Conv3x3BiasAct(Function):
         if ctx.needs_input_grad[0] and not ctx.needs_input_grad[1] and not need_db:
             # frozen layer (VGG backbone): only the data gradient is wanted - mask the gradient inside the conv
             wm = packed(weight, 1, cin, cout, 3, 1, 1, wscale)
-            dx = masked_dgrad(dy, y, alpha, gain, wm, n, cout, cin, h, w)
+            dx = masked_dgrad(dy, y, alpha, gain, wm, n, cout, cin, h, w, sign_bits=ctx.sign_bits)
             if dx is not None:
                 return dx, None, None, None, None, None
         slot = None
@@ -592,7 +603,8 @@ class _Conv3x3BiasAct(Function):
             # gradient kernels (and the bias gradient in the wgrad kernel), so the masked gradient is never written
             dx = None
             if ctx.needs_input_grad[0]:
-                dx = masked_dgrad(dy, y, alpha, gain, packed(weight, 1, cin, cout, 3, 1, 1, wscale), n, cout, cin, h, w)
+                dx = masked_dgrad(dy, y, alpha, gain, packed(weight, 1, cin, cout, 3, 1, 1, wscale), n, cout, cin, h, w,
+                                  sign_bits=ctx.sign_bits)
             if dx is not None or not ctx.needs_input_grad[0]:
                 db = torch.zeros(cout, dtype=torch.float32, device=dy.device) if need_db else None
                 dw = slot if slot is not None else torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dy.device)
@@ -727,16 +739,23 @@ class _ModulatedConv(Function):
         return dx, dstyle, None, None, None, None, None, None, None, None
 
 
-def masked_dgrad(dy, y_act, alpha, gain, wmat_bwd, n, cin, cout, h, w, in_scale=None, out_scale=None):
+def masked_dgrad(dy, y_act, alpha, gain, wmat_bwd, n, cin, cout, h, w, in_scale=None, out_scale=None, sign_bits=None):
     """Data gradient of a 3x3 conv + leaky-ReLU layer with the activation's backward applied while the gradient is
     gathered (gg_conv3x3_masked_dgrad_f32): no separate masked-gradient tensor.  `cin` = reduction channels (the
-    layer's output channels), `cout` = the layer's input channels.  None when the shape is not served."""
+    layer's output channels), `cout` = the layer's input channels.  None when the shape is not served.
+    sign_bits: the 1-bit plane the layer's forward wrote (conv_forward(want_sign_bits=True)); the gather then reads one
+    word per pixel and 32 channels instead of the 32 saved outputs - bitwise the same gradient."""
     limbs = limb_code(grad=True)
     if limbs not in (1, 2, 18) or 'mask_dgrad' in DISABLED or not isinstance(wmat_bwd, PackedWeight) or \
             not wmat_bwd.split_ok():
         return None
     wbuf, stride_l = wmat_bwd.split(limbs)
     dx = torch.empty((n, cout, h, w), dtype=torch.float32, device=dy.device)
+    if sign_bits is not None and limbs == 18:
+        rc = _lib.call('gg_conv3x3_masked_dgrad_bits_f32', dx, dy, sign_bits, alpha, gain, wbuf, stride_l, limbs,
+                       in_scale, out_scale, n, cin, cout, h, w, allow=(_lib.NOT_SERVED,))
+        if rc == 0:
+            return dx
     rc = _lib.call('gg_conv3x3_masked_dgrad_f32', dx, dy, y_act, alpha, gain, wbuf, stride_l, limbs, in_scale, out_scale,
                    n, cin, cout, h, w, allow=(_lib.NOT_SERVED,))
     return dx if rc == 0 else None
@@ -758,8 +777,9 @@ class _ModulatedConvAct(Function):
         demod = None
         if demodulate:
             demod = demod_pre if demod_pre is not None else torch.rsqrt((style * style) @ wsq.t() + 1e-8)
-        y = conv_forward(x, wmat_fwd, n, 1, cin, cout, 3, 1, 1, 0, in_scale=style, out_scale=demod,
-                         act=(noise.contiguous(), noise_weight.contiguous(), act_bias.contiguous(), alpha, gain))
+        y, ctx.sign_bits = conv_forward(x, wmat_fwd, n, 1, cin, cout, 3, 1, 1, 0, in_scale=style, out_scale=demod,
+                                        act=(noise.contiguous(), noise_weight.contiguous(), act_bias.contiguous(), alpha,
+                                             gain), want_sign_bits=bool(ctx.needs_input_grad[0]))
         ctx.save_for_backward(style, demod if demod is not None else style.new_empty(0), y)
         ctx.wmat_bwd = wmat_bwd
         ctx.conf = (demodulate, alpha, gain, cin)
@@ -773,7 +793,8 @@ class _ModulatedConvAct(Function):
             return (None,) * 12
         dy = dy.contiguous()
         n, cout, h, w = y.shape
-        dx = masked_dgrad(dy, y, alpha, gain, ctx.wmat_bwd, n, cout, cin, h, w, demod if demodulate else None, style)
+        dx = masked_dgrad(dy, y, alpha, gain, ctx.wmat_bwd, n, cout, cin, h, w, demod if demodulate else None, style,
+                          sign_bits=ctx.sign_bits)
         if dx is None:
             g = torch.empty_like(dy)
             _lib.call('gg_fused_lrelu_bwd_f32', g, None, dy, y, alpha, gain, n, cout, h * w)
@@ -799,8 +820,9 @@ class _StyledConvToRGB(Function):
         demod = None
         if demodulate:
             demod = demod_pre if demod_pre is not None else torch.rsqrt((style * style) @ wsq.t() + 1e-8)
-        y = conv_forward(x, wmat_fwd, n, 1, cin, cout, 3, 1, 1, 0, in_scale=style, out_scale=demod,
-                         act=(noise.contiguous(), noise_weight.contiguous(), act_bias.contiguous(), alpha, gain))
+        y, ctx.sign_bits = conv_forward(x, wmat_fwd, n, 1, cin, cout, 3, 1, 1, 0, in_scale=style, out_scale=demod,
+                                        act=(noise.contiguous(), noise_weight.contiguous(), act_bias.contiguous(), alpha,
+                                             gain), want_sign_bits=bool(ctx.needs_input_grad[0]))
         rgb_style = rgb_style.contiguous()
         rgb = conv_forward(y, rgb_wmat, n, 1, cout, 3, 1, 1, 0, 0, in_scale=rgb_style, bias=rgb_bias)
         ctx.save_for_backward(style, demod if demod is not None else style.new_empty(0), y, rgb_style, rgb_weight)
@@ -821,7 +843,8 @@ class _StyledConvToRGB(Function):
             g = gy.contiguous()              # produced for this node only (y's other consumer is internal): updated in place
         if grgb is not None:
             _lib.call('gg_torgb_dgrad_add_f32', g, grgb.contiguous(), rgb_weight, rgb_style, rgb_scale, n, cout, h * w)
-        dx = masked_dgrad(g, y, alpha, gain, ctx.wmat_bwd, n, cout, cin, h, w, demod if demodulate else None, style)
+        dx = masked_dgrad(g, y, alpha, gain, ctx.wmat_bwd, n, cout, cin, h, w, demod if demodulate else None, style,
+                          sign_bits=ctx.sign_bits)
         if dx is None:
             gm = torch.empty_like(g)
             _lib.call('gg_fused_lrelu_bwd_f32', gm, None, g, y, alpha, gain, n, cout, h * w)

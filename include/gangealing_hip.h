@@ -38,7 +38,9 @@ extern "C" {
 #define GG_NOT_SERVED (-1000)
 
 /* 2: library-owned scratch (gg_scratch_*), gg_lpips_tail_bwd_f32 gained `accumulate`
- * 3: gg_set_allocator; binary16 limbs (format code 18) accepted by the data-gradient entry points */
+ * 3: gg_set_allocator; binary16 limbs (format code 18) accepted by the data-gradient entry points
+ * 4: gg_modconv3x3_act_bits_f32 / gg_conv3x3_masked_dgrad_bits_f32 (1-bit sign plane), gg_set_tuning; the ticket page of
+ *    a stream may not be created inside a hipGraph capture (error -4) */
 int gg_abi_version(void);
 /* Pre-size the scratch buffer of `stream` on the current device to at least `bytes` and create its ticket page.
  * Optional for eager use (the entry points grow the scratch on demand); REQUIRED once per stream before a hipGraph
@@ -340,6 +342,28 @@ int gg_modconv3x3_act_f32(float* y, const float* x, const float* wmat, const uns
                           long long limb_stride, int limbs, const float* in_scale, const float* out_scale,
                           const float* noise, const float* noise_weight, const float* act_bias, float alpha,
                           float gain, int batch, int cin, int cout, int h, int w, void* stream);
+/* ABI 4: the same launch, additionally writing the SIGN PLANE of its output: one bit per element,
+ *   bit (co & 31) of sign_bits[(n * H * W + y * W + x) * (cout / 32) + co / 32] = (y[n, co, y, x] > 0),
+ * i.e. exactly what the leaky-ReLU backward tests (op/fused_act.py:33-38 -> fused_bias_act_kernel.cu:36-47 take the
+ * saved OUTPUT only as a sign).  gg_conv3x3_masked_dgrad_bits_f32 consumes it: the data gradient of the layer then reads
+ * one word per (pixel, 32 channels) where gg_conv3x3_masked_dgrad_f32 reads 32 floats.  The plane comes out of the 3x3
+ * patch tile's own activation epilogue: gg_last_sign_bits_written() (calling thread's last launch) is 1 when the launch
+ * produced it, 0 when another kernel served the shape (split-K, the fp32 kernel, cout % 32 != 0) - the caller then keeps
+ * mask_ref.  sign_bits: N * H * W * (cout / 32) words, or NULL. */
+int gg_modconv3x3_act_bits_f32(float* y, const float* x, const float* wmat, const unsigned short* wsplit,
+                               long long limb_stride, int limbs, const float* in_scale, const float* out_scale,
+                               const float* noise, const float* noise_weight, const float* act_bias, float alpha,
+                               float gain, int batch, int cin, int cout, int h, int w, unsigned int* sign_bits,
+                               void* stream);
+int gg_last_sign_bits_written(void);
+/* gg_conv3x3_masked_dgrad_f32 with the mask taken from the sign plane of gg_modconv3x3_act_bits_f32 (words per pixel =
+ * cin / 32; cin = the reduction channels of this launch = the layer's output channels).  limbs = 18 only (the
+ * binary16-limb patch tiles); GG_NOT_SERVED otherwise and when the patch tile does not cover the shape.  Results are
+ * bitwise equal to gg_conv3x3_masked_dgrad_f32 on the fp32 output the plane was taken from. */
+int gg_conv3x3_masked_dgrad_bits_f32(float* y, const float* x, const unsigned int* mask_bits, float alpha, float gain,
+                                     const unsigned short* wsplit, long long limb_stride, int limbs,
+                                     const float* in_scale, const float* out_scale, int batch, int cin, int cout, int h,
+                                     int w, void* stream);
 /* Weight gradient: dw (groups, cout_g, cin_g, k, k) torch layout, overwritten.  (All weight-gradient entry points:
  * the K-splits' partial tiles go to the library's scratch and are added in split order.)
  *   dw[g,co,ci,ky,kx] = sum_{n,oy,ox} dy[n,g*cout_g+co,oy,ox] * x[n,g*cin_g+ci, oy*stride+ky-pad, ox*stride+kx-pad] */

@@ -39,10 +39,10 @@ def test_exports_every_declared_symbol(lib):
 def test_ctypes_prototypes_match_header():
     from gangealing_amd import _lib
     tm = {'float*': 'p', 'const float*': 'p', 'double*': 'p', 'const double*': 'p', 'unsigned short*': 'p', 'unsigned char*': 'p', 'const unsigned char*': 'p',
-          'const unsigned short*': 'p', 'const void*': 'p', 'int*': 'p', 'const int*': 'p', 'int': 'i', 'long long': 'q',
+          'const unsigned short*': 'p', 'const void*': 'p', 'unsigned int*': 'p', 'const unsigned int*': 'p', 'int*': 'p', 'const int*': 'p', 'int': 'i', 'long long': 'q',
           'float': 'f', 'double': 'd', 'void*': 's'}
     for name, args in header_decls():
-        if name in ('gg_abi_version', 'gg_last_error', 'gg_build_arch', 'gg_scratch_release', 'gg_set_allocator', 'gg_last_conv_kernel', 'gg_set_tuning'):
+        if name in ('gg_abi_version', 'gg_last_error', 'gg_build_arch', 'gg_scratch_release', 'gg_set_allocator', 'gg_last_conv_kernel', 'gg_set_tuning', 'gg_last_sign_bits_written'):
             continue
         proto = ''.join(tm[re.sub(r'\s+\w+$', '', a.strip()).replace(' *', '*')] for a in args.split(','))
         assert _lib._PROTOS[name] == proto, name
