@@ -235,7 +235,7 @@ def _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile)
     workload_is_c2 = (wl['gen_size'], wl['flow_size'], wl['num_heads'], wl['flips']) == (256, 128, 1, False)
     from gangealing_amd.train_step import GangealingTrainer
     conv_mfma.set_precision(precision)
-    trainer = GangealingTrainer(device, perturb_heads=0.02, seed=0, use_graph=graph and world == 1,
+    trainer = GangealingTrainer(device, perturb_heads=0.02, seed=0, use_graph=graph,
                                 stn_lr=SYNTHETIC_LR, ll_lr=SYNTHETIC_LR, allow_random_loss=True, **wl)
 
     def barrier():
@@ -456,8 +456,9 @@ def main():
                          'operand, 3 MFMA products (binary16 limbs on the forward convolutions / bf16 limbs everywhere); '
                          'fp32 = exact-product fp32 MFMA')
     ap.add_argument('--graph', action='store_true',
-                    help='time hipGraph replays of the whole iteration instead of eager launches (single GPU; no '
-                         'roofline entry: HIP events cannot be recorded inside a replayed graph)')
+                    help='time hipGraph replays of the iteration instead of eager launches (one graph on a single GPU; '
+                         'four graphs with the eager gradient all-reduces between them when --gpus > 1; no roofline '
+                         'entry: HIP events cannot be recorded inside a replayed graph)')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the additional single-GPU measurements (hipGraph replay, plain-bf16 arithmetic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -540,6 +541,19 @@ def main():
                                                  'conv2d / conv_transpose2d with groups = N')
             except Exception as e:             # noqa: BLE001 - an extra must never take the headline line down
                 extras[name] = {'error': str(e)[:200]}
+        # the reference's own C2 recipe is 8 GPUs x batch 5 (scripts/training/lsun_cats_lpips.sh): the per-GPU step there,
+        # eager (bound by the host's launch rate) and as a hipGraph replay (what GangealingTrainer(use_graph='auto') picks
+        # at batches <= 8)
+        if args.workload == 'c2' and not args.batch:
+            for name, graph in (('batch5_eager', False), ('batch5_hipgraph', True)):
+                try:
+                    r = measure(device, dict(wl, batch=5), args.precision, graph, args.steps, args.warmup, world, gdist,
+                                profile=False)
+                    extras[name] = {'value': round(r['images'] / r['elapsed'], 3),
+                                    'ms_per_step': round(1e3 * r['elapsed'] / args.steps, 3), 'dtype': DTYPE[args.precision],
+                                    'launch': 'hipGraph replay' if r['graphed'] else 'eager', 'per_gpu_batch': 5}
+                except Exception as e:         # noqa: BLE001
+                    extras[name] = {'error': str(e)[:200]}
         # BASELINE configs[3] / [4] at the per-GPU batch of the reference's own 8-GPU recipes (scripts/training/celeba.sh,
         # lsun_cars.sh: 16), each with the roofline of ITS dominant kernel (parity at these batches: tests/golden/
         # cfg_c4b16.npz, cfg_c5b16.npz)

@@ -19,8 +19,10 @@ def no_weight_gradients():
     global weight_gradients_disabled
     old = weight_gradients_disabled
     weight_gradients_disabled = True
-    yield
-    weight_gradients_disabled = old
+    try:
+        yield
+    finally:                      # (restored when the body raises too; the reference, conv2d_gradfix.py:13-19, is not)
+        weight_gradients_disabled = old
 
 
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):

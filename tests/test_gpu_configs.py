@@ -114,7 +114,7 @@ def check_grads(test, mode, grads, case, select=lambda name: True, factor=GRAD_F
     the networks are piecewise linear (leaky ReLU / ReLU masks taken from the sign of an activation, max-pool and
     mip-level arg-max), so an activation within rounding distance of a kink can take the other branch in one
     implementation and moves a handful of gradient entries by O(|dy| |w|) - measured up to 2e-2 of the largest entry
-    from a single flipped unit among 8.4 M (scripts/debug_conv_shapes.py), while the L2 error stays at 1e-5."""
+    from a single flipped unit among 8.4 M, while the L2 error stays at 1e-5."""
     from oracle import config_cases as cc
     from conftest import PARITY
     norms, arrays = cc.pack_grads(grads)

@@ -129,3 +129,78 @@ def test_two_ranks_one_gpu_pipelined_trainer(cuda):
         assert res['same_order'] and res['loss_same'], ('pipelined and immediate update orders differ', res['worst'])
     for p in procs:
         assert p.exitcode == 0
+
+
+def _graph_worker(rank, world, port, q):
+    """GangealingTrainer(use_graph=True) with collectives: the iteration as four captured graphs with the eager
+    all-reduces between them (train_step.py: _capture_segments / _segment_step_on_stream)."""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    from gangealing_amd import distributed as gdist
+    from gangealing_amd.train_step import GangealingTrainer
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    assert gdist.setup_distributed('gloo') is True
+    result = dict(rank=rank)
+    try:
+        tr = GangealingTrainer(dev, use_graph=True, graph_warmup=2, **KW)
+        assert tr.collectives and tr.use_graph
+        init = tr.stn_arena.param.clone()
+        losses, ok_sync, moved = [], True, []
+        for step in range(7):
+            torch.manual_seed(1000 * (rank + 1) + step)
+            parts = tr.step(psi=0.5)
+            assert (tr._segments is None) == (step < 2)           # two eager iterations, then the captured segments
+            tr.flush()
+            losses.append(float(parts['p']))
+            for arena in (tr.stn_arena, tr.ema_arena, tr.ll_arena):
+                mine = arena.param.cpu()
+                both = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(both, mine)
+                ok_sync = ok_sync and torch.equal(both[0], both[1])
+            moved.append(float((tr.stn_arena.param - init).abs().max()))
+        both_losses = [None, None]
+        dist.all_gather_object(both_losses, losses)
+        # without flush() between the steps: the STN update of a step runs beside the next step's generator passes
+        for step in range(7, 11):
+            torch.manual_seed(1000 * (rank + 1) + step)
+            tr.step(psi=0.5)
+        assert tr._pending_work is not None
+        tr.flush()
+        mine = tr.stn_arena.param.cpu()
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        result.update(ok_sync=bool(ok_sync), pipelined_sync=bool(torch.equal(both[0], both[1])),
+                      finite=all(l == l and abs(l) != float('inf') for l in losses),
+                      distinct=both_losses[0] != both_losses[1], moved=moved, steps=tr.stn_arena.step_count,
+                      ll_steps=tr.ll_arena.step_count)
+    except Exception as e:
+        import traceback
+        result['error'] = ''.join(traceback.format_exception(type(e), e, e.__traceback__))[-3000:]
+    q.put(result)
+    gdist.synchronize()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_graph_replay_segments(cuda):
+    """hipGraph replay of the multi-process step (the reference's own recipe is 8 GPUs x batch 5, where the eager step is
+    bound by the host): replicas bit-identical after every flush() and after un-flushed (pipelined) replays, the ranks
+    see different data, parameters move, step counters track the replays."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for res in results:
+        assert 'error' not in res, res['error']
+        assert res['ok_sync'] and res['pipelined_sync'], 'replicas diverged'
+        assert res['finite'] and res['distinct']
+        assert res['moved'][-1] > res['moved'][0] > 0 and res['steps'] == 11 and res['ll_steps'] == 11
+    for p in procs:
+        assert p.exitcode == 0
