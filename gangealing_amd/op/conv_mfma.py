@@ -318,13 +318,13 @@ def pack_weight(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0)
 
 
 def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in_scale=None, out_scale=None,
-                 bias=None, out_hw=None, act=None, grad=False, want_sign_bits=False):
+                 bias=None, out_hw=None, act=None, grad=False, want_sign_bits=None):
     """act = (noise (N,1,OH,OW), noise_weight (1,), act_bias (Cout,), alpha, gain): the StyledConv tail
     lrelu(y + noise_weight*noise + act_bias)*gain fused behind a 3x3/stride-1/pad-1 convolution
     (gg_modconv3x3_act_f32).  grad: this launch is a gradient convolution (data gradient): bf16 limbs in every
-    split-precision mode.  want_sign_bits (with act): -> (y, bits): the 1-bit sign plane of y (int32
-    (N, OH*OW, Cout/32), gg_modconv3x3_act_bits_f32) for the layer's masked data gradient, or None when the kernel that
-    served the launch does not write it."""
+    split-precision mode.  want_sign_bits (with act; True / False, not None): the call returns (y, bits) - bits = the
+    1-bit sign plane of y (int32 (N, OH*OW, Cout/32), gg_modconv3x3_act_bits_f32) for the layer's masked data gradient when
+    asked for with True, None when not asked for or when the kernel that served the launch does not write it."""
     sign_bits = None
     h, w = x.shape[-2], x.shape[-1]
     if mode == 0:
@@ -389,7 +389,7 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             if prof.every:
                 prof.names[sig] = name
             prof.end(start, 2.0 * batch * groups * cout_g * cin_g * k * k * pos, name)
-    return (y, sign_bits) if want_sign_bits else y
+    return y if want_sign_bits is None else (y, sign_bits)
 
 
 # Gradient slots: weight storage address -> (the tensor its gradient is ACCUMULATED into, weak reference to the

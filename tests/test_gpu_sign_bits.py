@@ -28,12 +28,12 @@ def pack_signs(y):
 
 
 SHAPES = [
-    # n, cin, cout, h, w, style-scaled
-    (4, 128, 128, 32, 64, True),      # 256-pixel (8-wave, pipelined) tile: enough tiles for two blocks per CU
-    (2, 96, 128, 16, 16, True),       # 128-pixel tile
-    (2, 64, 64, 32, 32, False),       # 64-channel tiles (cout <= 64), the STN trunk's form
-    (2, 128, 96, 16, 64, False),      # ragged co tile (96 = 3 x 32): the last 32-block of the 128-channel tile is empty
-    (16, 128, 64, 64, 64, True),      # 64-channel tiles on 256 pixels
+    # n, cin, cout, h, w, style-scaled      (>= 512 tiles each: launches with fewer are split along Cin, see below)
+    (16, 128, 128, 64, 128, True),    # 256-pixel (8-wave, pipelined) tile
+    (8, 96, 128, 64, 128, True),      # 128-pixel tile
+    (16, 64, 64, 64, 64, False),      # 64-channel tiles (cout <= 64), the STN trunk's form
+    (8, 128, 96, 64, 128, False),     # ragged co tile (96 = 3 x 32): the last 32-block of the 128-channel tile is empty
+    (16, 128, 64, 64, 64, True),      # 64-channel tiles, style-scaled
 ]
 
 
