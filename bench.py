@@ -50,17 +50,17 @@ MFMA_PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0, 'bf16x6': 2
 # descriptions only (roofline.kernel_detail); roofline.kernel is the name the dispatcher reports at run time
 KERNEL_NAME = {
     'fp32': 'conv_igemm_kernel<3,0,2,2,2,2,*> (3x3 correlation, 128co x 128pix tile, v_mfma_f32_32x32x2_f32)',
-    'bf16x3': 'conv3x3_patch_kernel<2, true, 256, 2, false, 1> (3x3 stride-1 modulated conv + fused noise/bias/lrelu epilogue, '
+    'bf16x3': 'conv3x3_patch_kernel<2, true, 256, 2, 0, 1> (3x3 stride-1 modulated conv + fused noise/bias/lrelu epilogue, '
               '128co x 256pix tile, input patch staged once per 32-channel chunk, double-buffered weight slab with a '
               'software-pipelined tap loop, v_mfma_f32_32x32x16_bf16, 2 bf16 limbs per fp32 operand = 3 MFMA products per '
               'algorithmic product)',
-    'fp16x3': 'conv3x3_patch_kernel<2, true, 256, 2, false, 1, true> (the bf16x3 tile with binary16 limbs: '
+    'fp16x3': 'conv3x3_patch_kernel<2, true, 256, 2, 0, 1, true> (the bf16x3 tile with binary16 limbs: '
               'v_mfma_f32_32x32x16_f16, 2 limbs per fp32 operand = 3 MFMA products per algorithmic product, weights '
               'pre-scaled by 2^8 in the pack, a power-of-two block exponent per tile; data gradients the same, weight '
               'gradients on bf16 limbs)',
-    'bf16': 'conv3x3_patch_kernel<1, true, 256, 2, false, 3> (same tile as bf16x3, one bf16 limb per operand = one MFMA '
+    'bf16': 'conv3x3_patch_kernel<1, true, 256, 2, 0, 3> (same tile as bf16x3, one bf16 limb per operand = one MFMA '
             'product per algorithmic product, fp32 accumulate; three tap slabs staged per barrier interval)',
-    'bf16x6': 'conv3x3_patch_kernel<3, true, 128, 2, false, 1> (same layers, 128co x 128pix tile, 3 bf16 limbs per fp32 operand '
+    'bf16x6': 'conv3x3_patch_kernel<3, true, 128, 2, 0, 1> (same layers, 128co x 128pix tile, 3 bf16 limbs per fp32 operand '
               '= 6 MFMA products per algorithmic product)',
 }
 MFMA_PRODUCTS = {'fp32': 1, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6, 'fp16x3': 3}

@@ -315,6 +315,13 @@ class vgg16(nn.Module):
         of values instead of the list of feature maps (LPIPS' fused per-tap distance).
         observe: optional callable (torchvision `features` index of a convolution, its ReLU output) - diagnostics
         (tests/test_gpu_lpips_masks.py inspects / pins the branch decisions through it)."""
+        if observe is not None and conv_mfma.ACT_OBSERVER is None:
+            # a diagnostics hook may edit the outputs: the layers must keep no sign plane beside them (conv_mfma.ACT_OBSERVER)
+            conv_mfma.ACT_OBSERVER = lambda site, y: None
+            try:
+                return self.forward(x, tap=tap, observe=observe)
+            finally:
+                conv_mfma.ACT_OBSERVER = None
         feats = []
         for si in range(5):
             for name, mod in getattr(self, f'slice{si + 1}').named_children():

@@ -365,7 +365,8 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             noise, noise_weight, act_bias, alpha, gain = act       # noise / noise_weight / act_bias may be None
             wbuf, stride_l = wmat.split(code) if use_split else (None, 0)
             wm = None if use_split else (wmat.fp32() if isinstance(wmat, PackedWeight) else wmat)
-            if want_sign_bits and use_split and code == 18 and cout_g % 32 == 0 and 'sign_bits' not in DISABLED:
+            if (want_sign_bits and use_split and code == 18 and cout_g % 32 == 0 and 'sign_bits' not in DISABLED
+                    and ACT_OBSERVER is None):
                 sign_bits = torch.empty((batch, oh * ow, cout_g // 32), dtype=torch.int32, device=x.device)
                 _lib.call('gg_modconv3x3_act_bits_f32', y, x, wm, wbuf, stride_l, code, in_scale, out_scale,
                           noise, noise_weight, act_bias, alpha, gain, batch, cin_g, cout_g, h, w, sign_bits)
@@ -445,6 +446,18 @@ def _slot_for(weight):
 # developer A/B switches (comma separated names in GG_DISABLE): slots, style_demod, fuse_act, wgrad_rows, lpips_tail,
 # pack_registry, mask_dgrad, torgb_fuse
 DISABLED = frozenset(filter(None, os.environ.get('GG_DISABLE', '').split(',')))
+
+# Diagnostics hook (tests/test_gpu_act_masks.py, tests/test_gpu_lpips_masks.py): a callable (site, y) handed the OUTPUT of
+# every leaky-ReLU / ReLU layer right after it was produced - the tensor the backward takes its branch decisions from.
+# An observer may edit y.data (decision replay); while one is installed the layers keep no sign plane, so that the
+# edited tensor is what their backward reads.  None (always, outside those tests) costs nothing.
+ACT_OBSERVER = None
+
+
+def observe_activation(site, y):
+    if ACT_OBSERVER is not None:
+        ACT_OBSERVER(site, y)
+    return y
 # opt-in paths (GG_ENABLE): mask_wgrad - leaky-ReLU backward inside BOTH gradient kernels of a trainable conv+act layer
 # (gg_conv3x3_masked_wgrad_f32).  Measured 1 % SLOWER than the separate 5 TB/s mask pass on the STN shapes (the masked
 # kernels read a second tensor), so it is off by default; the frozen layers use the masked data gradient only.
@@ -575,6 +588,7 @@ class _Conv3x3BiasAct(Function):
         y, ctx.sign_bits = conv_forward(x, wmat, n, 1, cin, cout, 3, 1, 1, 0,
                                         act=(None, None, None if bias is None else bias.contiguous(), alpha, gain),
                                         want_sign_bits=bool(ctx.needs_input_grad[0]))
+        observe_activation('conv3x3_bias_act', y)
         ctx.save_for_backward(x, weight, y)
         ctx.conf = (alpha, gain, wscale, bias is not None)
         ctx.bias_ref = bias          # (the parameter itself: looked up in the gradient-slot registry in backward)
@@ -780,6 +794,7 @@ class _ModulatedConvAct(Function):
         y, ctx.sign_bits = conv_forward(x, wmat_fwd, n, 1, cin, cout, 3, 1, 1, 0, in_scale=style, out_scale=demod,
                                         act=(noise.contiguous(), noise_weight.contiguous(), act_bias.contiguous(), alpha,
                                              gain), want_sign_bits=bool(ctx.needs_input_grad[0]))
+        observe_activation('styled_conv', y)
         ctx.save_for_backward(style, demod if demod is not None else style.new_empty(0), y)
         ctx.wmat_bwd = wmat_bwd
         ctx.conf = (demodulate, alpha, gain, cin)
@@ -823,6 +838,7 @@ class _StyledConvToRGB(Function):
         y, ctx.sign_bits = conv_forward(x, wmat_fwd, n, 1, cin, cout, 3, 1, 1, 0, in_scale=style, out_scale=demod,
                                         act=(noise.contiguous(), noise_weight.contiguous(), act_bias.contiguous(), alpha,
                                              gain), want_sign_bits=bool(ctx.needs_input_grad[0]))
+        observe_activation('styled_conv', y)
         rgb_style = rgb_style.contiguous()
         rgb = conv_forward(y, rgb_wmat, n, 1, cout, 3, 1, 1, 0, 0, in_scale=rgb_style, bias=rgb_bias)
         ctx.save_for_backward(style, demod if demod is not None else style.new_empty(0), y, rgb_style, rgb_weight)

@@ -32,6 +32,13 @@ def _bias_act(x, bias, ref, act, grad, alpha, scale):
     return out
 
 
+def _observe(site, out):
+    """Diagnostics hook of the decision-replay tests (conv_mfma.ACT_OBSERVER); nothing is installed otherwise."""
+    from . import conv_mfma
+    if conv_mfma.ACT_OBSERVER is not None:
+        conv_mfma.ACT_OBSERVER(site, out)
+
+
 class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, out, negative_slope, scale):
@@ -59,6 +66,7 @@ class FusedLeakyReLUFunction(Function):
     @staticmethod
     def forward(ctx, input, bias, negative_slope, scale):
         out = _bias_act(input, bias, None, 3, 0, negative_slope, scale)
+        _observe('fused_leaky_relu', out)
         ctx.save_for_backward(out)
         ctx.negative_slope = negative_slope
         ctx.scale = scale
@@ -105,6 +113,7 @@ class NoiseBiasLeakyReLUFunction(Function):
         out = torch.empty_like(input)
         _lib.call('gg_noise_bias_act_f32', out, input, noise.contiguous(), noise_weight.contiguous(),
                   bias.contiguous(), negative_slope, scale, n, c, hw)
+        _observe('noise_bias_leaky_relu', out)
         ctx.save_for_backward(out, noise)
         ctx.conf = (negative_slope, scale)
         return out

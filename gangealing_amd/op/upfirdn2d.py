@@ -151,6 +151,8 @@ class _BlurNoiseAct(Function):
                   noise_weight.contiguous(), bias.contiguous(), None, negative_slope, scale)
         if prof is not None:
             prof.end(start, 4 * (x.numel() + out.numel() + noise.numel()), 'blur4_fused<noise+bias+lrelu>', 'byte')
+        from . import conv_mfma
+        conv_mfma.observe_activation('blur_noise_act', out)
         ctx.save_for_backward(kernel, out)
         # adjoint padding (reference upfirdn2d.py:113-118 with up = down = 1)
         ctx.g_pad = (4 - p0 - 1, in_w - out.shape[3] + p0)

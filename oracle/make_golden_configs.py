@@ -1,7 +1,7 @@
 """Golden vectors at BASELINE.json's own configurations, produced by the REFERENCE on CPU.
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py); authoring container only (needs /root/reference).
 
-    python oracle/make_golden_configs.py [c2_generator c2_stn c1 c2 c2t c2r c4 c5 c4b4 c5b4 c4b16 c5b8 c5b16 lpips lpips_masks]      # ~15 min on 8 cores for all
+    python oracle/make_golden_configs.py [c2_generator c2_stn c1 c2 c2t c2r c4 c5 c4b4 c5b4 c4b16 c5b8 c5b16 lpips lpips_masks act_masks]      # ~15 min on 8 cores for all
 
 Writes tests/golden/{c2_generator,c2_stn,cfg_c1,cfg_c2,cfg_c2t,cfg_c4,cfg_c5,lpips}.npz.  The reference runs unmodified: its
 modules are imported exactly as oracle/make_golden.py does, plus a local VGG16 `features` stack placed where
@@ -184,6 +184,89 @@ def gen_lpips(api):
     save('lpips', cases)
 
 
+def _record_lrelu_signs(root):
+    """Forward hooks on every FusedLeakyReLU module below `root`: -> (list filled in call order with (out > 0), handles)."""
+    from models.stylegan2.op import FusedLeakyReLU
+    signs, hooks = [], []
+    for mod in root.modules():
+        if isinstance(mod, FusedLeakyReLU):
+            hooks.append(mod.register_forward_hook(lambda m, i, o: signs.append((o > 0).clone())))
+    return signs, hooks
+
+
+def gen_act_masks(api):
+    """The reference's own leaky-ReLU branch decisions (one bit per activation unit, in call order) for two small runs, with
+    the gradients of the same runs in float32 and float64: tests/test_gpu_act_masks.py replays the HIP path with these
+    decisions pinned (the generator / STN counterpart of lpips_masks).
+      case 0  Generator(64), batch 2: gradient of <image, g> w.r.t. w through all ten style inputs (the run of
+              gen_c2_generator at a size whose masks fit a fixture);
+      case 1  similarity + flow STN at 64^2, batch 4: warped output, flow, every parameter gradient (the run of gen_c2_stn)."""
+    from models.losses.loss import total_variation_loss, flow_identity_loss
+    cases = []
+    # ---- generator
+    n = 2
+    g = api.Generator(64, 512, 8, channel_multiplier=2)
+    torch.nn.Module.load_state_dict(g, det_state_dict(g), strict=False)
+    g.eval().requires_grad_(False)
+    z = rnd('actmask.gen.z', (n, 512))
+    noise = [rnd(f'actmask.gen.noise{i}', (n, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2))) for i in range(g.num_layers)]
+    with torch.no_grad():
+        _, latent = g([z], return_latents=True, noise=noise)
+    w = latent[:, 0].detach().clone().requires_grad_(True)
+    signs, hooks = _record_lrelu_signs(g)
+    img, _ = g([w.unsqueeze(1).repeat(1, g.n_latent, 1)], input_is_latent=True, noise=noise)
+    for h in hooks:
+        h.remove()
+    gimg = rnd('actmask.gen.gimg', img.shape)
+    (gw,) = torch.autograd.grad(img, w, gimg)
+    g64 = g.double()
+    w64 = latent[:, 0].detach().double().clone().requires_grad_(True)
+    img64, _ = g64([w64.unsqueeze(1).repeat(1, g.n_latent, 1)], input_is_latent=True, noise=[t.double() for t in noise])
+    (gw64,) = torch.autograd.grad(img64, w64, gimg.double())
+    case = dict(w=latent[:, 0], gw=gw, gw64=gw64, img=img.detach(),
+                meta=dict(kind='generator', size=64, batch=n, num_layers=g.num_layers,
+                          shapes=[list(sg.shape) for sg in signs],
+                          active=[float(sg.float().mean()) for sg in signs]))
+    for k, sg in enumerate(signs):
+        case[f'sign{k:02d}'] = np.packbits(sg.numpy().reshape(-1))
+    cases.append(case)
+    # ---- STN
+    n = 4
+    case, meta = {}, dict(kind='stn', batch=n, padding_mode='reflection')
+    for dt, prefix in ((torch.float32, 'grad_'), (torch.float64, 'grad64_')):
+        stn = api.get_stn(['similarity', 'flow'], flow_size=64, supersize=64, channel_multiplier=0.5, num_heads=1)
+        torch.nn.Module.load_state_dict(stn, det_state_dict(stn, cc.STN_RULES), strict=False)
+        stn = stn.to(dt)
+        for m in stn.modules():
+            if isinstance(m.__dict__.get('identity_flow'), torch.Tensor):
+                m.identity_flow = m.identity_flow.to(dt)
+        x = cc.smooth_images('actmask.stn.x', n, 64).to(dt)
+        signs, hooks = _record_lrelu_signs(stn) if dt == torch.float32 else ([], [])
+        out, flow = stn(x, return_flow=True, padding_mode='reflection')
+        for h in hooks:
+            h.remove()
+        gout = rnd('actmask.stn.g', out.shape).to(dt)
+        loss = (out * gout).mean() + 10.0 * total_variation_loss(flow) + flow_identity_loss(flow)
+        params = list(stn.named_parameters())
+        grads = torch.autograd.grad(loss, [p for _, p in params])
+        norms, arrays = cc.pack_grads({n_: g_ for (n_, _), g_ in zip(params, grads)}, prefix)
+        case.update(arrays)
+        if dt == torch.float32:
+            meta['grad_norms'] = norms
+            meta['shapes'] = [list(sg.shape) for sg in signs]
+            meta['active'] = [float(sg.float().mean()) for sg in signs]
+            case['loss'] = loss
+            case.update(cc.pack_batch(out, 'out'))
+            case.update(cc.pack_batch(flow, 'flow'))
+            for k, sg in enumerate(signs):
+                case[f'sign{k:02d}'] = np.packbits(sg.numpy().reshape(-1))
+        else:
+            meta['grad_norms64'] = norms
+    case['meta'] = meta
+    cases.append(case)
+    save('act_masks', cases)
+
+
 def pool_winner_codes(x):
     """Which input of every 2x2 / stride-2 window ATen's max_pool2d picks (row-major scan, a later element replaces the
     maximum only if strictly greater): 0..3 = (dy * 2 + dx)."""
@@ -242,7 +325,7 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     api = reference_api()
     only = sys.argv[1:]
-    jobs = dict(lpips=lambda: gen_lpips(api), lpips_masks=lambda: gen_lpips_masks(api), c2_generator=lambda: gen_c2_generator(api), c2_stn=lambda: gen_c2_stn(api),
+    jobs = dict(lpips=lambda: gen_lpips(api), lpips_masks=lambda: gen_lpips_masks(api), act_masks=lambda: gen_act_masks(api), c2_generator=lambda: gen_c2_generator(api), c2_stn=lambda: gen_c2_stn(api),
                 c1=lambda: gen_config(api, 'c1'), c5=lambda: gen_config(api, 'c5'), c4=lambda: gen_config(api, 'c4'),
                 c2=lambda: gen_config(api, 'c2'), c2t=lambda: gen_config(api, 'c2t'), c2r=lambda: gen_config(api, 'c2r'),
                 **{n: (lambda n=n: gen_config(api, n)) for n in ('c4b4', 'c5b4', 'c4b16', 'c5b8')},

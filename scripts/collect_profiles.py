@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Copy the summaries of one scripts/measure_r04.sh session (gpurun_out/r04/) into profiles/ under their round-4 names,
-stamp each with the commit / kernel-source hash the session ran at, and rebuild profiles/r04_pmc_traffic.json from the
+"""Copy the summaries of one scripts/measure.sh session (gpurun_out/<round>/) into profiles/ under their round names,
+stamp each with the commit / kernel-source hash the session ran at, and rebuild profiles/<round>_pmc_traffic.json from the
 FETCH_SIZE / WRITE_SIZE passes and the calibration kernel (bench.py only trusts that file while the recorded
 kernel-source hash equals the tree's)."""
 import json
@@ -10,9 +10,10 @@ import shutil
 import subprocess
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-O = os.path.join(R, 'gpurun_out', 'r04')
+ROUND = os.environ.get('ROUND', 'r05')
+O = os.path.join(R, 'gpurun_out', ROUND)
 P = os.path.join(R, 'profiles')
-DOM = 'conv3x3_patch_kernel<2, true, 256, 2, fals'
+DOM = 'conv3x3_patch_kernel<2, true, 256, 2, 0,'        # (MASK = 0: the plain tile; round 4's bool printed as false)
 
 
 def rows(path):
@@ -35,7 +36,7 @@ commit = open(os.path.join(O, 'commit.txt')).read().strip()
 if 'no-git' in commit:        # the GPU box receives a snapshot without .git: the session ran at the tree it was sent from
     commit = subprocess.run(['git', 'rev-parse', 'HEAD'], cwd=R, capture_output=True, text=True).stdout.strip() + \
         ' (HEAD of the authoring tree when the snapshot was sent)'
-STAMP = f'# measured by scripts/measure_r04.sh at commit {commit}; kernel-source sha16 {sha}\n'
+STAMP = f'# measured by scripts/measure.sh at commit {commit}; kernel-source sha16 {sha}\n'
 
 
 def stamped(src, dst, header=''):
@@ -43,17 +44,17 @@ def stamped(src, dst, header=''):
         f.write(STAMP + header + open(os.path.join(O, src)).read())
 
 
-for src, dst in (('parity_r04.json', 'parity_r04.json'), ('bench_fp16x3.json', 'bench_r04_fp16x3.json'), ('bench_bf16x3.json', 'bench_r04_bf16x3.json'),
-                 ('bench_fp32.json', 'bench_r04_fp32.json'), ('bench_bf16.json', 'bench_r04_bf16.json'),
-                 ('bench_fp16x3_batch5.json', 'bench_r04_fp16x3_batch5.json'),
-                 ('bench_fp16x3_batch5_hipgraph.json', 'bench_r04_fp16x3_batch5_hipgraph.json'),
-                 ('bench_fp16x3_batch32.json', 'bench_r04_fp16x3_batch32.json'),
-                 ('bench_c4_batch4.json', 'bench_r04_c4_batch4.json'), ('bench_c4_batch16.json', 'bench_r04_c4_batch16.json'),
-                 ('bench_c5_batch4.json', 'bench_r04_c5_batch4.json'), ('bench_c5_batch16.json', 'bench_r04_c5_batch16.json'),
-                 ('bench_c4_batch4_hipgraph.json', 'bench_r04_c4_batch4_hipgraph.json'),
-                 ('bench_c5_batch4_hipgraph.json', 'bench_r04_c5_batch4_hipgraph.json'),
-                 ('bench_c2_under_rocprofv3.json', 'bench_r04_fp16x3_under_rocprofv3.json'),
-                 ('splat_bench.json', 'r04_splat_bench.json')):
+for src, dst in ((f'parity_{ROUND}.json', f'parity_{ROUND}.json'), ('bench_fp16x3.json', f'bench_{ROUND}_fp16x3.json'), ('bench_bf16x3.json', f'bench_{ROUND}_bf16x3.json'),
+                 ('bench_fp32.json', f'bench_{ROUND}_fp32.json'), ('bench_bf16.json', f'bench_{ROUND}_bf16.json'),
+                 ('bench_fp16x3_batch5.json', f'bench_{ROUND}_fp16x3_batch5.json'),
+                 ('bench_fp16x3_batch5_hipgraph.json', f'bench_{ROUND}_fp16x3_batch5_hipgraph.json'),
+                 ('bench_fp16x3_batch32.json', f'bench_{ROUND}_fp16x3_batch32.json'),
+                 ('bench_c4_batch4.json', f'bench_{ROUND}_c4_batch4.json'), ('bench_c4_batch16.json', f'bench_{ROUND}_c4_batch16.json'),
+                 ('bench_c5_batch4.json', f'bench_{ROUND}_c5_batch4.json'), ('bench_c5_batch16.json', f'bench_{ROUND}_c5_batch16.json'),
+                 ('bench_c4_batch4_hipgraph.json', f'bench_{ROUND}_c4_batch4_hipgraph.json'),
+                 ('bench_c5_batch4_hipgraph.json', f'bench_{ROUND}_c5_batch4_hipgraph.json'),
+                 ('bench_c2_under_rocprofv3.json', f'bench_{ROUND}_fp16x3_under_rocprofv3.json'),
+                 ('splat_bench.json', f'{ROUND}_splat_bench.json')):
     if os.path.exists(os.path.join(O, src)):
         shutil.copy(os.path.join(O, src), os.path.join(P, dst))
 
@@ -61,34 +62,34 @@ under = json.loads(open(os.path.join(O, 'bench_c2_under_rocprofv3.json')).read()
 stats = open(os.path.join(O, 'kernel_stats_c2.txt')).read()
 dom_line = next(l for l in stats.splitlines() if DOM in l)
 dom_avg = float(dom_line.split()[2])
-stamped('kernel_stats_c2.txt', 'r04_a_kernel_stats.txt',
+stamped('kernel_stats_c2.txt', f'{ROUND}_a_kernel_stats.txt',
         '# rocprofv3 --kernel-trace --output-format rocpd -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline '
         '--no-extras   (15 steps traced: 3 warm-up, the 2 steps of the kernel survey, 10 timed; per-step = total/15)\n'
-        f'# bench line printed by the same run: profiles/bench_r04_fp16x3_under_rocprofv3.json '
+        f'# bench line printed by the same run: profiles/bench_{ROUND}_fp16x3_under_rocprofv3.json '
         f'(roofline.avg_launch_ms {under["roofline"]["avg_launch_ms"]} vs {dom_avg} us below)\n')
 for w in ('c4', 'c5'):
-    stamped(f'kernel_stats_{w}.txt', f'r04_a_kernel_stats_{w}.txt',
+    stamped(f'kernel_stats_{w}.txt', f'{ROUND}_a_kernel_stats_{w}.txt',
             f'# rocprofv3 --kernel-trace -- python bench.py --workload {w} --batch 16 --steps 10 --warmup 3 --no-cpu-baseline '
             f'--batch 16 --no-extras (per-GPU batch 16; 15 steps traced)\n')
-stamped('blur_bench.txt', 'r04_d_blur_bench.txt')
+stamped('blur_bench.txt', f'{ROUND}_d_blur_bench.txt')
 if os.path.exists(os.path.join(O, 'splat_kernel_stats.txt')):
-    stamped('splat_kernel_stats.txt', 'r04_g_splat_kernel_stats.txt', '# rocprofv3 --kernel-trace -- python scripts/splat_bench.py (the reference kernel SplatForward runs in the same process as the checker)\n')
+    stamped('splat_kernel_stats.txt', f'{ROUND}_g_splat_kernel_stats.txt', '# rocprofv3 --kernel-trace -- python scripts/splat_bench.py (the reference kernel SplatForward runs in the same process as the checker)\n')
 if os.path.exists(os.path.join(O, 'pytest_reference.txt')):
-    stamped('pytest_reference.txt', 'r04_pytest_reference_dropin.txt', '# python -m pytest tests/test_gpu_reference_dropin.py tests/test_gpu_rccl_single_rank.py -q -m gpu (tail)\n')
-stamped('conv_layers.txt', 'r04_f_conv_layers.txt', '# scripts/conv_bench.py, fp16x3 (forward launches: binary16 limbs; the wgrad column: bf16 limbs), batch 16, ITERS=20\n')
+    stamped('pytest_reference.txt', f'{ROUND}_pytest_reference_dropin.txt', '# python -m pytest tests/test_gpu_reference_dropin.py tests/test_gpu_rccl_single_rank.py -q -m gpu (tail)\n')
+stamped('conv_layers.txt', f'{ROUND}_f_conv_layers.txt', '# scripts/conv_bench.py, fp16x3 (forward launches: binary16 limbs; the wgrad column: bf16 limbs), batch 16, ITERS=20\n')
 if os.path.exists(os.path.join(O, 'conv_layers_bf16x3.txt')):
-    stamped('conv_layers_bf16x3.txt', 'r04_f_conv_layers_bf16x3.txt', '# scripts/conv_bench.py "G ", bf16x3, batch 16, ITERS=20\n')
+    stamped('conv_layers_bf16x3.txt', f'{ROUND}_f_conv_layers_bf16x3.txt', '# scripts/conv_bench.py "G ", bf16x3, batch 16, ITERS=20\n')
 if os.path.exists(os.path.join(O, 'timeline_c2.txt')):
-    stamped('timeline_c2.txt', 'r04_j_step_timeline_under_rocprofv3.txt',
-            '# one training step of the trace behind r04_a_kernel_stats.txt in launch order (scripts/rocpd_timeline.py): start, '
+    stamped('timeline_c2.txt', f'{ROUND}_j_step_timeline_under_rocprofv3.txt',
+            '# one training step of the trace behind the kernel_stats file of the same session in launch order (scripts/rocpd_timeline.py): start, '
             'duration, idle gap before the launch.  Under rocprofv3 the host is slower than the GPU (gaps of 5 - 11 us in front of '
             'most library launches); untraced, the step is GPU-bound (bench: kernel time ~ step time)\n')
-stamped('determinism.txt', 'r04_determinism.txt',
+stamped('determinism.txt', f'{ROUND}_determinism.txt',
         '# scripts/check_determinism.py: two runs of two training iterations from the same seeds, compared bit for bit\n')
-stamped('pytest_gpu.txt', 'r04_pytest_gpu.txt', '# python -m pytest tests -m gpu -q (tail)\n')
+stamped('pytest_gpu.txt', f'{ROUND}_pytest_gpu.txt', '# python -m pytest tests -m gpu -q (tail)\n')
 
 OLD_SPLAT = ''
-_prev = os.path.join(P, 'r04_b_pmc_hbm_traffic.txt')
+_prev = os.path.join(P, f'{ROUND}_b_pmc_hbm_traffic.txt')
 if os.path.exists(_prev):
     _t = open(_prev).read()
     _i = _t.find('# splat2d stress')
@@ -97,7 +98,7 @@ cal = {**rows('cal_fetch.txt'), **rows('cal_write.txt')}
 cal_f = find(cal, 'fused_bias_act_kernel', 'FETCH_SIZE')[1]
 cal_w = find(cal, 'fused_bias_act_kernel', 'WRITE_SIZE')[1]
 fetch, write = rows('pmc_fetch.txt'), rows('pmc_write.txt')
-with open(os.path.join(P, 'r04_b_pmc_hbm_traffic.txt'), 'w') as f:
+with open(os.path.join(P, f'{ROUND}_b_pmc_hbm_traffic.txt'), 'w') as f:
     f.write(STAMP + '# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 '
             '--warmup 1 --no-cpu-baseline --no-extras\n# mean counter value per kernel (KB); calibration kernel (512 MiB in, '
             '512 MiB out):\n')
@@ -113,7 +114,7 @@ with open(os.path.join(P, 'r04_b_pmc_hbm_traffic.txt'), 'w') as f:
         f.write('# splat2d stress (scripts/splat_bench.py under the same two passes):\n' + ''.join(fresh))
     else:          # a QUICK session skipped the (unchanged) splat2d passes: keep the last full session's lines
         f.write(OLD_SPLAT)
-stamped('pmc_sq.txt', 'r04_c_pmc_sq.txt', '# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- python bench.py '
+stamped('pmc_sq.txt', f'{ROUND}_c_pmc_sq.txt', '# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- python bench.py '
         '--steps 2 --warmup 1 --no-cpu-baseline --no-extras\n')
 
 fn, fv = find(fetch, DOM, 'FETCH_SIZE')
@@ -121,7 +122,7 @@ wn, wv = find(write, DOM, 'WRITE_SIZE')
 scale_f = 512 * 1024 / cal_f
 fetch_b, write_b = int(fv * 1024 * round(scale_f)), int(wv * 1024)
 json.dump({
-    'kernel': 'conv3x3_patch_kernel<2, true, 256, 2, false, 1, true>', 'precision': 'fp16x3', 'workload': 'c2', 'batch': 16,
+    'kernel': 'conv3x3_patch_kernel<2, true, 256, 2, 0, 1, true>', 'precision': 'fp16x3', 'workload': 'c2', 'batch': 16,
     'kernel_source_sha16': sha, 'commit': commit,
     'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python bench.py --steps 2 '
                '--warmup 1 --no-cpu-baseline --no-extras',
@@ -135,5 +136,5 @@ json.dump({
         'note': 'mean over the 6 forward launches per step: 512->512@64^2, 256->256@128^2, 128->128@256^2 (x2 generator '
                 'passes), batch 16, fp32'},
     'reading': f'reads = {fetch_b / 313174698:.2f}x the input tensor (tile halos), writes = {write_b / 313174698:.2f}x the output',
-}, open(os.path.join(P, 'r04_pmc_traffic.json'), 'w'), indent=1)
-print(open(os.path.join(P, 'r04_pmc_traffic.json')).read())
+}, open(os.path.join(P, f'{ROUND}_pmc_traffic.json'), 'w'), indent=1)
+print(open(os.path.join(P, f'{ROUND}_pmc_traffic.json')).read())

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-4 measurement on the GPU box, in SECTIONS (one gpurun call runs the sections named on the command line; no
-# arguments = the full session behind profiles/r04_* and profiles/bench_r04_*, copied by scripts/collect_profiles_r04.py).
-# This replaces the per-experiment session scripts of round 3 (gpu_session_r03_a..z.sh, now only in git history):
+# The round's measurement session on the GPU box, in SECTIONS (one gpurun call runs the sections named on the command line; no
+# arguments = the full session behind profiles/<round>_* and profiles/bench_<round>_*, copied by scripts/collect_profiles.py).
+# ROUND=r05 (default) names the output directory gpurun_out/$ROUND and the files; rounds 2 - 4 used earlier forms of this script:
 #
-#   suite        GPU test suite + parity report (-> parity_r04.json)
+#   suite        GPU test suite + parity report (-> parity_$ROUND.json)
 #   determinism  scripts/check_determinism.py on three configurations x three arithmetic modes
 #   bench        the driver's command, then every arithmetic mode / batch / workload (c4, c5 at batch 4 and 16)
 #   layers       per-layer convolution table (scripts/conv_bench.py), blur and splat2d stand-alone benchmarks
@@ -14,7 +14,8 @@
 #   reference    the reference's own modules on the HIP operators (literal drop-in) + the 1-rank RCCL trainer test
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r04
+ROUND=${ROUND:-r05}
+O=$R/gpurun_out/$ROUND
 mkdir -p $O
 export GANGEALING_SYNTHETIC=1 TMPDIR=/tmp
 cd $R
@@ -29,7 +30,7 @@ B="python bench.py --no-cpu-baseline --no-extras"
 
 sec_suite() {
   timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/pytest_gpu.txt
-  cp gpurun_out/parity_report.json $O/parity_r04.json 2>/dev/null
+  cp gpurun_out/parity_report.json $O/parity_$ROUND.json 2>/dev/null
   cat $O/pytest_gpu.txt
 }
 sec_reference() {

@@ -82,7 +82,12 @@ GRAD_FACTOR = 4.0                        # HIP-path error allowed as a multiple 
 # bf16x3; perceptual-loss input gradient 1.8e-3 / 3.9e-3) and tightened from 5e-3 / 2e-2 to 3e-3 / 6e-3.
 # fp16x3 (the benched arithmetic): its FORWARD is fp32-class, so the branch pattern - which is what these floors are about -
 # is the exact-fp32 kernels'; it gets their floors (measured worst: flow stage 6.3e-4, latent 3.7e-4, generator 7e-4)
-GRAD_FLOOR = {'fp32': (3e-3, 3e-3), 'bf16x3': (6e-3, 6e-3), 'fp16x3': (3e-3, 3e-3)}
+# Round 5: the library has been bitwise reproducible for two rounds, so the measured errors are the same on every box and
+# run (profiles/parity_r05.json); the floors were re-measured over all 118 (fixture, stage, mode) records and lowered to
+# <= 2x the worst: flow stage / generator fp32 9.2e-4, fp16x3 1.2e-3, bf16x3 3.1e-3; perceptual-loss input gradient
+# 1.8e-3 (fp32: its one flipped ReLU) / 4.8e-6 / 3.95e-3; latent learner (own scale LL_FLOOR_SCALE) 2.8e-4 / 3.1e-4 / 7.7e-4
+GRAD_FLOOR = {'fp32': (2.5e-3, 2.5e-3), 'bf16x3': (6e-3, 6e-3), 'fp16x3': (2e-3, 2e-3)}
+LL_FLOOR_SCALE = 0.5
 # the similarity stage additionally receives gradient through MipmapWarp's level selection, where a similarity warp
 # makes the four neighbour distances EXACTLY tied in real arithmetic: arg-max (and with it the sub-gradient) is decided
 # by last-ulp noise of the grid in every implementation, the reference's float32 and float64 runs included
@@ -90,7 +95,9 @@ GRAD_FLOOR = {'fp32': (3e-3, 3e-3), 'bf16x3': (6e-3, 6e-3), 'fp16x3': (3e-3, 3e-
 SIM_FACTOR = 8.0
 SIM_FLOOR_SCALE = 2.5                    # similarity-stage floors: 7.5e-3 / 1.5e-2 (round 2: 1.5e-2 / 6e-2; measured worst
                                          # outside c2_stn[1]: 3.2e-3 fp32, 1.17e-2 bf16x3 on cfg_c1)
-GRAD_MAX_ELEM = 5e-2                     # single entries, relative to the largest entry (measured worst: 3.0e-2)
+# single entries, relative to the largest entry (round 5 measured worst: fp32 7.0e-3, fp16x3 9.0e-3, bf16x3 3.0e-2; one
+# bound of 5e-2 for all modes before)
+GRAD_MAX_ELEM = {'fp32': 1.5e-2, 'fp16x3': 2e-2, 'bf16x3': 5e-2}
 
 
 def grad_errors(ours, ref32, ref64):
@@ -132,7 +139,7 @@ def check_grads(test, mode, grads, case, select=lambda name: True, factor=GRAD_F
         n_o = abs(norms[name] - n64) / n64
         n_r = abs(meta['grad_norms'][name] - n64) / n64
         rows.append((l2_o, l2_r, n_o, n_r, mx_o, mx_r, name))
-        if l2_o > max(factor * l2_r, l2_floor) or n_o > max(factor * n_r, n_floor) or mx_o > GRAD_MAX_ELEM:
+        if l2_o > max(factor * l2_r, l2_floor) or n_o > max(factor * n_r, n_floor) or mx_o > GRAD_MAX_ELEM[mode]:
             failures.append((name, 'l2', l2_o, l2_r, 'norm', n_o, n_r, 'max', mx_o, mx_r))
     worst = sorted(rows, reverse=True)[:3]
     PARITY.setdefault(test, {}).setdefault(mode, {})['gradients_vs_reference_fp64'] = dict(
@@ -150,7 +157,7 @@ def check_one_grad(test, mode, tensor, ours, ref32, ref64):
     l2_o, l2_r, mx_o, mx_r = grad_errors(ours, ref32, ref64)
     PARITY.setdefault(test, {}).setdefault(mode, {})[tensor + '_vs_reference_fp64'] = dict(
         rel_l2_err_ours=l2_o, rel_l2_err_reference_fp32=l2_r, max_entry_err_ours=mx_o, max_entry_err_reference_fp32=mx_r)
-    assert l2_o <= max(GRAD_FACTOR * l2_r, GRAD_FLOOR[mode][0]) and mx_o <= GRAD_MAX_ELEM, (l2_o, l2_r, mx_o, mx_r)
+    assert l2_o <= max(GRAD_FACTOR * l2_r, GRAD_FLOOR[mode][0]) and mx_o <= GRAD_MAX_ELEM[mode], (l2_o, l2_r, mx_o, mx_r)
 
 
 def load_det(module, rules=()):
@@ -254,7 +261,7 @@ def test_config_loss_step(name, mode, cuda):
     else:       # a single similarity STN: its parameters carry no `stns.N.` prefix
         check_grads(test + '/similarity-stage', mode, grads, c, select=lambda k: k != 'll.coefficients',
                     factor=SIM_FACTOR, floor_scale=SIM_FLOOR_SCALE)
-    check_grads(test + '/latent-learner', mode, grads, c, select=lambda k: k == 'll.coefficients')
+    check_grads(test + '/latent-learner', mode, grads, c, select=lambda k: k == 'll.coefficients', floor_scale=LL_FLOOR_SCALE)
 
 
 def test_config_c5_batch16_from_reference_halves(mode, cuda):
@@ -294,7 +301,8 @@ def test_config_c5_batch16_from_reference_halves(mode, cuda):
     check_grads(test + '/flow-stage', mode, grads, both, select=lambda k: k.startswith('stns.1.'), sample_norms=True)
     check_grads(test + '/similarity-stage', mode, grads, both, select=lambda k: k.startswith('stns.0.'),
                 factor=SIM_FACTOR, floor_scale=SIM_FLOOR_SCALE, sample_norms=True)
-    check_grads(test + '/latent-learner', mode, grads, both, select=lambda k: k == 'll.coefficients', sample_norms=True)
+    check_grads(test + '/latent-learner', mode, grads, both, select=lambda k: k == 'll.coefficients', sample_norms=True,
+                floor_scale=LL_FLOOR_SCALE)
 
 
 @pytest.mark.parametrize('case', load_golden('lpips'), ids=lambda c: 'lin' if c['meta']['lpips'] else 'baseline')
