@@ -54,6 +54,9 @@ for src, dst in ((f'parity_{ROUND}.json', f'parity_{ROUND}.json'), ('bench_fp16x
                  ('bench_c4_batch4_hipgraph.json', f'bench_{ROUND}_c4_batch4_hipgraph.json'),
                  ('bench_c5_batch4_hipgraph.json', f'bench_{ROUND}_c5_batch4_hipgraph.json'),
                  ('bench_c2_under_rocprofv3.json', f'bench_{ROUND}_fp16x3_under_rocprofv3.json'),
+                 ('bench_c4_under_rocprofv3.json', f'bench_{ROUND}_c4_batch16_under_rocprofv3.json'),
+                 ('bench_c5_under_rocprofv3.json', f'bench_{ROUND}_c5_batch16_under_rocprofv3.json'),
+                 ('smoke.txt', f'{ROUND}_smoke.txt'),
                  ('splat_bench.json', f'{ROUND}_splat_bench.json')):
     if os.path.exists(os.path.join(O, src)):
         shutil.copy(os.path.join(O, src), os.path.join(P, dst))

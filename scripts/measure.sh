@@ -3,6 +3,7 @@
 # arguments = the full session behind profiles/<round>_* and profiles/bench_<round>_*, copied by scripts/collect_profiles.py).
 # ROUND=r05 (default) names the output directory gpurun_out/$ROUND and the files; rounds 2 - 4 used earlier forms of this script:
 #
+#   smoke        __graft_entry__.smoke()
 #   suite        GPU test suite + parity report (-> parity_$ROUND.json)
 #   determinism  scripts/check_determinism.py on three configurations x three arithmetic modes
 #   bench        the driver's command, then every arithmetic mode / batch / workload (c4, c5 at batch 4 and 16)
@@ -28,6 +29,10 @@ SECTIONS="$*"
 [ -z "$SECTIONS" ] && SECTIONS="suite determinism bench layers trace pmc"
 B="python bench.py --no-cpu-baseline --no-extras"
 
+sec_smoke() {
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
+  tail -n 2 $O/smoke.txt
+}
 sec_suite() {
   timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/pytest_gpu.txt
   cp gpurun_out/parity_report.json $O/parity_$ROUND.json 2>/dev/null
@@ -42,19 +47,19 @@ sec_determinism() {
   cat $O/determinism.txt
 }
 sec_bench() {
+  # the driver's command (its extras carry bf16x3 / bf16 / hipGraph / batch 5 eager + replay / C4 and C5 at batch 16 /
+  # both drop-in routes), then the exact-fp32 mode
   python bench.py --steps 20 --warmup 5 > $O/bench_fp16x3.json 2> $O/bench_fp16x3.err
-  $B --steps 30 --warmup 5 --precision bf16x3 > $O/bench_bf16x3.json 2>/dev/null
   $B --steps 10 --warmup 3 --precision fp32 > $O/bench_fp32.json 2>/dev/null
-  $B --steps 30 --warmup 5 --precision bf16 > $O/bench_bf16.json 2>/dev/null
-  $B --steps 30 --warmup 5 --batch 5 > $O/bench_fp16x3_batch5.json 2>/dev/null
-  $B --steps 30 --warmup 5 --batch 5 --graph > $O/bench_fp16x3_batch5_hipgraph.json 2>/dev/null
-  [ -z "${QUICK:-}" ] && $B --steps 20 --warmup 5 --batch 32 > $O/bench_fp16x3_batch32.json 2>/dev/null
-  for w in c4 c5; do for b in 4 16; do
-    $B --workload $w --batch $b --steps 10 --warmup 3 > $O/bench_${w}_batch$b.json 2>/dev/null
-  done; done
   if [ -z "${QUICK:-}" ]; then
-    $B --workload c4 --batch 4 --steps 20 --warmup 5 --graph > $O/bench_c4_batch4_hipgraph.json 2>/dev/null
-    $B --workload c5 --batch 4 --steps 20 --warmup 5 --graph > $O/bench_c5_batch4_hipgraph.json 2>/dev/null
+    $B --steps 30 --warmup 5 --precision bf16x3 > $O/bench_bf16x3.json 2>/dev/null
+    $B --steps 30 --warmup 5 --precision bf16 > $O/bench_bf16.json 2>/dev/null
+    $B --steps 30 --warmup 5 --batch 5 > $O/bench_fp16x3_batch5.json 2>/dev/null
+    $B --steps 30 --warmup 5 --batch 5 --graph > $O/bench_fp16x3_batch5_hipgraph.json 2>/dev/null
+    $B --steps 20 --warmup 5 --batch 32 > $O/bench_fp16x3_batch32.json 2>/dev/null
+    for w in c4 c5; do for b in 4 16; do
+      $B --workload $w --batch $b --steps 10 --warmup 3 > $O/bench_${w}_batch$b.json 2>/dev/null
+    done; done
   fi
   head -c 600 $O/bench_fp16x3.json; echo
 }

@@ -95,18 +95,18 @@ def test_generator_gradient_is_exact_once_lrelu_decisions_are_pinned(mode, cuda)
         err = float((img.detach().cpu() - torch.from_numpy(case['img'])).abs().max())
         assert err <= 1e-4 * max(1.0, float(np.abs(case['img']).max())), err       # pinning does not move the forward
         (gw,) = torch.autograd.grad(img, w, D('actmask.gen.gimg', tuple(img.shape), cuda))
-        out[pin] = dict(rel_l2_vs_reference_fp32=rel_l2(gw.cpu().numpy(), case['gw']),
+        out['pinned' if pin else 'free'] = dict(rel_l2_vs_reference_fp32=rel_l2(gw.cpu().numpy(), case['gw']),
                         rel_l2_vs_reference_fp64=rel_l2(gw.cpu().numpy(), case['gw64']),
                         flips=pinner.flips, units=pinner.units)
     out['reference_fp32_vs_fp64'] = rel_l2(case['gw'], case['gw64'])
     PARITY.setdefault('act_masks[generator]', {})[mode] = out
     # only a handful of the 11 M units sit close enough to a kink to flip
-    assert out[False]['flips'] <= (64 if mode != 'bf16x3' else 512), out
+    assert out['free']['flips'] <= (64 if mode != 'bf16x3' else 512), out
     # with the reference's decisions, the reference's gradient: rounding of nine modulated layers (the data gradients of
     # fp16x3 run on binary16 limbs, of bf16x3 on bf16 limbs)
     bound = {'fp32': 2e-5, 'fp16x3': 2e-5, 'bf16x3': 2e-4}[mode]
-    assert out[True]['rel_l2_vs_reference_fp32'] <= bound, out
-    assert out[True]['rel_l2_vs_reference_fp32'] <= out[False]['rel_l2_vs_reference_fp32'] * 1.001 + 1e-7, out
+    assert out['pinned']['rel_l2_vs_reference_fp32'] <= bound, out
+    assert out['pinned']['rel_l2_vs_reference_fp32'] <= out['free']['rel_l2_vs_reference_fp32'] * 1.001 + 1e-7, out
 
 
 def test_stn_gradients_are_exact_once_lrelu_decisions_are_pinned(mode, cuda):
@@ -141,7 +141,7 @@ def test_stn_gradients_are_exact_once_lrelu_decisions_are_pinned(mode, cuda):
             errs = [(rel_l2(arrays['grad_' + k.replace('.', '_')], case['grad_' + k.replace('.', '_')]), k)
                     for k in names if k.startswith(stage)]
             per_stage[stage] = max(errs)
-        out[pin] = dict(flips=pinner.flips, units=pinner.units,
+        out['pinned' if pin else 'free'] = dict(flips=pinner.flips, units=pinner.units,
                         flow_stage_worst_rel_l2_vs_reference_fp32=per_stage['stns.1.'][0],
                         flow_stage_worst_param=per_stage['stns.1.'][1],
                         similarity_stage_worst_rel_l2_vs_reference_fp32=per_stage['stns.0.'][0],
@@ -150,8 +150,8 @@ def test_stn_gradients_are_exact_once_lrelu_decisions_are_pinned(mode, cuda):
               for k in names if k.startswith('stns.1.'))
     out['reference_fp32_vs_fp64_flow_stage_worst'] = ref
     PARITY.setdefault('act_masks[stn]', {})[mode] = out
-    assert out[False]['flips'] <= (256 if mode != 'bf16x3' else 2048), out
+    assert out['free']['flips'] <= (256 if mode != 'bf16x3' else 2048), out
     # flow stage: every leaky-ReLU decision of its trunk is pinned; what is left un-pinned on its gradient path are the two
     # plain ReLUs of the RAFT head (warping_heads.py:130-135) and the similarity stage's output it consumes
     bound = {'fp32': 1e-4, 'fp16x3': 1e-4, 'bf16x3': 1e-3}[mode]
-    assert out[True]['flow_stage_worst_rel_l2_vs_reference_fp32'] <= bound, out
+    assert out['pinned']['flow_stage_worst_rel_l2_vs_reference_fp32'] <= bound, out

@@ -93,8 +93,9 @@ LL_FLOOR_SCALE = 0.5
 # by last-ulp noise of the grid in every implementation, the reference's float32 and float64 runs included
 # (measured worst case, c2_stn[1]: 7.9e-3 fp32 / 1.8e-2 bf16x3 against the reference's own 4.3e-3)
 SIM_FACTOR = 8.0
-SIM_FLOOR_SCALE = 2.5                    # similarity-stage floors: 7.5e-3 / 1.5e-2 (round 2: 1.5e-2 / 6e-2; measured worst
-                                         # outside c2_stn[1]: 3.2e-3 fp32, 1.17e-2 bf16x3 on cfg_c1)
+# similarity-stage floors stay at round 3's 7.5e-3 (fp32, fp16x3) / 1.5e-2 (bf16x3), as multiples of GRAD_FLOOR (round 5
+# measured worst outside c2_stn[1]: fp32 5.5e-3, fp16x3 7.9e-3 on cfg_c2t against the reference's own 1.1e-3, bf16x3 6.2e-3)
+SIM_FLOOR_SCALE = {'fp32': 3.0, 'fp16x3': 3.75, 'bf16x3': 2.5}
 # single entries, relative to the largest entry (round 5 measured worst: fp32 7.0e-3, fp16x3 9.0e-3, bf16x3 3.0e-2; one
 # bound of 5e-2 for all modes before)
 GRAD_MAX_ELEM = {'fp32': 1.5e-2, 'fp16x3': 2e-2, 'bf16x3': 5e-2}
@@ -130,6 +131,8 @@ def check_grads(test, mode, grads, case, select=lambda name: True, factor=GRAD_F
     meta = case['meta']
     names = [k for k in meta['grad_norms'] if select(k)]
     assert set(norms) >= set(names)
+    if isinstance(floor_scale, dict):
+        floor_scale = floor_scale[mode]
     n_floor, l2_floor = GRAD_FLOOR[mode][1] * floor_scale, GRAD_FLOOR[mode][0] * floor_scale
     rows, failures = [], []
     for name in names:
