@@ -41,10 +41,15 @@ def sample_gan_supervised_pairs(generator, ll, resize_fake2stn, psi, batch, dim_
     if z is None:
         z = torch.randn(batch, dim_latent, device=device)
     # measured (MI355X, C2): +3.5 % at per-GPU batch 5, +0.6 % at batch 16 - while every kernel's own duration
-    # roughly doubles under the contention, which would blur the per-kernel roofline measurement.  Hence: automatic for
-    # small batches (the reference recipes use 5 per GPU), opt-in (GG_ENABLE=two_streams) otherwise.
+    # roughly doubles under the contention, which would blur the per-kernel roofline measurement.
+    # Round 5: OPT-IN only (GG_ENABLE=two_streams).  Rounds 2 - 4 forked automatically at batches <= 8; this round's
+    # repeated determinism runs (profiles/r05_d_two_stream_determinism.txt) found that with the fork 5 % of the runs of
+    # one small configuration (K = 2 heads, flips, full-resolution sampling, batch 2) differ from their twin in the
+    # first forked iteration - with round 4's kernels as well as this round's; 0 of 74 without the fork.  The shared
+    # state the two streams race on has not been located, so the library's bitwise-reproducibility claim is kept by
+    # not forking.
     overlap = (isinstance(generator, torch.nn.Module) and z.is_cuda and hasattr(generator, 'get_latent') and
-               'two_streams' not in conv_mfma.DISABLED and (batch <= 8 or 'two_streams' in conv_mfma.ENABLED))
+               'two_streams' not in conv_mfma.DISABLED and 'two_streams' in conv_mfma.ENABLED)
     if overlap:
         # Everything derived from the frozen weights (GEMM-layout packs, squared-weight tables, scaled EqualLinear
         # weights, style-bank job tables) is built lazily by whichever pass touches a layer first and then cached on

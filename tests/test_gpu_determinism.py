@@ -12,7 +12,8 @@ CONFIGS = {
     # and generic weight gradients the benchmark runs
     'c2-batch16': dict(gen_size=256, flow_size=128, batch=16, transform=('similarity', 'flow'), inject=5, ndirs=1,
                        perturb_heads=0.02),
-    # small: two-stream generator passes (batch <= 8), similarity-only and clustering heads
+    # small: the batch sizes at which rounds 2 - 4 forked the generator passes onto two streams (opt-in since round 5:
+    # losses.sample_gan_supervised_pairs), similarity-only and clustering heads
     'small-flow': dict(gen_size=64, flow_size=64, batch=2, transform=('similarity', 'flow'), inject=3, ndirs=2,
                        perturb_heads=0.02),
     'small-cluster': dict(gen_size=64, flow_size=64, batch=2, transform=('similarity', 'flow'), inject=3, ndirs=2,
