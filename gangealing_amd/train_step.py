@@ -547,10 +547,11 @@ class GangealingTrainer:
             self._capture_segments()
         g1, g2, g3, g4 = self._segments
         cap = torch.cuda.current_stream()
+        if self._pending_work is not None:
+            self._upd_stream.wait_stream(cap)          # the update stream continues from the END of the previous step ...
         self._upload(self._psi_dev, [float(psi)])
-        g1.replay()
-        if self._pending_work is not None:             # the previous iteration's STN update, beside this one's g1
-            self._upd_stream.wait_stream(cap)          # (after the upload queue: the ring's events are recorded on `cap`)
+        g1.replay()                                    # ... so that what it does next runs BESIDE this step's generator passes
+        if self._pending_work is not None:             # the previous iteration's STN update
             with torch.cuda.stream(self._upd_stream):
                 self._finish_pending_replay()
             cap.wait_stream(self._upd_stream)
