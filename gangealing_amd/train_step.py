@@ -247,6 +247,19 @@ class GangealingTrainer:
         # per-GPU batches <= 8, where the eager step is bound by the host's launch rate (the reference recipe: 5 per
         # GPU); eager launches at larger batches, where the GPU is the bound and replay buys nothing.
         self.use_graph = (batch <= 8) if use_graph == 'auto' else bool(use_graph)
+        if self.use_graph and self.collectives and 'graph_segments' not in conv_mfma.ENABLED:
+            # Round 5: the four-graph replay is WITHDRAWN from the default route.  With the generator passes on one
+            # stream, the SECOND replay of the segments produced NaN gradients in sessions 7 - 9 (3 of 3 test runs, both
+            # with and without a flush between the steps), but not in session 10 (same code, eight other processes on the
+            # GPU); with the passes forked onto two streams it passed 2 of 2.  The cause is not located
+            # (profiles/r05_e_segment_replay_nan.txt), so the route is opt-in for debugging only: GG_ENABLE=graph_segments.
+            if use_graph == 'auto':
+                self.use_graph = False
+            else:
+                raise RuntimeError('GangealingTrainer(use_graph=True) with collectives (world > 1): the segmented hipGraph '
+                                   'replay is withdrawn (NaN at the second replay in some sessions, see '
+                                   'profiles/r05_e_segment_replay_nan.txt); use eager steps (use_graph=False or "auto"), '
+                                   'or opt in with GG_ENABLE=graph_segments')
         self._graph = None
         self._segments = None          # (g1, g2, g3, g4) with collectives
         self._capture_switch = None    # set while the segments are being captured (see _before_stn_forward)

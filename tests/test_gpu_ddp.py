@@ -136,7 +136,7 @@ def _graph_worker(rank, world, port, q):
     all-reduces between them (train_step.py: _capture_segments / _segment_step_on_stream)."""
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY='0')
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY='0', GG_ENABLE='graph_segments')
     import torch.distributed as dist
     from gangealing_amd import distributed as gdist
     from gangealing_amd.train_step import GangealingTrainer
@@ -184,6 +184,61 @@ def _graph_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+SEGMENTS_WITHDRAWN = pytest.mark.skipif(
+    os.environ.get('GG_TEST_GRAPH_SEGMENTS') != '1',
+    reason='segmented hipGraph replay of the multi-process step is withdrawn (NaN at the second replay in sessions 7-9 and '
+           '11 of round 5, cause not located: profiles/r05_e_segment_replay_nan.txt); GG_TEST_GRAPH_SEGMENTS=1 runs it')
+
+
+def _withdrawn_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    os.environ.pop('GG_ENABLE', None)
+    import torch.distributed as dist
+    from gangealing_amd import distributed as gdist
+    from gangealing_amd.train_step import GangealingTrainer
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    assert gdist.setup_distributed('gloo') is True
+    result = dict(rank=rank)
+    try:
+        try:
+            GangealingTrainer(dev, use_graph=True, **KW)
+            result['raised'] = False
+        except RuntimeError as e:
+            result['raised'] = 'withdrawn' in str(e)
+        tr = GangealingTrainer(dev, use_graph='auto', **KW)        # batch 2 <= 8: 'auto' would pick replay in one process
+        result['auto_is_eager'] = tr.collectives and not tr.use_graph
+        parts = tr.step(psi=0.5)
+        tr.flush()
+        result['finite'] = bool(torch.isfinite(parts['p']))
+    except Exception as e:
+        import traceback
+        result['error'] = ''.join(traceback.format_exception(type(e), e, e.__traceback__))[-3000:]
+    q.put(result)
+    gdist.synchronize()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_graph_replay_is_withdrawn(cuda):
+    """use_graph=True with collectives raises (the segmented replay is opt-in while its NaN is not located) and
+    use_graph='auto' falls back to the eager pipelined step, which trains."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_withdrawn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for res in results:
+        assert 'error' not in res, res['error']
+        assert res['raised'] is True and res['auto_is_eager'] and res['finite']
+
+
+@SEGMENTS_WITHDRAWN
 def test_two_ranks_graph_replay_segments(cuda):
     """hipGraph replay of the multi-process step (the reference's own recipe is 8 GPUs x batch 5, where the eager step is
     bound by the host): replicas bit-identical after every flush() and after un-flushed (pipelined) replays, the ranks
