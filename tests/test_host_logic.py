@@ -406,3 +406,70 @@ def test_limb_format_rule_follows_the_kernel_that_serves_the_shape():
             cm.set_precision('fp8')
     finally:
         cm.set_precision(saved)
+
+
+def test_launcher_standins_for_an_offline_box(tmp_path):
+    """gangealing_amd/_standins.py: what `launch.stub_missing` installs into the modules it had to stub so that the
+    reference's train.py runs where torchvision / tensorboard are absent.  VGG16: the layer list of configuration 'D'
+    (the convolution indices are the keys the reference's checkpoints carry, lpips_backbones.py:101-121); make_grid:
+    torchvision's geometry (utils/vis_tools/helpers.py:37-41 feeds it); SummaryWriter: scalars as JSON lines."""
+    import json
+    import torch
+    from gangealing_amd import _standins
+    feats = _standins.vgg16().features
+    convs = [i for i, m in enumerate(feats) if isinstance(m, torch.nn.Conv2d)]
+    pools = [i for i, m in enumerate(feats) if isinstance(m, torch.nn.MaxPool2d)]
+    assert len(feats) == 31 and convs == [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28] and pools == [4, 9, 16, 23, 30]
+    assert [feats[i].out_channels for i in convs] == [64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512]
+    assert feats[0].in_channels == 3 and all(feats[i].kernel_size == (3, 3) and feats[i].padding == (1, 1) for i in convs)
+    with pytest.raises(RuntimeError):
+        _standins.vgg16(pretrained=True)
+    # make_grid: 5 images, 3 per row, padding 2 -> 2 rows x 3 columns of (H + 2, W + 2) cells plus the closing border
+    x = torch.arange(5 * 3 * 4 * 6, dtype=torch.float32).view(5, 3, 4, 6)
+    g = _standins.make_grid(x, nrow=3, padding=2, pad_value=-1.0)
+    assert tuple(g.shape) == (3, 2 * (4 + 2) + 2, 3 * (6 + 2) + 2)
+    assert torch.equal(g[:, 2:6, 2:8], x[0]) and torch.equal(g[:, 2:6, 10:16], x[1]) and torch.equal(g[:, 8:12, 2:8], x[3])
+    assert float(g[0, 0, 0]) == -1.0 and float(g[0, 8, 20]) == -1.0              # border; the empty sixth cell
+    n = _standins.make_grid(x, nrow=3, normalize=True)
+    assert float(n.max()) == 1.0 and float(n[:, 2:6, 2:8].min()) == 0.0
+    e = _standins.make_grid(x, nrow=5, normalize=True, value_range=(0.0, 1000.0))
+    assert abs(float(e[0, 2, 2 + 8]) - float(x[1, 0, 0, 0]) / 1000.0) < 1e-6
+    one = _standins.make_grid(torch.ones(2, 1, 4, 4), nrow=2, padding=0)           # single-channel images become RGB
+    assert tuple(one.shape) == (3, 4, 8)
+    w = _standins.SummaryWriter(str(tmp_path / 'logs'))
+    w.add_scalar('loss/p', torch.tensor(0.25), 7)
+    w.add_image('ignored', x[0], 7)
+    w.add_scalar('lr', 1e-3, 8)
+    w.close()
+    rows = [json.loads(ln) for ln in open(tmp_path / 'logs' / 'scalars.jsonl')]
+    assert rows == [{'tag': 'loss/p', 'value': 0.25, 'step': 7}, {'tag': 'lr', 'value': 1e-3, 'step': 8}]
+    with pytest.raises(AttributeError):
+        w.no_such_method
+
+
+def test_stub_missing_installs_working_standins_only_where_a_package_is_absent():
+    """launch.stub_missing in a child interpreter: a package that imports is left alone; torchvision / tensorboard, when
+    absent, become stubs whose `vgg16`, `make_grid`, `SummaryWriter` are the functional stand-ins."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, importlib\n"
+        "sys.path.insert(0, %r)\n"
+        "from gangealing_amd import launch, _standins\n"
+        "import numpy\n"
+        "launch.stub_missing(names=('numpy', 'torchvision', 'torchvision.models', 'torchvision.utils', "
+        "'no_such_pkg_xyz', 'no_such_pkg_xyz.sub'))\n"
+        "assert sys.modules['numpy'] is numpy and not isinstance(numpy, launch._Stub)\n"
+        "import no_such_pkg_xyz\n"
+        "from no_such_pkg_xyz import sub\n"
+        "assert isinstance(no_such_pkg_xyz, launch._Stub) and no_such_pkg_xyz.Anything()() is None\n"
+        "tv = sys.modules['torchvision']\n"
+        "if isinstance(tv, launch._Stub):\n"
+        "    from torchvision import models\n"
+        "    from torchvision.utils import make_grid\n"
+        "    assert models.vgg16 is _standins.vgg16 and make_grid is _standins.make_grid\n"
+        "    print('stubbed')\n"
+        "else:\n"
+        "    print('installed')\n" % REPO)
+    res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.strip() in ('stubbed', 'installed'), res.stderr[-2000:]
