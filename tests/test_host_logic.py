@@ -473,3 +473,20 @@ def test_stub_missing_installs_working_standins_only_where_a_package_is_absent()
         "    print('installed')\n" % REPO)
     res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and res.stdout.strip() in ('stubbed', 'installed'), res.stderr[-2000:]
+
+
+def test_committed_pmc_traffic_belongs_to_this_trees_kernels():
+    """bench.py reports `roofline.traffic` only while the kernel-source hash recorded with the committed PMC passes equals
+    the tree's.  This guards the pairing: editing a convolution translation unit without re-running the `pmc` section of
+    scripts/measure.sh (+ collect_profiles.py) would silently turn the driver line's `traffic` into null."""
+    import json
+    sys.path.insert(0, REPO)
+    import bench
+    with open(os.path.join(REPO, 'profiles', 'r05_pmc_traffic.json')) as f:
+        rec = json.load(f)
+    assert rec['kernel_source_sha16'] == bench.kernel_source_hash(), \
+        'convolution sources changed after profiles/r05_pmc_traffic.json was measured: re-run the pmc passes'
+    traffic = bench.pmc_traffic('fp16x3', 'c2', 16)
+    assert traffic == rec['hbm_bytes_per_launch'] and 6e8 < traffic < 1.2e9          # ~1.3x the 626 MB algorithmic bytes
+    alg = rec['algorithmic_bytes_per_launch']
+    assert abs(alg['activations_in'] + alg['activations_out'] - 626.3e6) < 1e6
