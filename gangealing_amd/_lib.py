@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GANGEALING_HIP_LIB selects another build of the same library (kernel A/B measurements); the ABI check still applies.
 LIB_PATH = os.environ.get('GANGEALING_HIP_LIB') or os.path.join(_HERE, 'lib', 'libgangealing_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 NOT_SERVED = -1000            # GG_NOT_SERVED of the header
 
 # signature alphabet: p device pointer (tensor or None), i int, q long long, f float, d double, s stream
@@ -34,8 +34,8 @@ _PROTOS = {
     'gg_splat2d_f32': 'ppppppiiiiiis',
     'gg_mip_downsample2x_f32': 'ppiiis',
     'gg_mip_downsample2x_bwd_f32': 'ppiiis',
-    'gg_mipmap_warp_fwd_f32': 'pppppppiiiiiiiiiffiis',
-    'gg_mipmap_warp_bwd_f32': 'pppppppppppiiiiiiiiiffiis',
+    'gg_mipmap_warp_fwd_f32': 'ppppipiiiiiiiiiffiis',
+    'gg_mipmap_warp_bwd_f32': 'ppppppipiiiiiiiiiffiis',
     'gg_mipmap_warp_indices_f32': 'pppppiiiiiffiis',
     'gg_affine_grid_f32': 'ppiiis',
     'gg_affine_grid_bwd_f32': 'ppiiis',

@@ -40,6 +40,8 @@ def make_grid(tensor, nrow=8, padding=2, normalize=False, range=None, value_rang
     bottom, `nrow` per row; normalize maps [low, high] (given, or each image's / the batch's min and max) to [0, 1]."""
     if isinstance(tensor, (list, tuple)):
         tensor = torch.stack(list(tensor), 0)
+    if tensor.dim() == 2:                    # a single (H, W) image
+        tensor = tensor.unsqueeze(0)
     if tensor.dim() == 3:
         tensor = tensor.unsqueeze(0)
     tensor = tensor.detach().float().clone()
@@ -54,6 +56,8 @@ def make_grid(tensor, nrow=8, padding=2, normalize=False, range=None, value_rang
                 norm_(t, *(rng if rng is not None else (float(t.min()), float(t.max()))))
         else:
             norm_(tensor, *(rng if rng is not None else (float(tensor.min()), float(tensor.max()))))
+    if tensor.size(0) == 1:                  # torchvision hands a single image back as it is: no padding frame
+        return tensor.squeeze(0)
     n, c, h, w = tensor.shape
     cols = min(nrow, n)
     rows = int(math.ceil(n / cols))

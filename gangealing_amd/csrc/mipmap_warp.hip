@@ -239,8 +239,30 @@ __device__ __forceinline__ Taps make_taps(const float* g, int h, int w, int padd
   return t;
 }
 
-struct Pyr { const float* p[4]; };
-struct GPyr { float* p[4]; };
+// Un-upsampled pyramid: level 0 = the (padded) image, levels 1 .. nlev-1 consecutively in ONE buffer (`rest`), level l
+// as (planes, hp >> l, wp >> l).  MAXL = how many level pointers a kernel instantiation carries: 4 (the heads'
+// max_num_levels = 3.5, warping_heads.py:32,170 - the training path) or 8 (the reference's default constructor,
+// antialiased_sampling.py:22: levels up to 7).  A lane picks its two levels from the array with a select chain, so the
+// 4-level instantiation keeps the training path at its round-1..5 cost.
+constexpr int kMaxLevels = 8;
+template <int MAXL> struct PyrT { const float* p[MAXL]; };
+template <int MAXL> struct GPyrT { float* p[MAXL]; };
+
+template <int MAXL, typename P, typename T>
+P make_pyr(T* base, T* rest, int nlev, long long planes, int hp, int wp) {
+  P r;
+  long long off = 0;
+  for (int l = 0; l < MAXL; ++l) {
+    if (l == 0) { r.p[0] = base; continue; }
+    if (l < nlev && rest) {
+      r.p[l] = rest + off;
+      off += planes * (long long)(hp >> l) * (wp >> l);
+    } else {
+      r.p[l] = r.p[l - 1];          // never selected: levels are clamped to nlev - 1
+    }
+  }
+  return r;
+}
 
 // Values of the 4 bilinear taps (nw, ne, sw, se) of stack level `lvl`, channel plane `plane`.
 __device__ __forceinline__ void tap_values(const float* __restrict__ img, int wl, const Axis ay[2], const Axis ax[2],
@@ -275,10 +297,11 @@ __device__ __forceinline__ void make_axes(const Taps& t, int lvl, int h, int w, 
 
 // ---------------------------------------------------------------- forward
 
+template <int MAXL>
 __global__ __launch_bounds__(256) void mipmap_warp_fwd_kernel(
-    float* __restrict__ out, float* __restrict__ levels_out, Pyr pyr, const float* __restrict__ grid, int n, int c,
+    float* __restrict__ out, float* __restrict__ levels_out, PyrT<MAXL> pyr, const float* __restrict__ grid, int n, int c,
     int h, int w, int hp, int wp, int pad_l, int ho, int wo, float max_level, float min_level, int padding_mode,
-    int antialias) {
+    int antialias, int top) {
   const long long total = (long long)n * ho * wo;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
@@ -294,6 +317,10 @@ __global__ __launch_bounds__(256) void mipmap_warp_fwd_kernel(
       li.level = 0.f; li.lo = 0; li.hi = 0; li.frac = 0.f;
     }
     if (levels_out) levels_out[o] = li.level;
+    // `top` = the deepest level the pyramid holds (its 1 x 1 level at the latest): a deeper request - where the
+    // reference's ReflectionPad2d(1) of a 1 x 1 map raises (antialiased_sampling.py:117) - samples that level
+    li.lo = min(li.lo, top);
+    li.hi = min(li.hi, top);
     const Taps t = make_taps(grid_n + ((size_t)oy * wo + ox) * 2, h, w, padding_mode);
     const float wt[4] = {t.wy0 * t.wx0, t.wy0 * t.wx1, t.wy1 * t.wx0, t.wy1 * t.wx1};
     Axis ay0[2], ax0[2], ay1[2], ax1[2];
@@ -370,11 +397,12 @@ __device__ __forceinline__ void scatter_taps(float* __restrict__ gimg, int wl, c
   }
 }
 
+template <int MAXL>
 __global__ __launch_bounds__(256) void mipmap_warp_bwd_kernel(
-    float* __restrict__ ggrid, GPyr gpyr, const float* __restrict__ gout, Pyr pyr, const float* __restrict__ grid,
-    int n, int c, int h, int w, int hp, int wp, int pad_l, int ho, int wo, float max_level, float min_level,
-    int padding_mode, int antialias, int want_image_grad, int* __restrict__ nb_target,
-    float2* __restrict__ nb_grad) {
+    float* __restrict__ ggrid, GPyrT<MAXL> gpyr, const float* __restrict__ gout, PyrT<MAXL> pyr,
+    const float* __restrict__ grid, int n, int c, int h, int w, int hp, int wp, int pad_l, int ho, int wo,
+    float max_level, float min_level, int padding_mode, int antialias, int want_image_grad,
+    int* __restrict__ nb_target, float2* __restrict__ nb_grad, int top) {
   const long long total = (long long)n * ho * wo;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
@@ -390,6 +418,8 @@ __global__ __launch_bounds__(256) void mipmap_warp_bwd_kernel(
     } else {
       li.level = 0.f; li.lo = 0; li.hi = 0; li.frac = 0.f; li.arg = -1; li.dcoef = 0.f; li.ddx = li.ddy = 0.f;
     }
+    li.lo = min(li.lo, top);
+    li.hi = min(li.hi, top);
     const Taps t = make_taps(grid_n + ((size_t)oy * wo + ox) * 2, h, w, padding_mode);
     const float wt[4] = {t.wy0 * t.wx0, t.wy0 * t.wx1, t.wy1 * t.wx0, t.wy1 * t.wx1};
     Axis ay0[2], ax0[2], ay1[2], ax1[2];
@@ -491,7 +521,7 @@ int check_common(const float* grid, int n, int c, int h, int w, int hp, int wp, 
   }
   if (hp != wp || (hp & (hp - 1)) != 0 || hp < h + pad_l || wp < w + pad_l || pad_l < 0)
     return gg::fail(-2, "mipmap_warp: pyramid base must be a square power of two covering the padded input");
-  if (hp < 8) return gg::fail(-2, "mipmap_warp: pyramid base must be at least 8x8");
+  if (hp < 2) return gg::fail(-2, "mipmap_warp: pyramid base must be at least 2x2");
   return 0;
 }
 
@@ -516,20 +546,47 @@ extern "C" int gg_mip_downsample2x_bwd_f32(float* grad_in, const float* grad_out
   return gg::launch_status("mip_downsample2x_bwd");
 }
 
-extern "C" int gg_mipmap_warp_fwd_f32(float* out, float* levels_out, const float* pyr0, const float* pyr1,
-                                      const float* pyr2, const float* pyr3, const float* grid, int n, int c, int h,
-                                      int w, int hp, int wp, int pad_l, int ho, int wo, float max_level,
-                                      float min_level, int padding_mode, int antialias, void* stream) {
+// num_levels: how many pyramid levels the caller built (level 0 = pyr0, 1 .. num_levels-1 in pyr_rest); the sampling
+// needs ceil(max_level) + 1 of them unless the pyramid ends earlier at its 1 x 1 level.
+static int check_levels(const char* who, int antialias, float max_level, int num_levels, const void* rest, int hp,
+                        int* top) {
+  *top = 0;
+  if (!antialias) return 0;
+  if (!(max_level >= 0.f) || max_level > (float)(kMaxLevels - 1))
+    return gg::fail(-2, "%s: max_level must be in [0, %d] (max_num_levels <= %d)", who, kMaxLevels - 1, kMaxLevels);
+  int avail = 1;
+  while ((hp >> avail) >= 1 && avail < kMaxLevels) ++avail;          // levels down to 1 x 1
+  int need = (int)ceilf(max_level) + 1;
+  if (need > avail) need = avail;
+  if (num_levels < need || num_levels > kMaxLevels || (num_levels > 1 && !rest))
+    return gg::fail(-2, "%s: antialias with max_level %g on a %d-pixel base needs %d pyramid levels, got %d", who,
+                    (double)max_level, hp, need, num_levels);
+  *top = num_levels - 1;
+  return 0;
+}
+
+extern "C" int gg_mipmap_warp_fwd_f32(float* out, float* levels_out, const float* pyr0, const float* pyr_rest,
+                                      int num_levels, const float* grid, int n, int c, int h, int w, int hp, int wp,
+                                      int pad_l, int ho, int wo, float max_level, float min_level, int padding_mode,
+                                      int antialias, void* stream) {
   int rc = check_common(grid, n, c, h, w, hp, wp, pad_l, ho, wo, padding_mode, antialias);
   if (rc) return rc;
   const long long total = (long long)n * ho * wo;
   if (total == 0 || c == 0) return 0;
   if (!out || !pyr0) return gg::fail(-2, "mipmap_warp_fwd: null pointer");
-  if (antialias && (max_level > 3.f || !pyr1 || !pyr2 || !pyr3))
-    return gg::fail(-2, "mipmap_warp_fwd: antialias needs 4 pyramid levels and max_level <= 3");
-  Pyr pyr{{pyr0, pyr1, pyr2, pyr3}};
-  mipmap_warp_fwd_kernel<<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(
-      out, levels_out, pyr, grid, n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, padding_mode, antialias);
+  int top;
+  if ((rc = check_levels("mipmap_warp_fwd", antialias, max_level, num_levels, pyr_rest, hp, &top))) return rc;
+  const long long planes = (long long)n * c;
+  hipStream_t st = gg::as_stream(stream);
+  if (top < 4) {
+    auto pyr = make_pyr<4, PyrT<4>>(pyr0, pyr_rest, top + 1, planes, hp, wp);
+    mipmap_warp_fwd_kernel<4><<<gg::stream_grid(total, 256), 256, 0, st>>>(
+        out, levels_out, pyr, grid, n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, padding_mode, antialias, top);
+  } else {
+    auto pyr = make_pyr<8, PyrT<8>>(pyr0, pyr_rest, top + 1, planes, hp, wp);
+    mipmap_warp_fwd_kernel<8><<<gg::stream_grid(total, 256), 256, 0, st>>>(
+        out, levels_out, pyr, grid, n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, padding_mode, antialias, top);
+  }
   return gg::launch_status("mipmap_warp_fwd");
 }
 
@@ -538,7 +595,8 @@ extern "C" int gg_mipmap_warp_indices_f32(int* ix_nw, int* iy_nw, int* lvl_floor
                                           int padding_mode, int antialias, void* stream) {
   if (n < 0 || h <= 0 || w <= 0 || ho < 0 || wo < 0 || !grid) return gg::fail(-2, "mipmap_warp_indices: bad sizes");
   if (padding_mode < 0 || padding_mode > 2) return gg::fail(-2, "mipmap_warp_indices: padding_mode must be 0, 1 or 2");
-  if (antialias && max_level > 3.f) return gg::fail(-2, "mipmap_warp_indices: max_level <= 3");
+  if (antialias && (!(max_level >= 0.f) || max_level > (float)(kMaxLevels - 1)))
+    return gg::fail(-2, "mipmap_warp_indices: max_level must be in [0, 7]");
   const long long total = (long long)n * ho * wo;
   if (total == 0) return 0;
   mipmap_warp_indices_kernel<<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(
@@ -546,21 +604,20 @@ extern "C" int gg_mipmap_warp_indices_f32(int* ix_nw, int* iy_nw, int* lvl_floor
   return gg::launch_status("mipmap_warp_indices");
 }
 
-extern "C" int gg_mipmap_warp_bwd_f32(float* grad_grid, float* grad_pyr0, float* grad_pyr1, float* grad_pyr2,
-                                      float* grad_pyr3, const float* grad_out, const float* pyr0, const float* pyr1,
-                                      const float* pyr2, const float* pyr3, const float* grid, int n, int c, int h,
-                                      int w, int hp, int wp, int pad_l, int ho, int wo, float max_level,
-                                      float min_level, int padding_mode, int antialias, void* stream) {
+extern "C" int gg_mipmap_warp_bwd_f32(float* grad_grid, float* grad_pyr0, float* grad_pyr_rest, const float* grad_out,
+                                      const float* pyr0, const float* pyr_rest, int num_levels, const float* grid,
+                                      int n, int c, int h, int w, int hp, int wp, int pad_l, int ho, int wo,
+                                      float max_level, float min_level, int padding_mode, int antialias, void* stream) {
   int rc = check_common(grid, n, c, h, w, hp, wp, pad_l, ho, wo, padding_mode, antialias);
   if (rc) return rc;
   const long long total = (long long)n * ho * wo;
   if (total == 0) return 0;
   if (!grad_grid || !grad_out || !pyr0) return gg::fail(-2, "mipmap_warp_bwd: null pointer");
-  if (antialias && (max_level > 3.f || !pyr1 || !pyr2 || !pyr3))
-    return gg::fail(-2, "mipmap_warp_bwd: antialias needs 4 pyramid levels and max_level <= 3");
+  int top;
+  if ((rc = check_levels("mipmap_warp_bwd", antialias, max_level, num_levels, pyr_rest, hp, &top))) return rc;
   const int want_img = grad_pyr0 != nullptr;
-  if (want_img && antialias && (!grad_pyr1 || !grad_pyr2 || !grad_pyr3))
-    return gg::fail(-2, "mipmap_warp_bwd: image gradient needs all 4 grad_pyr levels");
+  if (want_img && antialias && top > 0 && !grad_pyr_rest)
+    return gg::fail(-2, "mipmap_warp_bwd: the image gradient needs grad_pyr_rest (same layout as pyr_rest)");
   hipStream_t st = gg::as_stream(stream);
   if (c == 0) {
     hipError_t e = hipMemsetAsync(grad_grid, 0, sizeof(float) * (size_t)total * 2, st);
@@ -576,12 +633,20 @@ extern "C" int gg_mipmap_warp_bwd_f32(float* grad_grid, float* grad_pyr0, float*
     nb_grad = reinterpret_cast<float2*>(sc);
     nb_target = reinterpret_cast<int*>(sc + (size_t)total * 8);
   }
-  Pyr pyr{{pyr0, pyr1, pyr2, pyr3}};
-  GPyr gp{{grad_pyr0, grad_pyr1, grad_pyr2, grad_pyr3}};
-  mipmap_warp_bwd_kernel<<<gg::stream_grid(total, 256), 256, 0, st>>>(grad_grid, gp, grad_out, pyr, grid, n, c, h, w,
-                                                                      hp, wp, pad_l, ho, wo, max_level, min_level,
-                                                                      padding_mode, antialias, want_img, nb_target,
-                                                                      nb_grad);
+  const long long planes = (long long)n * c;
+  if (top < 4) {
+    auto pyr = make_pyr<4, PyrT<4>>(pyr0, pyr_rest, top + 1, planes, hp, wp);
+    auto gp = make_pyr<4, GPyrT<4>>(grad_pyr0, grad_pyr_rest, top + 1, planes, hp, wp);
+    mipmap_warp_bwd_kernel<4><<<gg::stream_grid(total, 256), 256, 0, st>>>(
+        grad_grid, gp, grad_out, pyr, grid, n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, padding_mode,
+        antialias, want_img, nb_target, nb_grad, top);
+  } else {
+    auto pyr = make_pyr<8, PyrT<8>>(pyr0, pyr_rest, top + 1, planes, hp, wp);
+    auto gp = make_pyr<8, GPyrT<8>>(grad_pyr0, grad_pyr_rest, top + 1, planes, hp, wp);
+    mipmap_warp_bwd_kernel<8><<<gg::stream_grid(total, 256), 256, 0, st>>>(
+        grad_grid, gp, grad_out, pyr, grid, n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, padding_mode,
+        antialias, want_img, nb_target, nb_grad, top);
+  }
   rc = gg::launch_status("mipmap_warp_bwd");
   if (rc || !antialias) return rc;
   mipmap_warp_bwd_gather_kernel<<<gg::stream_grid(total, 256), 256, 0, st>>>(grad_grid, nb_target, nb_grad, total, ho,

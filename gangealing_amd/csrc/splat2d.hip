@@ -403,6 +403,15 @@ extern "C" int gg_splat_forward_f32(const float* coords, const float* values, co
   return gg::launch_status("splat_forward");
 }
 
+// the reference's symbol (splat_gpu_impl.cuh:11-22): stream first, no status
+extern "C" void SplatForwardGpu(void* stream, const float* bottom_coordinates, const float* bottom_values,
+                                const float* bottom_sigma, float* top_alpha_splats, float* top_output,
+                                const int num_points_, const int channels_, const int height_, const int width_,
+                                const int top_count) {
+  (void)gg_splat_forward_f32(bottom_coordinates, bottom_values, bottom_sigma, top_alpha_splats, top_output, num_points_,
+                             channels_, height_, width_, top_count, stream);
+}
+
 extern "C" int gg_splat2d_f32(float* output, float* alpha_ws, const float* input, const float* coords,
                               const float* values, const float* sigma, int n, int num_points, int channels,
                               int height, int width, int soft_normalize, void* stream) {

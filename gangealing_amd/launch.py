@@ -124,7 +124,14 @@ def inject(reference_root, modules=False):
                     setattr(shim, name, getattr(src, name))
                 # everything else the reference's file exposes (normalize_tensor, spatial_average, upsample, the
                 # backbones module `pn`, ...) resolves to the reference's own code, loaded on first use
-                shim.__getattr__ = (lambda name, _t=target: getattr(_reference_module(reference_root, _t), name))
+                # (dunder probes - __path__, __file__, __wrapped__ from the import machinery / inspect's hasattr -
+                # must not execute the reference's file: an import error there would leave a hasattr() as something
+                # other than AttributeError)
+                def _fallback(name, _t=target):
+                    if name.startswith('__'):
+                        raise AttributeError(name)
+                    return getattr(_reference_module(reference_root, _t), name)
+                shim.__getattr__ = _fallback
                 sys.modules[target] = shim
         done += sorted(MODEL_MODULES)
     return done

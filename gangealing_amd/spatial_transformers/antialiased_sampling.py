@@ -27,16 +27,41 @@ def _check(t, name):
         raise TypeError(f'{name}: float32 only, got {t.dtype}')
 
 
+MAX_LEVELS = 8        # kMaxLevels of csrc/mipmap_warp.hip: max_num_levels <= 8, the reference's default (:22)
+
+
+def _num_levels(max_level, size):
+    """Pyramid levels the sampling can touch: ceil(max_level) + 1, at most down to the 1 x 1 level of a `size` base."""
+    return int(min(int(np.ceil(max_level)) + 1, int(np.log2(size)) + 1, MAX_LEVELS))
+
+
+def _level_views(rest, n, c, hp, wp, levels):
+    """Views of the levels 1 .. levels-1 held consecutively in `rest` (level l: (N,C,hp>>l,wp>>l))."""
+    views, off = [], 0
+    for lvl in range(1, levels):
+        h, w = hp >> lvl, wp >> lvl
+        views.append(rest[off:off + n * c * h * w].view(n, c, h, w))
+        off += n * c * h * w
+    return views
+
+
+def _rest_numel(n, c, hp, wp, levels):
+    return sum(n * c * (hp >> lvl) * (wp >> lvl) for lvl in range(1, levels))
+
+
 def _build_pyramid(base, levels=4):
-    """base (N,C,S,S), S a power of two -> [base, down(base), ...] (un-upsampled Gaussian pyramid)."""
-    pyr = [base]
+    """base (N,C,S,S), S a power of two -> (rest, [level 1, ...]): the un-upsampled Gaussian pyramid below the base, all
+    levels in ONE buffer (the layout gg_mipmap_warp_* takes) plus per-level views of it."""
     n, c, h, w = base.shape
-    for _ in range(1, levels):
-        nxt = torch.empty((n, c, h // 2, w // 2), dtype=base.dtype, device=base.device)
-        _lib.call('gg_mip_downsample2x_f32', nxt, pyr[-1], n * c, h, w)
-        pyr.append(nxt)
-        h, w = h // 2, w // 2
-    return pyr
+    if levels <= 1:
+        return None, []
+    rest = torch.empty(_rest_numel(n, c, h, w, levels), dtype=base.dtype, device=base.device)
+    views = _level_views(rest, n, c, h, w, levels)
+    src = base
+    for lvl, dst in enumerate(views, start=1):
+        _lib.call('gg_mip_downsample2x_f32', dst, src, n * c, h >> (lvl - 1), w >> (lvl - 1))
+        src = dst
+    return rest, views
 
 
 class _MipmapWarpFn(Function):
@@ -50,9 +75,12 @@ class _MipmapWarpFn(Function):
         ho, wo = grid.shape[1], grid.shape[2]
         pad_l = 0
         base = inputs
+        rest, nlev = None, 1
         if antialias:
             if h != w:
                 raise NotImplementedError('MipmapWarp expects square inputs (as the reference: antialiased_sampling.py:128)')
+            if max_level > MAX_LEVELS - 1:
+                raise NotImplementedError(f'MipmapWarp: max_num_levels <= {MAX_LEVELS} (the reference default)')
             log_size = np.log2(w)
             if not float(log_size).is_integer():      # reflect-pad to the next power of two (:130-137)
                 target = int(2 ** np.ceil(log_size))
@@ -60,38 +88,40 @@ class _MipmapWarpFn(Function):
                 pad_l = int(total // 2)
                 pad_r = int(total - pad_l)
                 base = F.pad(inputs, (pad_l, pad_r, pad_l, pad_r), mode='reflect').contiguous()
-            pyr = _build_pyramid(base, 4)
-        else:
-            pyr = [base, None, None, None]
+            nlev = _num_levels(max_level, base.shape[-1])
+            rest, _ = _build_pyramid(base, nlev)
         hp, wp = base.shape[-2:]
         out = torch.empty((n, c, ho, wo), dtype=inputs.dtype, device=inputs.device)
         levels = torch.empty((n, ho, wo), dtype=inputs.dtype, device=inputs.device)
-        _lib.call('gg_mipmap_warp_fwd_f32', out, levels, pyr[0], pyr[1], pyr[2], pyr[3], grid, n, c, h, w, hp, wp,
+        _lib.call('gg_mipmap_warp_fwd_f32', out, levels, base, rest, nlev, grid, n, c, h, w, hp, wp,
                   pad_l, ho, wo, max_level, min_level, _PAD_MODES[padding_mode], int(antialias))
-        ctx.save_for_backward(grid, *[p for p in pyr if p is not None])
-        ctx.conf = (n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, _PAD_MODES[padding_mode], int(antialias))
+        ctx.save_for_backward(grid, base, *([rest] if rest is not None else []))
+        ctx.conf = (n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, _PAD_MODES[padding_mode], int(antialias),
+                    nlev)
         ctx.mark_non_differentiable(levels)
         return out, levels
 
     @staticmethod
     def backward(ctx, grad_out, _grad_levels):
-        grid, *pyr = ctx.saved_tensors
-        n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, pm, antialias = ctx.conf
-        pyr = list(pyr) + [None] * (4 - len(pyr))
+        grid, base, *more = ctx.saved_tensors
+        rest = more[0] if more else None
+        n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, pm, antialias, nlev = ctx.conf
         grad_out = grad_out.contiguous()
         grad_grid = torch.empty_like(grid)
         want_img = ctx.needs_input_grad[0]
-        gp = [None] * 4
+        g0 = grest = None
         if want_img:
-            gp = [torch.zeros_like(p) if p is not None else None for p in pyr]
-        _lib.call('gg_mipmap_warp_bwd_f32', grad_grid, gp[0], gp[1], gp[2], gp[3], grad_out, pyr[0], pyr[1], pyr[2],
-                  pyr[3], grid, n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, pm, antialias)
+            g0 = torch.zeros_like(base)
+            grest = torch.zeros_like(rest) if rest is not None else None
+        _lib.call('gg_mipmap_warp_bwd_f32', grad_grid, g0, grest, grad_out, base, rest, nlev, grid, n, c, h, w, hp, wp,
+                  pad_l, ho, wo, max_level, min_level, pm, antialias)
         grad_in = None
         if want_img:
-            if antialias:   # fold the pyramid gradients back: g[l-1] += down2x^T(g[l])
-                for lvl in (3, 2, 1):
+            if grest is not None:   # fold the pyramid gradients back: g[l-1] += down2x^T(g[l])
+                gp = [g0] + _level_views(grest, n, c, hp, wp, nlev)
+                for lvl in range(nlev - 1, 0, -1):
                     _lib.call('gg_mip_downsample2x_bwd_f32', gp[lvl - 1], gp[lvl], n * c, hp >> (lvl - 1), wp >> (lvl - 1))
-            grad_in = gp[0]
+            grad_in = g0
             if pad_l or hp != h:
                 # adjoint of the reflect pad: fold the border gradients back onto the image
                 full = grad_in
@@ -148,9 +178,10 @@ class MipmapWarp(nn.Module):
         blur = blur / torch.sum(blur)
         self.register_buffer('blur_filter', blur[None, None, ...])     # kept for state_dict compatibility
         self.levels_map = None
-        if max_num_levels - 1.0 > 3.0:
-            raise NotImplementedError('MipmapWarp: the fused kernel keeps 4 pyramid levels (max_num_levels <= 4); '
-                                      'the heads use 3.5 (warping_heads.py:32,170)')
+        if max_num_levels - 1.0 > MAX_LEVELS - 1:
+            raise NotImplementedError(f'MipmapWarp: the fused kernel keeps up to {MAX_LEVELS} pyramid levels '
+                                      f'(max_num_levels <= {MAX_LEVELS}: the reference default, :22; the heads use 3.5, '
+                                      f'warping_heads.py:32,170)')
 
     def forward(self, inputs, grid, min_level=0.0, padding_mode='border'):
         out, levels = _MipmapWarpFn.apply(inputs, grid, float(self.max_num_levels - 1.0), float(min_level),

@@ -40,7 +40,9 @@ extern "C" {
 /* 2: library-owned scratch (gg_scratch_*), gg_lpips_tail_bwd_f32 gained `accumulate`
  * 3: gg_set_allocator; binary16 limbs (format code 18) accepted by the data-gradient entry points
  * 4: gg_modconv3x3_act_bits_f32 / gg_conv3x3_masked_dgrad_bits_f32 (1-bit sign plane), gg_set_tuning; the ticket page of
- *    a stream may not be created inside a hipGraph capture (error -4) */
+ *    a stream may not be created inside a hipGraph capture (error -4)
+ * 5: gg_mipmap_warp_fwd/bwd_f32 take the pyramid as (level 0, the deeper levels in one buffer, num_levels <= 8) instead of
+ *    four level pointers; SplatForwardGpu (the reference's own symbol) exported */
 int gg_abi_version(void);
 /* Pre-size the scratch buffer of `stream` on the current device to at least `bytes` and create its ticket page.
  * Optional for eager use (the entry points grow the scratch on demand); REQUIRED once per stream before a hipGraph
@@ -175,6 +177,13 @@ int gg_splat_forward_f32(const float* coords, const float* values, const float* 
 int gg_splat2d_f32(float* output, float* alpha_ws, const float* input, const float* coords,
                    const float* values, const float* sigma, int n, int num_points, int channels,
                    int height, int width, int soft_normalize, void* stream);
+/* The reference's own C symbol, name and argument order unchanged (splat_gpu_impl.cuh:11-22: stream FIRST, void return),
+ * so that the reference's torch binding utils/splat2d_cuda/src/splat_gpu.c:29-31 links against this library as it
+ * stands.  `stream` is a hipStream_t.  An alias of gg_splat_forward_f32: same kernels, same results; a failure (which
+ * the reference's void signature cannot report) is left in gg_last_error(). */
+void SplatForwardGpu(void* stream, const float* bottom_coordinates, const float* bottom_values,
+                     const float* bottom_sigma, float* top_alpha_splats, float* top_output, const int num_points_,
+                     const int channels_, const int height_, const int width_, const int top_count);
 
 /* ------------------------------------------------------------------------------------------
  * a6  anti-aliased sampling (MipmapWarp / Warp), models/spatial_transformers/antialiased_sampling.py.
@@ -190,16 +199,20 @@ int gg_mip_downsample2x_bwd_f32(float* grad_in, const float* grad_out, int plane
  * pixel the mip level is computed from the grid (:62-97,181-210), the two bracketing levels are
  * sampled straight from the pyramid (bilinear upsample :155-160 folded into the tap fetch) and
  * blended (:212-238).
- *   pyr[l]      level-l image (N,C,hp>>l,wp>>l), l = 0..3; pyr[0] is the (reflect-padded to a power
- *               of two, :130-137) input; hp, wp its size; pad_l the left/top pad (0 when h is 2^k)
+ *   pyr0        level 0: the (reflect-padded to a power of two, :130-137) input (N,C,hp,wp); pad_l the left/top pad
+ *               (0 when h is 2^k)
+ *   pyr_rest    levels 1 .. num_levels-1 consecutively in one buffer, level l as (N,C,hp>>l,wp>>l)   (ABI 5: the pyramid
+ *               depth is an argument - ABI <= 4 took four fixed level pointers and refused max_level > 3, so the
+ *               reference's DEFAULT constructor MipmapWarp(max_num_levels=8), antialiased_sampling.py:22, was not served)
+ *   num_levels  levels the caller built: >= min(ceil(max_level) + 1, log2(hp) + 1), <= 8.  A pixel whose level lies
+ *               beyond the pyramid's last (1 x 1) level - where the reference raises in ReflectionPad2d, :117 - samples it
  *   h, w        size of the ORIGINAL input (sampling coordinates refer to it)
  *   grid        (N,ho,wo,2) normalised coordinates
  *   out         (N,C,ho,wo);  levels_out (N,ho,wo) receives the clamped fractional level
- *   antialias   0 -> plain Warp (:9-16): level 0 everywhere
- *   max_level   = max_num_levels - 1 (2.5 for the heads, warping_heads.py:32,170)
+ *   antialias   0 -> plain Warp (:9-16): level 0 everywhere (num_levels 1, pyr_rest NULL)
+ *   max_level   = max_num_levels - 1 in [0, 7] (2.5 for the heads, warping_heads.py:32,170; 7 for the default)
  */
-int gg_mipmap_warp_fwd_f32(float* out, float* levels_out,
-                           const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3,
+int gg_mipmap_warp_fwd_f32(float* out, float* levels_out, const float* pyr0, const float* pyr_rest, int num_levels,
                            const float* grid, int n, int c, int h, int w, int hp, int wp, int pad_l,
                            int ho, int wo, float max_level, float min_level,
                            int padding_mode, int antialias, void* stream);
@@ -212,12 +225,11 @@ int gg_mipmap_warp_fwd_f32(float* out, float* levels_out,
 int gg_mipmap_warp_indices_f32(int* ix_nw, int* iy_nw, int* lvl_floor, int* lvl_ceil, const float* grid,
                                int n, int h, int w, int ho, int wo, float max_level, float min_level,
                                int padding_mode, int antialias, void* stream);
-/* Backward.  grad_grid (N,ho,wo,2) is overwritten; grad_pyr{0..3} ACCUMULATE (pass NULL for all four
- * to skip the image gradient).  Includes the gradient that reaches the grid through the fractional
- * mip level (levels % 1.0 is differentiable in the reference's autograd graph). */
-int gg_mipmap_warp_bwd_f32(float* grad_grid, float* grad_pyr0, float* grad_pyr1, float* grad_pyr2, float* grad_pyr3,
-                           const float* grad_out,
-                           const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3,
+/* Backward.  grad_grid (N,ho,wo,2) is overwritten; grad_pyr0 / grad_pyr_rest (the layout of pyr0 / pyr_rest)
+ * ACCUMULATE (pass NULL for both to skip the image gradient).  Includes the gradient that reaches the grid through the
+ * fractional mip level (levels % 1.0 is differentiable in the reference's autograd graph). */
+int gg_mipmap_warp_bwd_f32(float* grad_grid, float* grad_pyr0, float* grad_pyr_rest, const float* grad_out,
+                           const float* pyr0, const float* pyr_rest, int num_levels,
                            const float* grid, int n, int c, int h, int w, int hp, int wp, int pad_l,
                            int ho, int wo, float max_level, float min_level,
                            int padding_mode, int antialias, void* stream);

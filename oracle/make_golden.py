@@ -187,6 +187,47 @@ def gen_mipmap_warp():
     save('grid_sample', cases)
 
 
+def gen_mipmap_warp_deep():
+    """MipmapWarp beyond the heads' 3.5: the reference's DEFAULT constructor (max_num_levels = 8,
+    antialiased_sampling.py:22) and 4.5, on grids that reach the deep levels (the 7-level clamp included), a non
+    power-of-two image (pad path) and a 32-pixel image whose pyramid ends at 1 x 1 before the clamp does."""
+    from models.spatial_transformers.antialiased_sampling import MipmapWarp
+
+    def aff(theta, n, r):
+        return F.affine_grid(torch.tensor(theta, dtype=torch.float32).view(1, 2, 3).repeat(n, 1, 1),
+                             (n, 3, r, r), align_corners=False)
+    c, s = math.cos(0.4), math.sin(0.4)
+    cases = []
+    ci = 0
+    for (size, r, mnl, mode, name, theta) in [
+        (128, 16, 8, 'border', 'zoom_out_4', [[4, 0, 0.3], [0, 4, 0]]),
+        (128, 16, 8, 'reflection', 'zoom_out_12_rot', [[12 * c, -12 * s, 0], [12 * s, 12 * c, 0.2]]),
+        (128, 8, 8, 'reflection', 'zoom_out_40', [[40, 0, 0], [0, 40, 0]]),          # levels hit the clamp at 7
+        (128, 8, 8, 'zeros', 'zoom_out_20_rot', [[20 * c, -20 * s, 0.1], [20 * s, 20 * c, 0]]),
+        (128, 16, 8, 'border', 'aniso', [[9, 0, 0], [0, 1.5, 0]]),
+        (128, 16, 8, 'border', 'default_ctor_identity', [[1, 0, 0], [0, 1, 0]]),
+        (100, 16, 8, 'reflection', 'pad_zoom_out_8', [[8, 0, 0], [0, 8, 0.1]]),       # 100 -> reflect-padded to 128
+        (32, 16, 8, 'border', 'small_zoom_out_4', [[4, 0, 0], [0, 4, 0]]),            # 32-pixel base: 6 levels exist
+        (64, 32, 4.5, 'reflection', 'zoom_out_6_rot', [[6 * c, -6 * s, 0], [6 * s, 6 * c, 0]]),
+        (64, 16, 4.5, 'border', 'zoom_out_3', [[3, 0, 0.2], [0, 3, -0.1]]),
+        (64, 16, 4.5, 'zeros', 'zoom_out_16', [[16, 0, 0], [0, 16, 0]]),              # clamp at 3.5
+    ]:
+        grid = aff(theta, 2, r)
+        if name != 'default_ctor_identity':
+            grid = grid + rnd(f'mipd.j{ci}', (2, r, r, 2), 0.02)
+        x = rnd(f'mipd.x{ci}', (2, 3, size, size)).requires_grad_(True)
+        grid_l = grid.clone().requires_grad_(True)
+        warp = MipmapWarp() if name == 'default_ctor_identity' else MipmapWarp(max_num_levels=mnl)
+        out = warp(x, grid_l, padding_mode=mode)
+        g = rnd(f'mipd.g{ci}', out.shape)
+        gx, ggrid = torch.autograd.grad(out, (x, grid_l), g)
+        cases.append(dict(x=x, grid=grid_l, out=out, g=g, gx=gx, ggrid=ggrid, levels_map=warp.levels_map,
+                          meta=dict(padding_mode=mode, grid=name, max_num_levels=mnl,
+                                    max_level_reached=float(warp.levels_map.detach().max() * (mnl - 1.0)))))
+        ci += 1
+    save('mipmap_warp_deep', cases)
+
+
 def gen_heads():
     from models.spatial_transformers.warping_heads import SimilarityHead, FlowHead, apply_affine
     cases = []
@@ -752,7 +793,8 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     import_reference()
     only = sys.argv[1:]
-    gens = dict(upfirdn2d=gen_upfirdn2d, fused_act=gen_fused_act, mipmap_warp=gen_mipmap_warp, heads=gen_heads,
+    gens = dict(upfirdn2d=gen_upfirdn2d, fused_act=gen_fused_act, mipmap_warp=gen_mipmap_warp,
+                mipmap_warp_deep=gen_mipmap_warp_deep, heads=gen_heads,
                 misc=gen_misc, modconv=gen_modconv, generator=gen_generator, stn=gen_stn,
                 train_step=gen_train_step, cluster_classifier=gen_cluster_classifier,
                 point_transfer=gen_point_transfer, warp_indices=gen_warp_indices, annealing=gen_annealing, stn_inference=gen_stn_inference,

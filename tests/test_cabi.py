@@ -48,6 +48,23 @@ def test_ctypes_prototypes_match_header():
         assert _lib._PROTOS[name] == proto, name
 
 
+def test_reference_splat_symbol_is_exported(lib):
+    """The reference's one true C symbol (utils/splat2d_cuda/src/splat_gpu_impl.cuh:11-22): same name, stream first,
+    void return - so splat_gpu.c:29-31 links unchanged.  Declared in the header with exactly those eleven parameters."""
+    assert hasattr(lib, 'SplatForwardGpu')
+    hdr = open(os.path.join(REPO, 'include', 'gangealing_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    m = re.search(r'void\s+SplatForwardGpu\s*\(([^;]*?)\)\s*;', hdr)
+    assert m, 'SplatForwardGpu not declared'
+    args = [re.sub(r'\s+\w+$', '', a.strip()).replace(' *', '*') for a in m.group(1).split(',')]
+    assert args == ['void*', 'const float*', 'const float*', 'const float*', 'float*', 'float*',
+                    'const int', 'const int', 'const int', 'const int', 'const int']
+    # top_count <= 0: nothing to do, nothing launched, no GPU needed
+    lib.SplatForwardGpu.restype = None
+    lib.SplatForwardGpu.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 5
+    lib.SplatForwardGpu(None, None, None, None, None, None, 0, 0, 0, 0, 0)
+
+
 def test_argument_errors_do_not_need_a_gpu(lib):
     # negative sizes are rejected before any launch
     rc = lib.gg_upfirdn2d_f32(None, None, None, 1, 4, 4, 4, 4, 0, 1, 1, 1, 0, 0, 0, 0, None)

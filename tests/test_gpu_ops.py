@@ -172,14 +172,16 @@ def test_warp_golden(case, cuda):
     close(out, case['out'], 1e-5)
 
 
-@pytest.mark.parametrize('case', load_golden('mipmap_warp'),
+@pytest.mark.parametrize('case', load_golden('mipmap_warp') + load_golden('mipmap_warp_deep'),
                          ids=lambda c: f"{c['x'].shape[-1]}-{c['meta']['padding_mode']}-{c['meta']['grid']}")
 def test_mipmap_warp_golden(case, cuda):
     from gangealing_amd.spatial_transformers.antialiased_sampling import MipmapWarp
     from oracle import np_ops
     m = case['meta']
     x, grid = T(case['x'], cuda, True), T(case['grid'], cuda, True)
-    warp = MipmapWarp(max_num_levels=m['max_num_levels']).to(cuda)
+    # (mipmap_warp_deep: the reference's default constructor - 8 levels - and 4.5; antialiased_sampling.py:22-60)
+    warp = (MipmapWarp() if m['grid'] == 'default_ctor_identity' else MipmapWarp(max_num_levels=m['max_num_levels'])).to(cuda)
+    assert warp.max_num_levels == m['max_num_levels']
     out = warp(x, grid, padding_mode=m['padding_mode'])
     close(out, case['out'], 2e-5)
     close(warp.levels_map, case['levels_map'], 1e-6)
@@ -310,6 +312,47 @@ def test_splat2d_against_live_reference_kernel(shape, cuda):
         got = splat2d(inp, coords, values, sigma, soft)
         err = float((got - want).abs().max())
         assert err <= 5e-5 * max(1.0, float(want.abs().max())), (soft, err)
+
+
+def test_reference_symbol_SplatForwardGpu(cuda):
+    """The reference's own C entry point (splat_gpu_impl.cuh:11-22: stream first, void) called through ctypes exactly as
+    splat_gpu.c:29-31 calls it: bitwise equal to gg_splat_forward_f32 (binned boxes: no atomics) and - when the
+    compiled reference kernel travelled to this box - equal to ITS SplatForwardGpu within float-atomic reordering."""
+    import ctypes
+    from gangealing_amd import _lib
+    lib = _lib.load()
+    lib.SplatForwardGpu.restype = None
+    lib.SplatForwardGpu.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 5
+    n, c, h, w, p = 2, 3, 96, 80, 3000
+    g = torch.Generator().manual_seed(11)
+    coords = (torch.rand(n, p, 2, generator=g) * torch.tensor([w + 8.0, h + 8.0]) - 4.0).to(cuda)
+    values = torch.randn(n, p, c, generator=g).to(cuda)
+    sigma = torch.tensor([1.3, 2.5]).to(cuda)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(fn, stream_first):
+        alpha = torch.zeros(n, h, w, device=cuda)
+        out = torch.zeros(n, c, h, w, device=cuda)
+        ptrs = [coords.data_ptr(), values.data_ptr(), sigma.data_ptr(), alpha.data_ptr(), out.data_ptr()]
+        if stream_first:
+            fn(stream, *ptrs, p, c, h, w, n * p)
+        else:
+            assert fn(*ptrs, p, c, h, w, n * p, stream) == 0
+        torch.cuda.synchronize()
+        return alpha, out
+
+    a1, o1 = run(lib.SplatForwardGpu, True)
+    a0, o0 = run(lib.gg_splat_forward_f32, False)
+    assert torch.equal(a1, a0) and torch.equal(o1, o0)
+    assert float(a1.abs().max()) > 0
+    from oracle import make_golden_splat as ref
+    if ref.reference_available():
+        rl = ctypes.CDLL(ref.REF_SO)
+        rl.SplatForwardGpu.restype = None
+        rl.SplatForwardGpu.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 5
+        ar, orr = run(rl.SplatForwardGpu, True)
+        assert float((a1 - ar).abs().max()) <= 2e-5 * max(1.0, float(ar.abs().max()))
+        assert float((o1 - orr).abs().max()) <= 2e-5 * max(1.0, float(orr.abs().max()))
 
 
 @pytest.mark.parametrize('case', [

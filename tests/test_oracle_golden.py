@@ -41,7 +41,7 @@ def test_grid_sample(case):
     close(out, case['out'], 2e-6)
 
 
-@pytest.mark.parametrize('case', load_golden('mipmap_warp'),
+@pytest.mark.parametrize('case', load_golden('mipmap_warp') + load_golden('mipmap_warp_deep'),
                          ids=lambda c: f"{c['x'].shape[-1]}-{c['meta']['padding_mode']}-{c['meta']['grid']}")
 def test_mipmap_warp(case):
     m = case['meta']
