@@ -458,8 +458,7 @@ def main():
     ap.add_argument('--graph', action='store_true',
                     help='time hipGraph replays of the iteration instead of eager launches (one graph on a single GPU; no '
                          'roofline entry: HIP events cannot be recorded inside a replayed graph).  With --gpus > 1 the '
-                         'segmented replay is withdrawn (GangealingTrainer raises; GG_ENABLE=graph_segments opts in - see '
-                         'profiles/r05_e_segment_replay_nan.txt)')
+                         'gradient all-reduces are captured inside the graph (nccl / RCCL backend only; gloo raises)')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the additional single-GPU measurements (hipGraph replay, plain-bf16 arithmetic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -21,72 +21,22 @@ def flow_identity_loss(delta_flow):
     return flow_losses(delta_flow)[1]
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    s = _SIDE_STREAMS.get(device)
-    if s is None:
-        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
-    return s
-
-
 def sample_gan_supervised_pairs(generator, ll, resize_fake2stn, psi, batch, dim_latent, freeze_ll, device, z=None):
     """(unaligned G(w), aligned target G(mix(w, c))) - loss.py:21-29.  G pass #1 needs no graph.
 
-    The two synthesis passes are independent once w is known, so pass #1 can be issued on a second HIP stream and
-    overlap pass #2: the low-resolution layers (too few tiles to fill 256 CUs) and the HBM-bound blur / activation
-    kernels of one pass run beside the matrix-pipe-bound convolutions of the other.  The caller's stream waits for
-    the side stream before anything reads `unaligned_in`."""
+    Both synthesis passes run on the caller's stream.  (Rounds 2 - 5 could fork pass #1 onto a second HIP stream:
+    +0.3 % at per-GPU batch 5, +0.6 % at 16 - and 5 % of repeated runs of one small configuration lost bitwise
+    reproducibility with it, profiles/r05_d_two_stream_determinism.txt.  The state the two streams raced on was never
+    located, so round 6 removed the fork instead of shipping it behind a switch.)"""
     if z is None:
         z = torch.randn(batch, dim_latent, device=device)
-    # measured (MI355X, C2): +3.5 % at per-GPU batch 5, +0.6 % at batch 16 - while every kernel's own duration
-    # roughly doubles under the contention, which would blur the per-kernel roofline measurement.
-    # Round 5: OPT-IN only (GG_ENABLE=two_streams).  Rounds 2 - 4 forked automatically at batches <= 8; this round's
-    # repeated determinism runs (profiles/r05_d_two_stream_determinism.txt) found that with the fork 5 % of the runs of
-    # one small configuration (K = 2 heads, flips, full-resolution sampling, batch 2) differ from their twin in the
-    # first forked iteration - with round 4's kernels as well as this round's; 0 of 74 without the fork.  The shared
-    # state the two streams race on has not been located, so the library's bitwise-reproducibility claim is kept by
-    # not forking.
-    overlap = (isinstance(generator, torch.nn.Module) and z.is_cuda and hasattr(generator, 'get_latent') and
-               'two_streams' not in conv_mfma.DISABLED and 'two_streams' in conv_mfma.ENABLED)
-    if overlap:
-        # Everything derived from the frozen weights (GEMM-layout packs, squared-weight tables, scaled EqualLinear
-        # weights, style-bank job tables) is built lazily by whichever pass touches a layer first and then cached on
-        # the host.  With two streams that would be the side stream, while the other pass reads the cached buffers on
-        # the main stream with no dependency between them: a read-before-write race on the first iteration and after
-        # every weight load.  So the first call for a given set of weight versions (and arithmetic mode) runs both
-        # passes on the current stream - which builds every cache there - and only later calls fork.
-        # (storage address + version of every parameter: in-place updates bump the version, `p.data = ...` / .to()
-        # re-pointing changes the address.  ~130 parameters: tens of microseconds of host time per step, hidden behind
-        # a GPU-bound step)
-        key = (conv_mfma.PRECISION, z.device, psi is not None) + tuple(
-            (p.data_ptr(), p._version) for p in generator.parameters())
-        if generator.__dict__.get('_two_stream_ready') != key:
-            generator.__dict__['_two_stream_ready'] = key
-            overlap = False
-    if not overlap:
-        with torch.no_grad():
-            unaligned_in, w_noise = generator([z], noise=None, return_latents=True)
-        side = None
-    else:
-        with torch.no_grad():
-            w = generator.get_latent(z)                                    # mapping network (both passes need w)
-            w_noise = w.unsqueeze(1).repeat(1, generator.n_latent, 1)      # as Generator.forward builds it (:548-549)
-        cur = torch.cuda.current_stream()
-        side = _side_stream(z.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side), torch.no_grad():
-            unaligned_in, _ = generator([w_noise], input_is_latent=True, noise=None)
-        w_noise.record_stream(side)
+    with torch.no_grad():
+        unaligned_in, w_noise = generator([z], noise=None, return_latents=True)
     with torch.set_grad_enabled(not freeze_ll):
         w_aligned = ll([w_noise[:, 0, :]], psi=psi)
         aligned_target, _ = generator(w_aligned, input_is_latent=True, noise=None,
                                       grad_latents=getattr(ll, 'inject_index', None))
         aligned_target = resize_fake2stn(aligned_target)
-    if side is not None:
-        torch.cuda.current_stream().wait_stream(side)
-        unaligned_in.record_stream(torch.cuda.current_stream())
     return unaligned_in, aligned_target
 
 

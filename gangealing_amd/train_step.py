@@ -240,36 +240,32 @@ class GangealingTrainer:
         self.pipeline_update = self.collectives if pipeline_update is None else bool(pipeline_update)
         self.stn.register_forward_pre_hook(lambda module, inputs: self._before_stn_forward())
         # hipGraph replay of the iteration: after `graph_warmup` eager iterations the step - zeroing the gradient
-        # arenas, loss forward, backward, both optimizers, EMA, weight re-pack: ~700 launches - is captured once and
-        # replayed; psi and the optimizers' step-dependent scalars live in device memory and are refreshed by the host
-        # before every replay.  One graph in a single process; with collectives (world > 1) four graphs with the
-        # gradient all-reduces between them (_capture_segments / _replay_segments).  use_graph='auto': replay at
-        # per-GPU batches <= 8, where the eager step is bound by the host's launch rate (the reference recipe: 5 per
-        # GPU); eager launches at larger batches, where the GPU is the bound and replay buys nothing.
-        self.use_graph = (batch <= 8) if use_graph == 'auto' else bool(use_graph)
-        if self.use_graph and self.collectives and 'graph_segments' not in conv_mfma.ENABLED:
-            # Round 5: the four-graph replay is WITHDRAWN from the default route.  With the generator passes on one
-            # stream, the SECOND replay of the segments produced NaN gradients in sessions 7 - 9 (3 of 3 test runs, both
-            # with and without a flush between the steps), but not in session 10 (same code, eight other processes on the
-            # GPU); with the passes forked onto two streams it passed 2 of 2.  The cause is not located
-            # (profiles/r05_e_segment_replay_nan.txt), so the route is opt-in for debugging only: GG_ENABLE=graph_segments.
-            if use_graph == 'auto':
-                self.use_graph = False
-            else:
-                raise RuntimeError('GangealingTrainer(use_graph=True) with collectives (world > 1): the segmented hipGraph '
-                                   'replay is withdrawn (NaN at the second replay in some sessions, see '
-                                   'profiles/r05_e_segment_replay_nan.txt); use eager steps (use_graph=False or "auto"), '
-                                   'or opt in with GG_ENABLE=graph_segments')
+        # arenas, loss forward, backward, the gradient all-reduces (when there are ranks to reduce over), both
+        # optimizers, EMA, weight re-pack: ~700 launches - is captured ONCE and replayed; psi and the optimizers'
+        # step-dependent scalars live in device memory and are refreshed by the host before every replay.
+        # With collectives the all-reduces are captured INSIDE the graph: RCCL's collectives are stream-ordered kernel
+        # launches on the communicator's stream, forked from / joined to the capturing stream by events, and a hipGraph
+        # records exactly that (backend "nccl" only - gloo reduces on the host and cannot be captured).
+        # use_graph='auto': replay at per-GPU batches <= 8 in a single process (where the eager step is bound by the
+        # host's launch rate), eager launches otherwise (at larger batches the GPU is the bound; with collectives the
+        # eager step hides the all-reduce behind the next iteration's generator passes, which one graph cannot).
+        # (Round 5 replayed the multi-process step as FOUR graphs with eager collectives between them; that route gave
+        # NaN at the second replay in some sessions, the cause was never located, and round 6 removed it.)
+        if use_graph == 'auto':
+            self.use_graph = batch <= 8 and not self.collectives
+        else:
+            self.use_graph = bool(use_graph)
+        if self.use_graph and self.collectives:
+            import torch.distributed as dist
+            backend = dist.get_backend() if dist.is_initialized() else None
+            if backend != 'nccl':
+                raise RuntimeError(f'GangealingTrainer(use_graph=True) with collectives needs the nccl (RCCL) backend: its '
+                                   f'all-reduce is captured inside the hipGraph; backend {backend!r} reduces on the host. '
+                                   f'Use eager steps (use_graph=False or "auto").')
+            self.pipeline_update = False       # one graph per iteration: the update is not deferred
         self._graph = None
-        self._segments = None          # (g1, g2, g3, g4) with collectives
-        self._capture_switch = None    # set while the segments are being captured (see _before_stn_forward)
-        self._pending_work = None      # replay path: the asynchronous all-reduce of the STN gradients of the last step
-        self._upd_stream = None
         self._graph_calls = 0
-        # two eager iterations at least when the generator passes fork onto a side stream (batch <= 8): the first call
-        # of sample_gan_supervised_pairs does not fork (it builds the weight caches on one stream), so only the second
-        # creates the side stream's scratch / ticket page - which must exist before the capture, not inside it
-        self._graph_warmup = max(int(graph_warmup), 2 if batch <= 8 else 1)
+        self._graph_warmup = max(int(graph_warmup), 1)
         self._psi_dev = torch.zeros((), dtype=torch.float32, device=device)
         self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=device)        # [stn x4, ll x4]
         self._cap_stream = None
@@ -384,6 +380,10 @@ class GangealingTrainer:
         total, parts = self.loss(self._psi_dev)
         with conv_mfma.grad_slots():
             total.backward()
+        if self.collectives:                     # (captured with the rest: see __init__)
+            import torch.distributed as dist
+            dist.all_reduce(self.ll_arena.grad, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self.stn_arena.grad, op=dist.ReduceOp.SUM)
         if not self.freeze_ll:
             adam_ema_step(self.ll_arena, 0.0, hyper=self._hyper_dev[4:8])
         adam_ema_step(self.stn_arena, 0.0, self.ema_arena, self.ema_decay, hyper=self._hyper_dev[0:4])
@@ -403,10 +403,11 @@ class GangealingTrainer:
         return parts
 
     def _graph_step_on_stream(self, psi, stn_lr, ll_lr):
-        if self.collectives:
-            return self._segment_step_on_stream(psi, stn_lr, ll_lr)
-        # the scalars this iteration's launches read from device memory
-        vals = adam_hyper(stn_lr, self.stn_arena.step_count + 1) + adam_hyper(ll_lr, self.ll_arena.step_count + 1)
+        # the scalars this iteration's launches read from device memory (the 1 / world of the gradient average rides in
+        # the Adam kernel's grad_scale)
+        scale = 1.0 / self.world
+        vals = adam_hyper(stn_lr, self.stn_arena.step_count + 1, grad_scale=scale) + \
+            adam_hyper(ll_lr, self.ll_arena.step_count + 1, grad_scale=scale)
         # pinned staging ring: the copy is asynchronous (no host sync per iteration); a slot is rewritten 16 iterations
         # later, after its event shows the copy has been consumed
         if self._hyper_ring is None:
@@ -444,140 +445,8 @@ class GangealingTrainer:
         conv_mfma.mark_trainable_packs_current()
         return self._graph_parts
 
-    # ---- hipGraph path with collectives (world > 1) --------------------------------------------------------------
-    # A collective cannot sit inside a replayed graph on every backend (gloo cannot at all), and one graph per iteration
-    # would serialise the 172 MB gradient all-reduce with the next iteration.  So the iteration is captured as FOUR
-    # graphs and the collectives stay eager between them:
-    #   g1  zero the latent learner's gradient; both generator passes (everything in front of the STN's forward)
-    #   g2  zero the STN's gradient arena; STN forward, perceptual loss, regularisers, backward
-    #   g3  Adam of the latent learner          (after the all-reduce of its few gradients)
-    #   g4  Adam + EMA of the STN, weight re-pack (after the all-reduce of the gradient arena)
-    # Replay order of iteration i: g1(i)  ||  [wait all-reduce(i-1); g4(i-1)] on the update stream; join; g2(i);
-    # all-reduce(ll); g3(i); start all-reduce(stn) asynchronously.  As in the eager pipelined step the STN update of an
-    # iteration hides behind the next iteration's generator passes, which read neither the STN nor its gradients.  The
-    # boundary g1 | g2 is the STN's forward pre-hook: during the capture it ends one graph and begins the next, so the
-    # loss functions stay as they are.
-    def _upload(self, dst, values):
-        if self._hyper_ring is None:
-            self._hyper_ring = [[torch.zeros(9, dtype=torch.float32).pin_memory(), None] for _ in range(32)]
-            self._ring_pos = 0
-        slot = self._hyper_ring[self._ring_pos % len(self._hyper_ring)]
-        self._ring_pos += 1
-        if slot[1] is not None:
-            slot[1].synchronize()
-        n = len(values)
-        slot[0][:n] = torch.tensor(values, dtype=torch.float32)
-        dst.copy_(slot[0][:n].view(dst.shape), non_blocking=True)
-        slot[1] = torch.cuda.Event()
-        slot[1].record()
-
     def _before_stn_forward(self):
-        sw = self._capture_switch
-        if sw is None:
-            self.flush()
-            return
-        # capturing the segments: everything so far (the generator passes) was g1; the STN's part goes to g2
-        g1, g2, pool = sw
-        self._capture_switch = None
-        g1.capture_end()
-        g2.capture_begin(pool=pool)
-        self.stn_arena.grad.zero_()
-
-    def _capture_segments(self):
-        import gc
-        pool = torch.cuda.graph_pool_handle()
-        g1, g2, g3, g4 = (torch.cuda.CUDAGraph() for _ in range(4))
-        gc.collect()
-        torch.cuda.synchronize()
-        steps = (self.stn_arena.step_count, self.ll_arena.step_count)
-        self._capture_switch = (g1, g2, pool)
-        g1.capture_begin(pool=pool)
-        try:
-            self.ll_arena.grad.zero_()
-            total, self._graph_parts = self.loss(self._psi_dev)      # (the STN pre-hook switches g1 -> g2)
-            if self._capture_switch is not None:
-                raise RuntimeError('the STN forward was never reached while capturing')
-            with conv_mfma.grad_slots():
-                total.backward()
-            g2.capture_end()
-            g3.capture_begin(pool=pool)
-            if not self.freeze_ll:
-                adam_ema_step(self.ll_arena, 0.0, hyper=self._hyper_dev[4:8])
-            g3.capture_end()
-            g4.capture_begin()         # its own pool: g4 replays BESIDE the next iteration's g1 (nothing may alias)
-            adam_ema_step(self.stn_arena, 0.0, self.ema_arena, self.ema_decay, hyper=self._hyper_dev[0:4])
-            conv_mfma.repack_trainable()
-            g4.capture_end()
-        finally:
-            self._capture_switch = None
-        self.stn_arena.step_count, self.ll_arena.step_count = steps       # the captures executed nothing
-        del total
-        self._segments = (g1, g2, g3, g4)
-
-    def _finish_pending_replay(self, stream=None):
-        """The deferred STN update of the replay path: wait for the gradient all-reduce, replay g4."""
-        work, hyper = self._pending_work
-        self._pending_work = None
-        ev = self._comm_mark()
-        work.wait()
-        self._comm_mark(ev)
-        self._upload(self._hyper_dev[0:4], hyper)
-        self._segments[3].replay()
-        self.stn_arena.step_count += 1
-        self.stn_arena.touch()
-        self.ema_arena.touch()
-        conv_mfma.mark_trainable_packs_current()
-
-    def _segment_step_on_stream(self, psi, stn_lr, ll_lr):
-        import torch.distributed as dist
-        scale = 1.0 / self.world
-        self._graph_calls += 1
-        if self._segments is None and self._graph_calls <= self._graph_warmup:
-            # eager iterations on the capture stream, un-pipelined, with the device-resident scalars: every cache,
-            # workspace, ticket page and communicator the captures must not create exists afterwards
-            self._upload(self._psi_dev, [float(psi)])
-            self._upload(self._hyper_dev, adam_hyper(stn_lr, self.stn_arena.step_count + 1, grad_scale=scale) +
-                         adam_hyper(ll_lr, self.ll_arena.step_count + 1, grad_scale=scale))
-            self.stn_arena.zero_grad()
-            self.ll_arena.zero_grad()
-            self.stn_arena.grad.zero_()
-            self.ll_arena.grad.zero_()
-            total, parts = self.loss(self._psi_dev)
-            with conv_mfma.grad_slots():
-                total.backward()
-            dist.all_reduce(self.ll_arena.grad, op=dist.ReduceOp.SUM)
-            dist.all_reduce(self.stn_arena.grad, op=dist.ReduceOp.SUM)
-            if not self.freeze_ll:
-                adam_ema_step(self.ll_arena, 0.0, hyper=self._hyper_dev[4:8])
-            adam_ema_step(self.stn_arena, 0.0, self.ema_arena, self.ema_decay, hyper=self._hyper_dev[0:4])
-            conv_mfma.repack_trainable()
-            return parts
-        if self._segments is None:
-            if self._upd_stream is None:
-                self._upd_stream = torch.cuda.Stream(device=self.device)
-                with torch.cuda.stream(self._upd_stream):
-                    _lib.reserve_scratch(0)            # (its ticket page may not be created inside a capture)
-            self._capture_segments()
-        g1, g2, g3, g4 = self._segments
-        cap = torch.cuda.current_stream()
-        if self._pending_work is not None:
-            self._upd_stream.wait_stream(cap)          # the update stream continues from the END of the previous step ...
-        self._upload(self._psi_dev, [float(psi)])
-        g1.replay()                                    # ... so that what it does next runs BESIDE this step's generator passes
-        if self._pending_work is not None:             # the previous iteration's STN update
-            with torch.cuda.stream(self._upd_stream):
-                self._finish_pending_replay()
-            cap.wait_stream(self._upd_stream)
-        g2.replay()
-        dist.all_reduce(self.ll_arena.grad, op=dist.ReduceOp.SUM)
-        if not self.freeze_ll:
-            self._upload(self._hyper_dev[4:8], adam_hyper(ll_lr, self.ll_arena.step_count + 1, grad_scale=scale))
-            g3.replay()
-            self.ll_arena.step_count += 1
-            self.ll_arena.touch()
-        work = dist.all_reduce(self.stn_arena.grad, op=dist.ReduceOp.SUM, async_op=True)
-        self._pending_work = (work, adam_hyper(stn_lr, self.stn_arena.step_count + 1, grad_scale=scale))
-        return self._graph_parts
+        self.flush()
 
     def _apply_stn_update(self, scale, lr):
         adam_ema_step(self.stn_arena, lr, self.ema_arena, self.ema_decay, grad_scale=scale)
@@ -594,12 +463,6 @@ class GangealingTrainer:
 
     def flush(self):
         """Apply a deferred STN update (no-op when nothing is pending)."""
-        if self._pending_work is not None:       # replay path with collectives
-            cur = torch.cuda.current_stream()
-            self._cap_stream.wait_stream(cur)
-            with torch.cuda.stream(self._cap_stream):
-                self._finish_pending_replay()
-            cur.wait_stream(self._cap_stream)
         if self._pending is not None:
             work, scale, lr = self._pending
             self._pending = None

@@ -40,28 +40,3 @@ def test_bench_two_ranks_one_gpu(cuda):
     assert d['allreduce_exposed_ms_per_step_max_rank'] >= 0
     # whole-job throughput = images of BOTH ranks over the max-over-ranks time
     assert abs(out['value'] - 2 * 4 * 3 / (out['ms_per_step'] * 3e-3)) / out['value'] < 1e-3
-
-
-@pytest.mark.skipif(os.environ.get('GG_TEST_GRAPH_SEGMENTS') != '1',
-                    reason='segmented hipGraph replay is withdrawn (profiles/r05_e_segment_replay_nan.txt)')
-def test_bench_two_ranks_graph_replay(cuda):
-    """`bench.py --gpus 2 --batch 5 --graph`: the reference recipe's per-GPU batch, the iteration replayed from captured
-    graphs with the gradient all-reduces between them (GangealingTrainer._segment_step_on_stream)."""
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, GANGEALING_SHARE_DEVICE='1', GANGEALING_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0',
-               GG_ENABLE='graph_segments')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-           '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '4',
-           '--warmup', '1', '--workload', 'c2', '--batch', '5', '--graph', '--no-extras', '--no-cpu-baseline']
-    res = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0, res.stderr[-3000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, res.stdout[-2000:]
-    out = json.loads(lines[0])
-    assert out['n_gpus'] == 2 and out['steps'] == 4 and out['value'] > 0
-    assert out['config']['global_batch'] == 10 and 'hipGraph' in out['config']['launch']
-    d = out['distributed']
-    assert d['world_size'] == 2 and d['ranks_counted_by_all_reduce'] == 2

@@ -12,6 +12,11 @@ Checked: the backend really is nccl and counts one rank; the arena pushed throug
 one-rank sum is the identity, so any difference is a stream hand-off bug: Adam reading the arena before the collective
 wrote it back, or the next backward writing gradients into a buffer RCCL is still reading); the exposed wait is
 recorded.
+
+Round 6: the hipGraph form of the multi-process step - `GangealingTrainer(collectives=True, use_graph=True)` captures both
+all-reduces INSIDE the one graph of the iteration (RCCL's kernels on the communicator's stream, event-forked from the
+capturing stream).  On the one-rank group: the capture succeeds, five replays run, and parameters / EMA / latent learner /
+losses agree bit for bit with the eager collective step and with the step that has no collective at all.
 """
 import os
 import socket
@@ -88,6 +93,38 @@ def _worker(port, q):
         result['worst'] = max(float((a['param'].double() - b['param'].double()).abs().max())
                               for a, b in zip(piped, plain))
         result['moved'] = float((piped[-1]['param'] - piped[0]['param']).abs().max())
+        # ---- the same iterations with the all-reduces captured inside the iteration's hipGraph
+        try:
+            trg = GangealingTrainer(dev, collectives=True, use_graph=True, graph_warmup=1, **KW)
+            assert trg.collectives and trg.use_graph and not trg.pipeline_update
+            calls.clear()
+            dist.all_reduce = spy
+            graphed = _iterate(trg)                  # call 1 eager, call 2 captures + replays, call 3 replays
+            more = []
+            for step in range(STEPS, STEPS + 2):     # two more replays
+                torch.manual_seed(100 + step)
+                more.append(float(trg.step(psi=0.5)['p']))
+            torch.cuda.synchronize()
+            dist.all_reduce = real
+            result['graph_captured'] = trg._graph is not None
+            result['graph_steps'] = (trg.stn_arena.step_count, trg.ll_arena.step_count)
+            result['graph_params_finite'] = bool(torch.isfinite(trg.stn_arena.param).all())
+            # python-level all_reduce calls: 2 in the eager warm-up iteration + 2 while capturing; replays issue none
+            result['graph_allreduce_calls'] = len(calls)
+            del trg
+            # reference: the same graph path with NO collective in it (a one-rank sum is the identity, so any difference
+            # is a hand-off bug between the capturing stream and RCCL's stream inside the graph) ...
+            solo = _iterate(GangealingTrainer(dev, collectives=False, use_graph=True, graph_warmup=1, **KW))
+            result['graph_bitwise'] = all(torch.equal(a[k], b[k]) for a, b in zip(graphed, solo)
+                                          for k in ('param', 'ema', 'll'))
+            result['graph_loss_same'] = all(a['loss'] == b['loss'] for a, b in zip(graphed, solo))
+            # ... and the eager step (host-side vs device-resident Adam scalars: equal to rounding)
+            result['graph_vs_eager'] = max(float((a['param'].double() - b['param'].double()).abs().max())
+                                           for a, b in zip(graphed, plain))
+            result['graph_more_finite'] = all(l == l and abs(l) != float('inf') for l in more)
+        except Exception as e:
+            import traceback
+            result['graph_error'] = ''.join(traceback.format_exception(type(e), e, e.__traceback__))[-3000:]
         dist.destroy_process_group()
     except Exception as e:          # surface the failure in the parent instead of a queue timeout
         import traceback
@@ -111,4 +148,10 @@ def test_single_rank_rccl_all_reduce_of_the_real_arena(cuda):
     assert len(res['exposed_ms']) == STEPS
     assert res['moved'] > 0
     assert res['bitwise'] and res['loss_same'], ('collective path differs from the plain path', res['worst'])
+    # the all-reduces captured inside the iteration's hipGraph (round 6)
+    assert 'graph_error' not in res, res['graph_error']
+    assert res['graph_captured'] and res['graph_allreduce_calls'] == 4, res['graph_allreduce_calls']
+    assert res['graph_bitwise'] and res['graph_loss_same'], 'captured collectives changed the replayed iteration'
+    assert res['graph_vs_eager'] <= 1e-5, res['graph_vs_eager']          # (learning rate 1e-4: one Adam step moves 1e-4)
+    assert res['graph_more_finite'] and res['graph_params_finite'] and res['graph_steps'] == (STEPS + 2, STEPS + 2)
     assert p.exitcode == 0
