@@ -78,13 +78,17 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+PMC_RECORDS = ('r06_pmc_traffic.json', 'r06_pmc_traffic_c4.json', 'r06_pmc_traffic_c5.json', 'r05_pmc_traffic.json',
+               'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+
+
 def pmc_traffic(precision, workload, batch):
     """HBM bytes per launch of the dominant kernel, measured offline with rocprofv3 --pmc on this same command
     (scripts/measure_r04.sh) and committed under profiles/.  None for configurations that were not profiled AND
     whenever the recorded kernel-source hash differs from the tree's (a profile of another version of the kernel says
     nothing about this one)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in PMC_RECORDS:
         try:
             with open(os.path.join(here, 'profiles', name)) as f:
                 rec = json.load(f)
@@ -95,6 +99,23 @@ def pmc_traffic(precision, workload, batch):
                 return None
             return rec.get('hbm_bytes_per_launch')
     return None
+
+
+def pmc_traffic_source(precision, workload, batch):
+    """Where roofline.traffic comes from: it is RECORDED (a rocprofv3 --pmc session cannot run inside this process),
+    and replayed only while the kernel sources hash to what was profiled."""
+    for name in PMC_RECORDS:
+        try:
+            with open(os.path.join(REPO, 'profiles', name)) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if (rec.get('precision'), rec.get('workload'), rec.get('batch')) == (precision, workload, batch):
+            if rec.get('kernel_source_sha16') != kernel_source_hash():
+                return f'none: profiles/{name} was recorded for other kernel sources ({rec.get("kernel_source_sha16")})'
+            return (f'recorded: profiles/{name} ({rec.get("command", "rocprofv3 --pmc")}; {rec.get("commit", "")}), replayed '
+                    f'because the kernel-source hash {rec.get("kernel_source_sha16")} equals this tree\'s')
+    return 'none: this configuration was not profiled'
 
 
 DTYPE = {'fp32': 'f32', 'bf16': 'bf16 (convolution operands rounded to bf16, fp32 accumulate, fp32 activations)', 'bf16x3': 'bf16x3 (fp32 operands split into 2 bf16 limbs, fp32 accumulate)',
@@ -252,7 +273,7 @@ def _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile)
     # keyed by the kernel instantiation the library reports (gg_last_conv_kernel).  Config C2 at its benchmark batch
     # keeps the launch predicate validated against rocprofv3 (conv_mfma.conv_forward); every other workload times, in
     # its timed region, the kernel the survey found on top.
-    survey, dominant = None, None
+    survey, dominant, step_classes = None, None, None
     if profile and not graphed and world == 1:
         sv = conv_mfma.LaunchProfiler(every=True)
         conv_mfma.PROFILER = sv
@@ -261,6 +282,16 @@ def _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile)
         trainer.flush()
         conv_mfma.PROFILER = None
         table = sv.by_kernel()
+        # whole-step classes (roofline.step): every convolution launch is MFMA-class work with its algorithmic FLOPs,
+        # every FIR / blur launch HBM-class work with its algorithmic bytes; everything else of the step (streaming
+        # activations, samplers, optimizer, ATen glue) is what remains of ms_per_step
+        step_classes = dict(
+            mfma_ms=sum(v['ms'] for v in table.values() if v['unit'] == 'flop') / 2,
+            mfma_flop=sum(v['work'] for v in table.values() if v['unit'] == 'flop') / 2,
+            mfma_launches=sum(v['launches'] for v in table.values() if v['unit'] == 'flop') / 2,
+            hbm_ms=sum(v['ms'] for v in table.values() if v['unit'] == 'byte') / 2,
+            hbm_bytes=sum(v['work'] for v in table.values() if v['unit'] == 'byte') / 2,
+            hbm_launches=sum(v['launches'] for v in table.values() if v['unit'] == 'byte') / 2)
         survey = [dict(kernel=k, launches_per_step=v['launches'] / 2, ms_per_step=round(v['ms'] / 2, 4),
                        rate=round(v['work'] / (v['ms'] * 1e-3) / 1e12, 3) if v['ms'] > 0 else 0.0,
                        unit='TFLOP/s' if v['unit'] == 'flop' else 'TB/s')
@@ -273,10 +304,13 @@ def _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile)
         conv_mfma.PROFILER = prof        # HIP events around the dominant kernel's launches inside the timed region
     if world > 1:
         trainer.comm_events = []
+    from gangealing_amd import _lib as _gglib
+    calls0 = _gglib.CALLS
     t0 = time.perf_counter()
     for _ in range(steps):
         parts = trainer.step(psi=0.5)
     trainer.flush()                      # a deferred (pipelined) optimizer step belongs to the timed region
+    lib_calls = (_gglib.CALLS - calls0) / max(steps, 1)
     torch.cuda.synchronize()
     own = time.perf_counter() - t0       # this rank's own time, before waiting for the others
     barrier()
@@ -302,13 +336,17 @@ def _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile)
                          ms_per_step_rank_min=round(min(ms), 3), ms_per_step_rank_max=round(max(ms), 3),
                          allreduce_exposed_ms_per_step_max_rank=round(float(ex.item()), 4),
                          allreduce_bytes=int(trainer.stn_arena.numel * 4), pipelined_update=bool(trainer.pipeline_update),
+                         ms_per_step_per_rank=[round(v, 3) for v in ms],
+                         collective_env={k: v for k, v in sorted(os.environ.items())
+                                         if k.startswith(('NCCL_', 'RCCL_', 'HSA_', 'TORCH_NCCL_')) or k == 'HIP_VISIBLE_DEVICES'},
                          devices=sorted({torch.cuda.current_device()}))
     loss = float(parts['p'])
     assert loss == loss and abs(loss) != float('inf'), 'non-finite loss'
     reported = sorted({r[3] for r in prof.records}) if (profile and not graphed) else None
-    res = dict(elapsed=elapsed, loss=loss, graphed=graphed, prof=prof.summary() if (profile and not graphed) else None,
+    res = dict(elapsed=elapsed, steps=steps, loss=loss, graphed=graphed, prof=prof.summary() if (profile and not graphed) else None,
                reported=reported,
                images=world * wl['batch'] * steps, dist=dist_info, survey=survey, dominant=dominant,
+               step_classes=step_classes, lib_calls=lib_calls,
                dominant_unit=(prof.records[0][4] if (dominant and prof.records) else 'flop'))
     del trainer
     torch.cuda.empty_cache()
@@ -385,6 +423,85 @@ def measure_reference_dropin(device, wl, precision, steps, warmup, modules=False
                 source=os.path.relpath(root, REPO) if root.startswith(REPO) else root)
 
 
+def recorded_parity(test, mode):
+    """The error of arithmetic `mode` against the reference's fixture `test`, as the GPU suite MEASURED it
+    (tests/test_gpu_configs.py -> gpurun_out/parity_report.json -> committed as profiles/parity_rNN.json).  Recorded, not
+    measured by this run: the fixture comparison belongs to the test suite."""
+    for name in ('parity_r06.json', 'parity_r05.json'):
+        try:
+            with open(os.path.join(REPO, 'profiles', name)) as f:
+                rec = json.load(f).get(test, {}).get(mode)
+        except (OSError, ValueError):
+            continue
+        if rec:
+            acts = {k: v['max_abs_err'] for k, v in rec.items()
+                    if isinstance(v, dict) and 'max_abs_err' in v and k.endswith(('_first', '_sub'))}
+            if acts:
+                worst = max(acts, key=acts.get)
+                return {'max_abs_err': acts[worst], 'max_abs_err_tensor': f'{test}/{worst}',
+                        'max_abs_err_source': f'recorded: profiles/{name} (activations of {test} against the reference\'s CPU '
+                                              f'fixture, measured by tests/test_gpu_configs.py; NOT a parity mode - the '
+                                              f'1e-4 bound is met by fp16x3)'}
+    return {'max_abs_err': None, 'max_abs_err_source': 'not recorded'}
+
+
+def allreduce_only(device, wl, world, iters, warmup):
+    """The step's only data-path collective by itself: all-reduce (SUM) of a float32 buffer with the element count of the
+    workload's STN gradient arena, `iters` times back to back, each timed with HIP events on the issuing stream (the
+    collective runs on RCCL's stream; the events bracket the hand-off there and back).  bus bandwidth = algorithm
+    bandwidth x 2 (world - 1) / world (ring all-reduce moves that multiple of the buffer over each link).  On a 7-link
+    xGMI node a ring is bound by one link direction (~ 50 - 60 GB/s effective per direction per link): the 172 MB arena
+    should take ~ 5 - 6 ms at 8 ranks if RCCL uses one ring, ~ 1 ms with all links - compare with `distributed.
+    allreduce_exposed_ms_per_step_max_rank` of the full run."""
+    import torch.distributed as dist
+    from gangealing_amd.spatial_transformers.spatial_transformer import get_stn
+    with torch.device('meta'):
+        stn = get_stn(list(wl['transform']), flow_size=wl['flow_size'], supersize=wl['gen_size'], channel_multiplier=0.5,
+                      num_heads=wl['num_heads'])
+    numel = sum(p.numel() for p in stn.parameters())
+    buf = torch.randn(numel, device=device) * 1e-3
+    have_group = dist.is_available() and dist.is_initialized()
+
+    def reduce_():
+        if have_group:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+
+    for _ in range(max(warmup, 2)):
+        reduce_()
+    torch.cuda.synchronize()
+    if have_group:
+        dist.barrier()
+    evs = []
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        reduce_()
+        b.record()
+        evs.append((a, b))
+        buf.mul_(1.0 / max(world, 1))          # keep the values bounded; also forces the stream hand-off each iteration
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    mine = torch.tensor([sum(ms) / len(ms), ms[0], ms[-1], 1e3 * wall / iters], device=device, dtype=torch.float64)
+    rows = [mine]
+    if have_group and world > 1:
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+    per_rank = [[round(float(v), 4) for v in r.tolist()] for r in rows]
+    mean_ms = max(r[0] for r in per_rank)
+    nbytes = numel * 4
+    algbw = nbytes / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
+    return {'metric': 'gradient all-reduce of the STN arena (bench.py --allreduce-only)', 'n_gpus': world,
+            'backend': dist.get_backend() if have_group else 'none (single process: no collective issued)',
+            'bytes': nbytes, 'iters': iters,
+            'ms_mean_max_over_ranks': round(mean_ms, 4), 'algbw_GBps': round(algbw, 2),
+            'busbw_GBps': round(algbw * 2 * (world - 1) / max(world, 1), 2),
+            'per_rank_ms_mean_min_max_wall': per_rank,
+            'collective_env': {k: v for k, v in sorted(os.environ.items())
+                               if k.startswith(('NCCL_', 'RCCL_', 'HSA_', 'TORCH_NCCL_')) or k == 'HIP_VISIBLE_DEVICES'}}
+
+
 def roofline_of(run, precision, workload, batch):
     """The `roofline` object of one measured run (measure()): the workload's dominant kernel, timed with HIP events over
     the timed region on the stream it is launched on.  `kernel` is what the library's dispatcher REPORTED for the timed
@@ -402,7 +519,8 @@ def roofline_of(run, precision, workload, batch):
             bound, peak, u = 'mfma', (MFMA_PEAK_TFLOPS['fp32'] if 'fp32' in name else MFMA_PEAK_TFLOPS[precision]), 'TFLOP/s'
         roof = {
             'bound': bound, 'achieved': round(rate, 3), 'peak': peak, 'unit': u, 'frac': round(rate / peak, 4),
-            'traffic': None, 'kernel': name,
+            'traffic': pmc_traffic(precision, workload, batch),
+            'traffic_source': pmc_traffic_source(precision, workload, batch), 'kernel': name,
             'note': 'the kernel instantiation with the largest share of this workload\'s GPU time (survey below: two '
                     'un-timed steps with HIP events around every convolution / FIR launch, keyed by '
                     'gg_last_conv_kernel); achieved = algorithmic FLOPs (2*N*Cin*Cout*k*k*positions) or algorithmic '
@@ -422,6 +540,7 @@ def roofline_of(run, precision, workload, batch):
             'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
             'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
             'traffic': pmc_traffic(precision, workload, batch),
+            'traffic_source': pmc_traffic_source(precision, workload, batch),
             'kernel': ' + '.join(reported) if reported else 'unknown',
             'kernel_detail': KERNEL_NAME[precision],
             'mfma_products_per_flop': MFMA_PRODUCTS[precision],
@@ -440,6 +559,30 @@ def roofline_of(run, precision, workload, batch):
         }
     if run.get('survey'):
         roof['kernels'] = run['survey']
+    sc = run.get('step_classes')
+    if sc:
+        ms_step = 1e3 * run['elapsed'] / max(run.get('steps', 1), 1)
+        tflop = sc['mfma_flop'] / 1e12
+        roof['step'] = {
+            'algorithmic_tflop_per_step': round(tflop, 4),
+            'achieved_tflops': round(tflop / (ms_step * 1e-3), 2), 'peak_tflops': MFMA_PEAK_TFLOPS[precision],
+            'frac': round(tflop / (ms_step * 1e-3) / MFMA_PEAK_TFLOPS[precision], 4),
+            'mfma_class': {'ms_per_step': round(sc['mfma_ms'], 3), 'launches_per_step': sc['mfma_launches'],
+                           'tflops': round(tflop / (sc['mfma_ms'] * 1e-3), 2) if sc['mfma_ms'] > 0 else None},
+            'hbm_class': {'ms_per_step': round(sc['hbm_ms'], 3), 'launches_per_step': sc['hbm_launches'],
+                          'algorithmic_gb_per_step': round(sc['hbm_bytes'] / 1e9, 3),
+                          'tb_per_s': round(sc['hbm_bytes'] / 1e12 / (sc['hbm_ms'] * 1e-3), 3) if sc['hbm_ms'] > 0 else None,
+                          'frac_of_8_tb_per_s': round(sc['hbm_bytes'] / 1e12 / (sc['hbm_ms'] * 1e-3) / 8.0, 4)
+                          if sc['hbm_ms'] > 0 else None},
+            'rest_ms_per_step': round(ms_step - sc['mfma_ms'] - sc['hbm_ms'], 3),
+            'library_calls_per_step': round(run.get('lib_calls', 0.0), 1),
+            'note': 'the WHOLE step: algorithmic convolution FLOPs of every convolution launch of a step (2*N*Cin*Cout*k*k*'
+                    'positions, summed over the survey\'s launches; matches SURVEY.md appendix C) / ms_per_step of the timed '
+                    'region, as a fraction of the dense 16-bit MFMA peak; mfma_class / hbm_class = HIP-event time of all '
+                    'convolution / all FIR-blur launches in the two survey steps (events around every launch: slightly '
+                    'slower than the timed region); rest = streaming activations, samplers, perceptual-loss tails, '
+                    'optimizer, ATen glue and idle; library_calls_per_step = C-ABI entry-point calls per step in the timed '
+                    'region (an entry point launches 1 - 3 kernels; the rocprofv3 dispatch count is in profiles/)'}
     return roof
 
 
@@ -459,6 +602,10 @@ def main():
                     help='time hipGraph replays of the iteration instead of eager launches (one graph on a single GPU; no '
                          'roofline entry: HIP events cannot be recorded inside a replayed graph).  With --gpus > 1 the '
                          'gradient all-reduces are captured inside the graph (nccl / RCCL backend only; gloo raises)')
+    ap.add_argument('--allreduce-only', action='store_true',
+                    help='micro-mode for attributing a poor scaling curve: no training step, only the gradient exchange of '
+                         'one - 50 all-reduces of a buffer the size of the STN gradient arena (C2: 43 M fp32 = 172 MB) on '
+                         'the same process group; prints per-rank ms, algorithm and bus bandwidth')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the additional single-GPU measurements (hipGraph replay, plain-bf16 arithmetic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -489,6 +636,14 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl['batch'] = args.batch
+    if args.allreduce_only:
+        out = allreduce_only(device, wl, world, max(args.steps, 1) * 5, args.warmup)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            gdist.synchronize()
+            torch.distributed.destroy_process_group()
+        return
     main_run = measure(device, wl, args.precision, args.graph, args.steps, args.warmup, world, gdist)
 
     if rank == 0:
@@ -536,6 +691,8 @@ def main():
                 extras[name] = {'value': round(r['images'] / r['elapsed'], 3),
                                 'ms_per_step': round(1e3 * r['elapsed'] / args.steps, 3), 'dtype': DTYPE[prec],
                                 'launch': 'hipGraph replay' if r['graphed'] else 'eager'}
+                if prec == 'bf16':
+                    extras[name].update(recorded_parity('cfg_c2', 'bf16'))
                 if form == 'grouped':
                     extras[name]['generator'] = ('reference formulation: materialised (N*Cout, Cin, k, k) weights, '
                                                  'conv2d / conv_transpose2d with groups = N')

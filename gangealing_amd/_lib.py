@@ -181,6 +181,7 @@ def _dev_ptr(t):
 
 
 _ENTRY = {}          # name -> (ctypes function, prototype string, argument count): resolved once per entry point
+CALLS = 0            # entry-point calls so far (bench.py reports calls per step)
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
@@ -196,6 +197,8 @@ def call(name, *args, allow=()):
     """Invoke a C-ABI entry point on torch's current HIP stream; the trailing stream argument is
     supplied here.  Tensors are passed as raw device pointers.  Returns the status code; codes other than 0 raise
     unless listed in `allow` (e.g. NOT_SERVED = "shape not served, nothing launched" of the optional fused entry points)."""
+    global CALLS
+    CALLS += 1
     ent = _ENTRY.get(name)
     if ent is None:
         lib = load()

@@ -267,6 +267,36 @@ def test_config_loss_step(name, mode, cuda):
     check_grads(test + '/latent-learner', mode, grads, c, select=lambda k: k == 'll.coefficients', floor_scale=LL_FLOOR_SCALE)
 
 
+def test_config_c2_one_limb_bf16_error_is_recorded(cuda):
+    """BASELINE.json configs[1] names "bf16".  The package's plain-bf16 arithmetic (ONE bf16 limb per operand, fp32
+    accumulate: `extras.bf16_eager` of the bench line) is not a parity mode - north_star's 1e-4 is met by fp16x3 - but its
+    distance from the reference on the benchmark configuration is measured here and recorded (parity report ->
+    profiles/parity_r06.json -> bench.py prints it as extras.bf16_eager.max_abs_err).  Bounds are sanity only: a limb of 8
+    significand bits through 14 + 14 + 13 convolution layers leaves ~1e-2 of the activation scale."""
+    from gangealing_amd.op import conv_mfma
+    from oracle import config_cases as cc
+    (c,) = load_golden('cfg_c2')
+    old = conv_mfma.PRECISION
+    conv_mfma.set_precision('bf16')
+    try:
+        res = cc.run_config(our_api(), 'c2', cuda)
+    finally:
+        conv_mfma.set_precision(old)
+    worst = 0.0
+    for key in ('unaligned', 'target', 'pred', 'stn_delta', 'delta_flow'):
+        packed = cc.pack_batch(res[key], key)
+        for part in ('first', 'sub'):
+            k = f'{key}_{part}'
+            err = record_parity('cfg_c2', 'bf16', k, packed[k], c[k])
+            worst = max(worst, err / max(1.0, float(np.abs(c[k]).max())))
+    for key in ('ploss', 'total', 'tv', 'identity'):
+        record_parity('cfg_c2', 'bf16', key, res[key].cpu().numpy(), c[key])
+    from conftest import PARITY
+    PARITY['cfg_c2']['bf16']['worst_activation_err_over_scale'] = dict(value=worst)
+    assert 1e-4 < worst < 0.25, worst          # far outside the parity bound, far inside "the same picture"
+    assert abs(float(res['ploss']) - float(c['ploss'])) <= 0.2 * abs(float(c['ploss']))
+
+
 def test_config_c5_batch16_from_reference_halves(mode, cuda):
     """C5 at the per-GPU batch `bench.py --workload c5 --batch 16` (extras.c5_batch16) and the reference's 8-GPU recipe
     run (scripts/training/lsun_cars.sh:4-7).  The reference cannot evaluate this batch on the authoring host (> 62 GB
