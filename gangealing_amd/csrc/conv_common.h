@@ -57,6 +57,10 @@ struct ConvArgs {
   int f16;                        // split-precision limbs are binary16 (forward convolutions), see Limb<>
   float acc_scale;                // accumulators are multiplied by this first (1 / kF16WeightScale with f16 limbs)
   int nt_store;                   // the 8-wave tiles' epilogues store with the non-temporal hint (outputs beyond the caches)
+  // binary16 limbs: lower edge of the E = 0 band of the block exponent (see f16_block_exp).  2^-3 for forward operands
+  // (activations: bit-identical to the unscaled kernel over their usual range), 2^5 for GRADIENT operands (format code
+  // bit 5): a chunk is then staged unscaled only where that loses nothing against the normalised form
+  float exp_lo;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -174,7 +178,12 @@ struct Limb<true> {
 // accumulators by 2^E in the epilogue - both exact.  E comes from the data itself: while a chunk (32 input channels of
 // the tile's patch, or one gathered slab) waits in registers, the block takes the maximum magnitude of what it is about
 // to stage (v_max per element, one wave butterfly, one LDS word per wave, published by a barrier the loop already has).
-//   * amax in [2^-3, 2^11]: E = 0, nothing is scaled (bit-identical to the unscaled kernel; 16x headroom to 65504);
+//   * amax in [lo, 2^11]: E = 0, nothing is scaled (16x headroom to 65504).  lo = 2^-3 for forward operands (activations:
+//     bit-identical to the unscaled kernel over their usual range; an element keeps an ABSOLUTE 2^-25, which the 1e-4
+//     activation bound never sees).  Round 6: lo = 2^5 for GRADIENT operands (ConvArgs::exp_lo).  With 2^-3 a gradient
+//     chunk holding one outlier in [0.125, 1) among entries of 1e-5 was staged unscaled and its small entries kept only
+//     2^-25 / 1e-5 = 3e-3 relative - 512x worse than the same chunk an ulp below the band edge, invisible to tests that
+//     bound err / max|ref|.  At 2^5 the unscaled form's floor (2^-25 <= 2^-30 amax) is what normalising would give;
 //   * otherwise E = floor(log2 amax) - 6, i.e. amax 2^-E in [2^6, 2^7): limb 0 keeps 11 bits of every element down to
 //     2^-14 of that, limb 1 another 11 bits down to 2^-3 and an ABSOLUTE 2^-25 below - 2^-31 of the chunk's largest
 //     element, so the error of a dot product is 2^-22 of its terms' scale whatever the operand's magnitude;
@@ -193,8 +202,8 @@ struct BlockExp {
 // within 2^6 of it.  exp2i saturates outside [-126, 127]: a rescale factor 2^(E_old - E_new) below 2^-126 (a tile whose
 // chunks differ by more than 126 binades) flushes the older, negligible, accumulators to zero instead of producing
 // garbage bits.
-__device__ __forceinline__ int f16_block_exp(float amax) {          // amax > 0, uniform
-  if (amax >= 0.125f && amax <= 2048.f) return 0;
+__device__ __forceinline__ int f16_block_exp(float amax, float lo) {          // amax > 0, uniform
+  if (amax >= lo && amax <= 2048.f) return 0;
   int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127 - 6;
   return e < -120 ? -120 : (e > 121 ? 121 : e);
 }
@@ -204,15 +213,15 @@ __device__ __forceinline__ float exp2i(int e) {
   return __builtin_bit_cast(float, (unsigned)(127 + e) << 23);
 }
 // -> factor for the accumulators (1 = leave them), updates `b` for a chunk whose largest magnitude is `amax`
-__device__ __forceinline__ float block_exp_update(BlockExp& b, float amax) {
+__device__ __forceinline__ float block_exp_update(BlockExp& b, float amax, float lo) {
   if (!(amax > 0.f)) return 1.f;
   if (!b.set) {
     b.set = 1;
-    b.e = f16_block_exp(amax);
+    b.e = f16_block_exp(amax, lo);
     return 1.f;                       // the accumulators are still zero
   }
   if (amax * exp2i(-b.e) <= 2048.f) return 1.f;
-  const int ne = f16_block_exp(amax);
+  const int ne = f16_block_exp(amax, lo);
   const float f = exp2i(b.e - ne);    // ne > b.e
   b.e = ne;
   return f;

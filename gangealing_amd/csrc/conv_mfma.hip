@@ -424,7 +424,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
     }
     for (int slab = slab0; slab < slab1; ++slab) {
       if (F16) {            // the slab's block exponent (published behind the previous barrier)
-        const float f = block_exp_update(bexp, read_block_amax<NT / 64>(sAmax));
+        const float f = block_exp_update(bexp, read_block_amax<NT / 64>(sAmax), a.exp_lo);
         if (f != 1.f) {
 #pragma unroll
           for (int i = 0; i < MI; ++i)
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   float amax_next = 0.f;                // pipelined tile: the next chunk's magnitude, fetched one barrier early
   auto begin_chunk = [&](int chunk) {
     if (F16) {
-      const float f = block_exp_update(bexp, PIPE ? amax_next : read_block_amax<NT / 64>(sAmax));
+      const float f = block_exp_update(bexp, PIPE ? amax_next : read_block_amax<NT / 64>(sAmax), a.exp_lo);
       if (f != 1.f) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(TQ * 4, 2) void convT3x3s2_patch_kernel(const ConvA
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
       __syncthreads();
       if (F16) {          // block exponent of this chunk (rescales the accumulators if it grew)
-        const float f = block_exp_update(bexp, read_block_amax<NT / 64>(sAmax));
+        const float f = block_exp_update(bexp, read_block_amax<NT / 64>(sAmax), a.exp_lo);
         if (f != 1.f) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
@@ -3332,8 +3332,12 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   if (mode == 0 && (stride < 1 || stride > 2)) return gg::fail(-2, "conv2d: stride must be 1 or 2");
   if (mode == 1 && stride != 2)
     return gg::fail(-2, "conv2d: transposed mode is implemented for stride 2 (stride 1 = mode 0 with flipped taps)");
-  const bool f16 = (limbs & 16) != 0;      // format code: bit 4 = binary16 limbs (see Limb<>), low bits = limb count
-  if (f16 && limbs != 18) return gg::fail(-2, "conv2d_split: binary16 limbs come in pairs (code 18)");
+  // format code: low bits = limb count, bit 4 = binary16 limbs (see Limb<>), bit 5 = the operand x is a GRADIENT (binary16
+  // limbs only: the block exponent's E = 0 band starts at 2^5 instead of 2^-3, conv_common.h)
+  const bool grad_operand = (limbs & 32) != 0 || mask.ref != nullptr || mask.bits != nullptr;
+  limbs &= ~32;
+  const bool f16 = (limbs & 16) != 0;
+  if (f16 && limbs != 18) return gg::fail(-2, "conv2d_split: binary16 limbs come in pairs (code 18 / 50)");
   limbs &= 15;
   if (limbs) {
     if (limbs < 1 || limbs > 3) return gg::fail(-2, "conv2d_split: limbs must be 1, 2, 3 or 18");
@@ -3347,6 +3351,7 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   a.wsplit = wsplit; a.wsplit_stride = wsplit_stride;
   a.part = nullptr; a.part_stride = 0;
   a.f16 = f16 ? 1 : 0;
+  a.exp_lo = grad_operand ? 32.f : 0.125f;
   a.acc_scale = f16 ? 1.f / kF16WeightScale : 1.f;
   a.mask_ref = mask.ref; a.mask_alpha = mask.alpha; a.mask_gain = mask.gain;
   a.mask_bits = mask.bits;

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(TPIX * 2, TPIX == 128 ? (S == 1 ? 3 : 2) : 1) void 
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
       const bool more = chunk + 1 < chunk1;
       __syncthreads();                    // the previous chunk's readers are done with sP
-      if (F16) rescale_acc(block_exp_update(bexp, read_block_amax<NT / 64>(sAmax)));
+      if (F16) rescale_acc(block_exp_update(bexp, read_block_amax<NT / 64>(sAmax), a.exp_lo));
       else prep_patch(chunk);
       split_patch();
       write_patch();

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(TCO * 4, 2) void convT3x3s2_c16_kernel(const ConvAr
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
       __syncthreads();                       // the previous chunk's readers are done with sP / sW
       if (F16) {          // block exponent of this chunk (rescales the accumulators if it grew)
-        const float f = block_exp_update(bexp, read_block_amax<NW>(sAmax));
+        const float f = block_exp_update(bexp, read_block_amax<NW>(sAmax), a.exp_lo);
         if (f != 1.f) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)

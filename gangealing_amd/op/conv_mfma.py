@@ -71,6 +71,20 @@ def last_conv_kernel():
 
 PROFILER = None
 
+
+def _prof_begin(sig):
+    """(profiler, start event) when the installed profiler times launches of signature `sig`, else (None, None)."""
+    p = PROFILER
+    if p is None or not p.every or not p.wants(sig):
+        return None, None
+    return p, p.begin()
+
+
+def _prof_end(p, start, sig, work, name):
+    if p is not None:
+        p.names[sig] = name
+        p.end(start, work, name)
+
 # Arithmetic of the implicit-GEMM convolutions:
 #   'fp32'   v_mfma_f32_32x32x2_f32 - exact fp32 products (the parity mode, default)
 #   'bf16x3' / 'bf16x6'  bf16 matrix pipe with 2 / 3 bf16 limbs per fp32 operand (3 / 6 MFMAs per tile step,
@@ -111,7 +125,13 @@ def limb_code(grad=False, generic=False):
     limbs = _LIMBS[PRECISION]
     if grad and generic and not _F16_GRAD_GENERIC:
         return limbs
-    return limbs | 16 if PRECISION in (_F16_GRAD if grad else _F16_FORWARD) else limbs
+    if PRECISION in (_F16_GRAD if grad else _F16_FORWARD):
+        # + 32 (round 6): the operand is a gradient - the block exponent's unscaled band starts at 2^5, not 2^-3
+        return limbs | 16 | (GRAD_OPERAND if grad else 0)
+    return limbs
+
+
+GRAD_OPERAND = 32
 
 
 _S2_PATCH = _os.environ.get('GG_S2_PATCH', '1') != '0'      # (the library reads the same switch)
@@ -194,7 +214,9 @@ class PackedWeight:
         return self.cin_g % 32 == 0 and self.cout_g > 32
 
     def split(self, limbs):
-        """limbs: format code (limb_code): 1 | 2 | 3 bf16 limbs, 18 = two binary16 limbs (pre-scaled weights)."""
+        """limbs: format code (limb_code): 1 | 2 | 3 bf16 limbs, 18 = two binary16 limbs (pre-scaled weights); the
+        gradient-operand bit (32) of a launch code does not concern the pack."""
+        limbs &= ~GRAD_OPERAND
         if limbs not in self._split:
             n = self.groups * self.cout_g * self.cin_g * self.k * self.k
             buf = torch.empty((limbs & 15, n), dtype=torch.int16, device=self.weight.device)
@@ -337,6 +359,7 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
     if y.numel():
         code = limb_code(grad, grad and _generic_shape(k, stride, pad, mode, w, h))
         limbs = code & 15
+        pack_code = code & ~GRAD_OPERAND
         use_split = limbs > 0 and isinstance(wmat, PackedWeight) and wmat.split_ok()
         prof = sig = None
         if PROFILER is not None and PROFILER.every:
@@ -365,7 +388,7 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             noise, noise_weight, act_bias, alpha, gain = act       # noise / noise_weight / act_bias may be None
             wbuf, stride_l = wmat.split(code) if use_split else (None, 0)
             wm = None if use_split else (wmat.fp32() if isinstance(wmat, PackedWeight) else wmat)
-            if (want_sign_bits and use_split and code == 18 and cout_g % 32 == 0 and 'sign_bits' not in DISABLED
+            if (want_sign_bits and use_split and pack_code == 18 and cout_g % 32 == 0 and 'sign_bits' not in DISABLED
                     and ACT_OBSERVER is None):
                 sign_bits = torch.empty((batch, oh * ow, cout_g // 32), dtype=torch.int32, device=x.device)
                 _lib.call('gg_modconv3x3_act_bits_f32', y, x, wm, wbuf, stride_l, code, in_scale, out_scale,
@@ -476,6 +499,17 @@ def conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, pad, scale=1.0, i
     stem = k == 1 and stride == 1 and pad == 0 and groups == 1 and cin_g <= 4 and (h * w) % 64 == 0   # RGB stem
     rows = split and k == 3 and stride == 1 and pad == 1 and (w % 32 == 0 or (w == 16 and h % 2 == 0))
     dw = into if into is not None else torch.empty((groups * cout_g, cin_g, k, k), dtype=torch.float32, device=x.device)
+    sig = ('wgrad', batch, groups, cin_g, cout_g, h, w, k, stride, pad, limbs)
+    prof, start = _prof_begin(sig)
+    try:
+        return _conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, pad, scale, into, h, w, limbs, split, stem,
+                           rows, dw)
+    finally:
+        _prof_end(prof, start, sig, 2.0 * batch * groups * cout_g * cin_g * k * k * oh * ow,
+                  f'conv_wgrad<k{k},s{stride},{"rows" if rows else ("stem" if stem else "generic")},limbs{limbs if (split or stem) else 0}>')
+
+
+def _conv_wgrad(x, dy, batch, groups, cin_g, cout_g, k, stride, pad, scale, into, h, w, limbs, split, stem, rows, dw):
     if 'wgrad_rows' in DISABLED and (stem or rows):
         # A/B switch: the generic kernels (the row-streaming kernel is what gg_conv2d_wgrad_ws_f32 would choose)
         if into is not None:
@@ -759,19 +793,25 @@ def masked_dgrad(dy, y_act, alpha, gain, wmat_bwd, n, cin, cout, h, w, in_scale=
     layer's output channels), `cout` = the layer's input channels.  None when the shape is not served.
     sign_bits: the 1-bit plane the layer's forward wrote (conv_forward(want_sign_bits=True)); the gather then reads one
     word per pixel and 32 channels instead of the 32 saved outputs - bitwise the same gradient."""
-    limbs = limb_code(grad=True)
+    limbs = limb_code(grad=True) & ~GRAD_OPERAND          # (the masked entry points imply the gradient-operand rule)
     if limbs not in (1, 2, 18) or 'mask_dgrad' in DISABLED or not isinstance(wmat_bwd, PackedWeight) or \
             not wmat_bwd.split_ok():
         return None
     wbuf, stride_l = wmat_bwd.split(limbs)
     dx = torch.empty((n, cout, h, w), dtype=torch.float32, device=dy.device)
+    sig = ('masked_dgrad', n, cin, cout, h, w, in_scale is None, sign_bits is not None, limbs)
+    prof, start = _prof_begin(sig)
+    work = 2.0 * n * cin * cout * 9 * h * w
     if sign_bits is not None and limbs == 18:
         rc = _lib.call('gg_conv3x3_masked_dgrad_bits_f32', dx, dy, sign_bits, alpha, gain, wbuf, stride_l, limbs,
                        in_scale, out_scale, n, cin, cout, h, w, allow=(_lib.NOT_SERVED,))
         if rc == 0:
+            _prof_end(prof, start, sig, work, last_conv_kernel() + '+lrelu-mask(sign plane)')
             return dx
     rc = _lib.call('gg_conv3x3_masked_dgrad_f32', dx, dy, y_act, alpha, gain, wbuf, stride_l, limbs, in_scale, out_scale,
                    n, cin, cout, h, w, allow=(_lib.NOT_SERVED,))
+    if rc == 0:
+        _prof_end(prof, start, sig, work, last_conv_kernel() + '+lrelu-mask(fp32 output)')
     return dx if rc == 0 else None
 
 

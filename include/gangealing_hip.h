@@ -318,6 +318,13 @@ int gg_conv2d_f32(float* y, const float* x, const float* wmat, const float* in_s
  * overflows and the output is inf / NaN (loud, never silently wrong); activations below ~1e-7 vanish.  Gradient
  * tensors span more than that: pass limbs = 2 for them (gg_conv3x3_masked_dgrad_f32 and the weight-gradient entry
  * points do not take 18).  A weight pack made with limbs = 18 must be used with limbs = 18 and vice versa.
+ * (Round 4: every tile carries a per-chunk block exponent taken from the data, so the range statement above is history
+ * - any finite operand is staged at full limb precision - and data gradients run on code 18 too.)
+ * limbs = 50 (= 32 + 18; ABI 5): as 18, and the operand x is a GRADIENT: the block exponent leaves a chunk unscaled
+ * (E = 0) only for amax in [2^5, 2^11] instead of [2^-3, 2^11] - unscaled, an entry keeps an absolute 2^-25, which an
+ * activation bound never sees but which is 3e-3 of a 1e-5 gradient entry next to an outlier of 0.5
+ * (tests/test_gpu_block_exponent_band.py).  The masked data-gradient entry points imply it.  gg_conv_pack_weight_split
+ * takes 18 for the pack of either.
  * Weights come pre-split from gg_conv_pack_weight_split: bf16 planes wsplit[limb][g][co][k], K ordered
  * (tap, ci) with ci fastest, limb planes `limb_stride` elements apart (= groups*cout_g*cin_g*kh*kw).
  * Requires cin_g % 32 == 0; every other argument as gg_conv2d_f32. */

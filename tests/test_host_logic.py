@@ -401,8 +401,8 @@ def test_limb_format_rule_follows_the_kernel_that_serves_the_shape():
         assert cm._generic_shape(*shape) is generic, shape
     try:
         cm.set_precision('fp16x3')
-        assert cm.limb_code() == 18 and cm.limb_code(grad=True) == (18 if cm._F16_GRAD else 2)
-        assert cm.limb_code(grad=True, generic=True) == (18 if cm._F16_GRAD_GENERIC else 2)
+        assert cm.limb_code() == 18 and cm.limb_code(grad=True) == (50 if cm._F16_GRAD else 2)   # 50 = 18 + gradient-operand bit
+        assert cm.limb_code(grad=True, generic=True) == (50 if cm._F16_GRAD_GENERIC else 2)
         assert cm.limb_code(grad=False, generic=True) == 18        # forward launches carry the range guarantee everywhere
         cm.set_precision('bf16x3')
         assert cm.limb_code() == 2 and cm.limb_code(grad=True) == 2
