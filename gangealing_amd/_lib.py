@@ -35,8 +35,8 @@ _PROTOS = {
     'gg_mip_downsample2x_f32': 'ppiiis',
     'gg_mip_downsample2x_bwd_f32': 'ppiiis',
     'gg_mipmap_warp_fwd_f32': 'ppppipiiiiiiiiiffiis',
-    'gg_mipmap_warp_bwd_f32': 'ppppppipiiiiiiiiiffiis',
-    'gg_mipmap_warp_indices_f32': 'pppppiiiiiffiis',
+    'gg_mipmap_warp_bwd_f32': 'ppppppipiiiiiiiiiffiips',
+    'gg_mipmap_warp_indices_f32': 'ppppppiiiiiffiis',
     'gg_affine_grid_f32': 'ppiiis',
     'gg_affine_grid_bwd_f32': 'ppiiis',
     'gg_flow_compose_fwd_f32': 'pppppiiiis',

@@ -147,8 +147,12 @@ struct LevelInfo {
   float ddx, ddy;   // (other - self) of the arg neighbour
 };
 
+// pin: -1, or the neighbour (0 l, 1 r, 2 u, 3 d) that the level's sub-gradient is routed through instead of this
+// evaluation's own arg-max (decision replay, tests/test_gpu_stn_decisions.py: under a similarity warp the four distances
+// are exactly tied in real arithmetic, so which one "is" the maximum is last-ulp noise in every implementation).  The
+// level itself - the forward value - is the true maximum's in either case.
 __device__ __forceinline__ LevelInfo mip_level(const float* __restrict__ grid_n, int oy, int ox, int ho, int wo,
-                                              int h, int w, float max_level, float min_level) {
+                                              int h, int w, float max_level, float min_level, int pin = -1) {
   const float* g = grid_n + ((size_t)oy * wo + ox) * 2;
   const float cx = level_coord(g[0], w), cy = level_coord(g[1], h);
   const int nx[4] = {max(ox - 1, 0), min(ox + 1, wo - 1), ox, ox};        // replicate pad (:73-80)
@@ -163,6 +167,15 @@ __device__ __forceinline__ LevelInfo mip_level(const float* __restrict__ grid_n,
     const float sqc = fmaxf(sq, 1.f);                                     // clamp BEFORE the sqrt (:84-87)
     const float d = sqrtf(sqc);
     if (!(d <= dmax)) { dmax = d; arg = k; sqmax = sq; bdx = dx; bdy = dy; }   // first max wins
+  }
+  float dgrad = dmax;                    // the distance the gradient flows through
+  if (pin >= 0 && pin < 4 && pin != arg) {
+    const float* q = grid_n + ((size_t)ny[pin] * wo + nx[pin]) * 2;
+    bdx = sub_rn(level_coord(q[0], w), cx);
+    bdy = sub_rn(level_coord(q[1], h), cy);
+    sqmax = add_rn(mul_rn(bdx, bdx), mul_rn(bdy, bdy));
+    dgrad = sqrtf(fmaxf(sqmax, 1.f));
+    arg = pin;
   }
   LevelInfo li;
   float lv = log2f(dmax);
@@ -190,7 +203,7 @@ __device__ __forceinline__ LevelInfo mip_level(const float* __restrict__ grid_n,
   li.frac = fmaxf(lv - (float)lo, 0.f);
   li.arg = arg;
   // d level / d sq = 1/(ln2 * dmax) * 0.5/sqrt(sq)  when sq >= 1 (clamp passes gradient inclusively)
-  li.dcoef = (!blocked && sqmax >= 1.f) ? (1.4426950408889634f / dmax) * (0.5f / dmax) : 0.f;
+  li.dcoef = (!blocked && sqmax >= 1.f) ? (1.4426950408889634f / dgrad) * (0.5f / dgrad) : 0.f;
   li.ddx = bdx;
   li.ddy = bdy;
   return li;
@@ -351,6 +364,7 @@ __global__ __launch_bounds__(256) void mipmap_warp_fwd_kernel(
 __global__ __launch_bounds__(256) void mipmap_warp_indices_kernel(int* __restrict__ ix_nw, int* __restrict__ iy_nw,
                                                                   int* __restrict__ lvl_floor,
                                                                   int* __restrict__ lvl_ceil,
+                                                                  int* __restrict__ arg_out,
                                                                   const float* __restrict__ grid, int n, int h, int w,
                                                                   int ho, int wo, float max_level, float min_level,
                                                                   int padding_mode, int antialias) {
@@ -362,17 +376,19 @@ __global__ __launch_bounds__(256) void mipmap_warp_indices_kernel(int* __restric
     const int oy = (int)(q % ho);
     const int s = (int)(q / ho);
     const float* grid_n = grid + (size_t)s * ho * wo * 2;
-    int lo = 0, hi = 0;
+    int lo = 0, hi = 0, arg = -1;
     if (antialias) {
       const LevelInfo li = mip_level(grid_n, oy, ox, ho, wo, h, w, max_level, min_level);
       lo = li.lo;
       hi = li.hi;
+      arg = li.arg;
     }
     const Taps t = make_taps(grid_n + ((size_t)oy * wo + ox) * 2, h, w, padding_mode);
     if (ix_nw) ix_nw[o] = t.x0;
     if (iy_nw) iy_nw[o] = t.y0;
     if (lvl_floor) lvl_floor[o] = lo;
     if (lvl_ceil) lvl_ceil[o] = hi;
+    if (arg_out) arg_out[o] = arg;
   }
 }
 
@@ -402,7 +418,7 @@ __global__ __launch_bounds__(256) void mipmap_warp_bwd_kernel(
     float* __restrict__ ggrid, GPyrT<MAXL> gpyr, const float* __restrict__ gout, PyrT<MAXL> pyr,
     const float* __restrict__ grid, int n, int c, int h, int w, int hp, int wp, int pad_l, int ho, int wo,
     float max_level, float min_level, int padding_mode, int antialias, int want_image_grad,
-    int* __restrict__ nb_target, float2* __restrict__ nb_grad, int top) {
+    int* __restrict__ nb_target, float2* __restrict__ nb_grad, int top, const signed char* __restrict__ arg_pin) {
   const long long total = (long long)n * ho * wo;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
@@ -414,7 +430,7 @@ __global__ __launch_bounds__(256) void mipmap_warp_bwd_kernel(
     float* ggrid_n = ggrid + (size_t)s * ho * wo * 2;
     LevelInfo li;
     if (antialias) {
-      li = mip_level(grid_n, oy, ox, ho, wo, h, w, max_level, min_level);
+      li = mip_level(grid_n, oy, ox, ho, wo, h, w, max_level, min_level, arg_pin ? (int)arg_pin[o] : -1);
     } else {
       li.level = 0.f; li.lo = 0; li.hi = 0; li.frac = 0.f; li.arg = -1; li.dcoef = 0.f; li.ddx = li.ddy = 0.f;
     }
@@ -590,9 +606,9 @@ extern "C" int gg_mipmap_warp_fwd_f32(float* out, float* levels_out, const float
   return gg::launch_status("mipmap_warp_fwd");
 }
 
-extern "C" int gg_mipmap_warp_indices_f32(int* ix_nw, int* iy_nw, int* lvl_floor, int* lvl_ceil, const float* grid,
-                                          int n, int h, int w, int ho, int wo, float max_level, float min_level,
-                                          int padding_mode, int antialias, void* stream) {
+extern "C" int gg_mipmap_warp_indices_f32(int* ix_nw, int* iy_nw, int* lvl_floor, int* lvl_ceil, int* level_arg,
+                                          const float* grid, int n, int h, int w, int ho, int wo, float max_level,
+                                          float min_level, int padding_mode, int antialias, void* stream) {
   if (n < 0 || h <= 0 || w <= 0 || ho < 0 || wo < 0 || !grid) return gg::fail(-2, "mipmap_warp_indices: bad sizes");
   if (padding_mode < 0 || padding_mode > 2) return gg::fail(-2, "mipmap_warp_indices: padding_mode must be 0, 1 or 2");
   if (antialias && (!(max_level >= 0.f) || max_level > (float)(kMaxLevels - 1)))
@@ -600,14 +616,15 @@ extern "C" int gg_mipmap_warp_indices_f32(int* ix_nw, int* iy_nw, int* lvl_floor
   const long long total = (long long)n * ho * wo;
   if (total == 0) return 0;
   mipmap_warp_indices_kernel<<<gg::stream_grid(total, 256), 256, 0, gg::as_stream(stream)>>>(
-      ix_nw, iy_nw, lvl_floor, lvl_ceil, grid, n, h, w, ho, wo, max_level, min_level, padding_mode, antialias);
+      ix_nw, iy_nw, lvl_floor, lvl_ceil, level_arg, grid, n, h, w, ho, wo, max_level, min_level, padding_mode, antialias);
   return gg::launch_status("mipmap_warp_indices");
 }
 
 extern "C" int gg_mipmap_warp_bwd_f32(float* grad_grid, float* grad_pyr0, float* grad_pyr_rest, const float* grad_out,
                                       const float* pyr0, const float* pyr_rest, int num_levels, const float* grid,
                                       int n, int c, int h, int w, int hp, int wp, int pad_l, int ho, int wo,
-                                      float max_level, float min_level, int padding_mode, int antialias, void* stream) {
+                                      float max_level, float min_level, int padding_mode, int antialias,
+                                      const signed char* level_arg_pin, void* stream) {
   int rc = check_common(grid, n, c, h, w, hp, wp, pad_l, ho, wo, padding_mode, antialias);
   if (rc) return rc;
   const long long total = (long long)n * ho * wo;
@@ -639,13 +656,13 @@ extern "C" int gg_mipmap_warp_bwd_f32(float* grad_grid, float* grad_pyr0, float*
     auto gp = make_pyr<4, GPyrT<4>>(grad_pyr0, grad_pyr_rest, top + 1, planes, hp, wp);
     mipmap_warp_bwd_kernel<4><<<gg::stream_grid(total, 256), 256, 0, st>>>(
         grad_grid, gp, grad_out, pyr, grid, n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, padding_mode,
-        antialias, want_img, nb_target, nb_grad, top);
+        antialias, want_img, nb_target, nb_grad, top, level_arg_pin);
   } else {
     auto pyr = make_pyr<8, PyrT<8>>(pyr0, pyr_rest, top + 1, planes, hp, wp);
     auto gp = make_pyr<8, GPyrT<8>>(grad_pyr0, grad_pyr_rest, top + 1, planes, hp, wp);
     mipmap_warp_bwd_kernel<8><<<gg::stream_grid(total, 256), 256, 0, st>>>(
         grad_grid, gp, grad_out, pyr, grid, n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, padding_mode,
-        antialias, want_img, nb_target, nb_grad, top);
+        antialias, want_img, nb_target, nb_grad, top, level_arg_pin);
   }
   rc = gg::launch_status("mipmap_warp_bwd");
   if (rc || !antialias) return rc;

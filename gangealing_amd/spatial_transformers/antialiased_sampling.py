@@ -64,6 +64,13 @@ def _build_pyramid(base, levels=4):
     return rest, views
 
 
+# Diagnostics (tests/test_gpu_stn_decisions.py): a list of per-call pins for the mip level's arg-max - entry k (an int8
+# (N,ho,wo) tensor, or None) is consumed by the k-th anti-aliased warp issued while the list is installed, and its
+# backward routes the level's sub-gradient through the pinned neighbours (gg_mipmap_warp_bwd_f32: level_arg_pin).
+# None (always, outside that test) costs nothing.
+LEVEL_ARG_PINS = None
+
+
 class _MipmapWarpFn(Function):
     @staticmethod
     def forward(ctx, inputs, grid, max_level, min_level, padding_mode, antialias):
@@ -95,6 +102,12 @@ class _MipmapWarpFn(Function):
         levels = torch.empty((n, ho, wo), dtype=inputs.dtype, device=inputs.device)
         _lib.call('gg_mipmap_warp_fwd_f32', out, levels, base, rest, nlev, grid, n, c, h, w, hp, wp,
                   pad_l, ho, wo, max_level, min_level, _PAD_MODES[padding_mode], int(antialias))
+        ctx.arg_pin = None
+        if antialias and LEVEL_ARG_PINS:
+            ctx.arg_pin = LEVEL_ARG_PINS.pop(0)
+            if ctx.arg_pin is not None:
+                assert ctx.arg_pin.dtype == torch.int8 and tuple(ctx.arg_pin.shape) == (n, ho, wo), 'level_arg pin shape'
+                ctx.arg_pin = ctx.arg_pin.contiguous()
         ctx.save_for_backward(grid, base, *([rest] if rest is not None else []))
         ctx.conf = (n, c, h, w, hp, wp, pad_l, ho, wo, max_level, min_level, _PAD_MODES[padding_mode], int(antialias),
                     nlev)
@@ -114,7 +127,7 @@ class _MipmapWarpFn(Function):
             g0 = torch.zeros_like(base)
             grest = torch.zeros_like(rest) if rest is not None else None
         _lib.call('gg_mipmap_warp_bwd_f32', grad_grid, g0, grest, grad_out, base, rest, nlev, grid, n, c, h, w, hp, wp,
-                  pad_l, ho, wo, max_level, min_level, pm, antialias)
+                  pad_l, ho, wo, max_level, min_level, pm, antialias, ctx.arg_pin)
         grad_in = None
         if want_img:
             if grest is not None:   # fold the pyramid gradients back: g[l-1] += down2x^T(g[l])
@@ -151,9 +164,22 @@ def warp_indices(grid, height, width, max_num_levels=3.5, min_level=0.0, padding
     grid = grid.contiguous()
     n, ho, wo, _ = grid.shape
     outs = [torch.empty((n, ho, wo), dtype=torch.int32, device=grid.device) for _ in range(4)]
-    _lib.call('gg_mipmap_warp_indices_f32', outs[0], outs[1], outs[2], outs[3], grid, n, height, width, ho, wo,
+    _lib.call('gg_mipmap_warp_indices_f32', outs[0], outs[1], outs[2], outs[3], None, grid, n, height, width, ho, wo,
               float(max_num_levels - 1.0), float(min_level), _PAD_MODES[padding_mode], int(antialias))
     return tuple(outs)
+
+
+def warp_level_arg(grid, height, width, max_num_levels=3.5, min_level=0.0):
+    """Which neighbour (0 left, 1 right, 2 up, 3 down) holds the maximum coordinate distance at every output pixel - the
+    arg-max of MipmapWarp.get_max_coord_distance (antialiased_sampling.py:62-97; first maximum wins), as the sampling
+    kernels evaluate it.  int32 (N,ho,wo)."""
+    _check(grid, 'warp_level_arg')
+    grid = grid.contiguous()
+    n, ho, wo, _ = grid.shape
+    arg = torch.empty((n, ho, wo), dtype=torch.int32, device=grid.device)
+    _lib.call('gg_mipmap_warp_indices_f32', None, None, None, None, arg, grid, n, height, width, ho, wo,
+              float(max_num_levels - 1.0), float(min_level), 1, 1)
+    return arg
 
 
 class Warp(nn.Module):

@@ -221,10 +221,13 @@ int gg_mipmap_warp_fwd_f32(float* out, float* levels_out, const float* pyr0, con
  * grid_sampler_compute_source_index (ATen GridSampler.h:143-160: unnormalise, then clip / reflect for the padding
  * mode; 'zeros' leaves them unclipped, so the indices may lie outside the image), and floor / ceil of the clamped
  * mip level (antialiased_sampling.py:49,208-209,226-227).  Any output pointer may be NULL.  north_star's "bit-exact
- * warp grid indices" is tested on these (tests/test_gpu_indices.py). */
-int gg_mipmap_warp_indices_f32(int* ix_nw, int* iy_nw, int* lvl_floor, int* lvl_ceil, const float* grid,
-                               int n, int h, int w, int ho, int wo, float max_level, float min_level,
-                               int padding_mode, int antialias, void* stream);
+ * warp grid indices" is tested on these (tests/test_gpu_indices.py).
+ * level_arg (ABI 5): which neighbour (0 left, 1 right, 2 up, 3 down) holds the maximum coordinate distance the level
+ * was computed from (:62-97: torch.max over the four distances, first maximum wins) - the point the level's
+ * sub-gradient flows through; -1 without antialiasing. */
+int gg_mipmap_warp_indices_f32(int* ix_nw, int* iy_nw, int* lvl_floor, int* lvl_ceil, int* level_arg,
+                               const float* grid, int n, int h, int w, int ho, int wo, float max_level,
+                               float min_level, int padding_mode, int antialias, void* stream);
 /* Backward.  grad_grid (N,ho,wo,2) is overwritten; grad_pyr0 / grad_pyr_rest (the layout of pyr0 / pyr_rest)
  * ACCUMULATE (pass NULL for both to skip the image gradient).  Includes the gradient that reaches the grid through the
  * fractional mip level (levels % 1.0 is differentiable in the reference's autograd graph). */
@@ -232,7 +235,12 @@ int gg_mipmap_warp_bwd_f32(float* grad_grid, float* grad_pyr0, float* grad_pyr_r
                            const float* pyr0, const float* pyr_rest, int num_levels,
                            const float* grid, int n, int c, int h, int w, int hp, int wp, int pad_l,
                            int ho, int wo, float max_level, float min_level,
-                           int padding_mode, int antialias, void* stream);
+                           int padding_mode, int antialias, const signed char* level_arg_pin, void* stream);
+/* level_arg_pin (ABI 5; NULL in product use): per output pixel (N,ho,wo) the neighbour 0..3 whose distance the level's
+ * sub-gradient is routed through, or -1 for this evaluation's own arg-max.  Diagnostics: under a similarity warp the four
+ * neighbour distances are exactly tied in real arithmetic and the arg-max is decided by the last ulp of the grid in every
+ * implementation; with the reference's recorded decisions pinned the gradient is the reference's to rounding
+ * (tests/test_gpu_stn_decisions.py). */
 
 /* ------------------------------------------------------------------------------------------
  * a7  F.affine_grid(theta (N,2,3), (N,C,ho,wo), align_corners=False) (warping_heads.py:135,176)

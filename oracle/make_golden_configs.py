@@ -1,7 +1,7 @@
 """Golden vectors at BASELINE.json's own configurations, produced by the REFERENCE on CPU.
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py); authoring container only (needs /root/reference).
 
-    python oracle/make_golden_configs.py [c2_generator c2_stn c1 c2 c2t c2r c4 c5 c4b4 c5b4 c4b16 c5b8 c5b16 lpips lpips_masks act_masks]      # ~15 min on 8 cores for all
+    python oracle/make_golden_configs.py [c2_generator c2_stn c1 c2 c2t c2r c4 c5 c4b4 c5b4 c4b16 c5b8 c5b16 lpips lpips_masks act_masks stn_decisions]      # ~15 min on 8 cores for all
 
 Writes tests/golden/{c2_generator,c2_stn,cfg_c1,cfg_c2,cfg_c2t,cfg_c4,cfg_c5,lpips}.npz.  The reference runs unmodified: its
 modules are imported exactly as oracle/make_golden.py does, plus a local VGG16 `features` stack placed where
@@ -267,6 +267,64 @@ def gen_act_masks(api):
     save('act_masks', cases)
 
 
+def gen_stn_decisions(api):
+    """The decisions of the STN run of act_masks (case 1: similarity + flow STN at 64^2, batch 4, same weights, same
+    input, same loss - asserted) that act_masks does NOT hold, so that tests/test_gpu_stn_decisions.py can pin ALL of them:
+      * head_sign{k}   the (N, C) output sign of the similarity stage's final EqualLinear(activation='fused_lrelu')
+                       (spatial_transformer.py:458,596 -> networks.py:147-149: a function call, no module to hook);
+      * relu{k}        the output sign of the RAFT heads' plain ReLUs (warping_heads.py:160-169), in call order;
+      * level_arg{k}   for each anti-aliased warp (MipmapWarp.get_max_coord_distance, antialiased_sampling.py:62-97) the
+                       index torch.max(dists, dim=0) returned - the neighbour (0 l, 1 r, 2 u, 3 d) the level's
+                       sub-gradient flows through.  Under a similarity warp the four distances are exactly tied in real
+                       arithmetic: this index is last-ulp noise of the grid, in the reference too."""
+    from models.losses.loss import total_variation_loss, flow_identity_loss
+    import models.stylegan2.networks as ref_networks
+    n = 4
+    stn = api.get_stn(['similarity', 'flow'], flow_size=64, supersize=64, channel_multiplier=0.5, num_heads=1)
+    torch.nn.Module.load_state_dict(stn, det_state_dict(stn, cc.STN_RULES), strict=False)
+    x = cc.smooth_images('actmask.stn.x', n, 64)
+    head_signs, relu_signs, level_args = [], [], []
+    real_flr, real_max = ref_networks.fused_leaky_relu, torch.max
+
+    def flr(inp, bias, *a, **k):
+        out = real_flr(inp, bias, *a, **k)
+        if out.dim() == 2:
+            head_signs.append((out > 0).clone())
+        return out
+
+    def tmax(*a, **k):
+        res = real_max(*a, **k)
+        if len(a) == 1 and k.get('dim') == 0 and a[0].dim() == 4 and a[0].shape[0] == 4:
+            level_args.append(res[1].clone())
+        return res
+    hooks = [m.register_forward_hook(lambda mod, i, o: relu_signs.append((o > 0).clone()))
+             for m in stn.modules() if isinstance(m, nn.ReLU)]
+    ref_networks.fused_leaky_relu, torch.max = flr, tmax
+    try:
+        out, flow = stn(x, return_flow=True, padding_mode='reflection')
+    finally:
+        ref_networks.fused_leaky_relu, torch.max = real_flr, real_max
+        for h in hooks:
+            h.remove()
+    gout = rnd('actmask.stn.g', out.shape)
+    loss = (out * gout).mean() + 10.0 * total_variation_loss(flow) + flow_identity_loss(flow)
+    ref = np.load(os.path.join(REPO, 'tests', 'golden', 'act_masks.npz'))
+    assert np.array_equal(loss.detach().numpy(), ref['case01/loss']), 'not the run stored in act_masks.npz'
+    assert len(head_signs) == 1 and len(level_args) == 2 and len(relu_signs) == 2, \
+        (len(head_signs), len(level_args), len(relu_signs))
+    case = dict(meta=dict(batch=n, head_shapes=[list(t.shape) for t in head_signs],
+                          relu_shapes=[list(t.shape) for t in relu_signs],
+                          level_arg_shapes=[list(t.shape) for t in level_args],
+                          level_arg_histogram=[np.bincount(t.numpy().reshape(-1), minlength=4).tolist() for t in level_args]))
+    for k, t in enumerate(head_signs):
+        case[f'head_sign{k}'] = np.packbits(t.numpy().reshape(-1))
+    for k, t in enumerate(relu_signs):
+        case[f'relu{k}'] = np.packbits(t.numpy().reshape(-1))
+    for k, t in enumerate(level_args):
+        case[f'level_arg{k}'] = t.numpy().astype(np.uint8)
+    save('stn_decisions', [case])
+
+
 def pool_winner_codes(x):
     """Which input of every 2x2 / stride-2 window ATen's max_pool2d picks (row-major scan, a later element replaces the
     maximum only if strictly greater): 0..3 = (dy * 2 + dx)."""
@@ -325,7 +383,7 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     api = reference_api()
     only = sys.argv[1:]
-    jobs = dict(lpips=lambda: gen_lpips(api), lpips_masks=lambda: gen_lpips_masks(api), act_masks=lambda: gen_act_masks(api), c2_generator=lambda: gen_c2_generator(api), c2_stn=lambda: gen_c2_stn(api),
+    jobs = dict(lpips=lambda: gen_lpips(api), lpips_masks=lambda: gen_lpips_masks(api), act_masks=lambda: gen_act_masks(api), stn_decisions=lambda: gen_stn_decisions(api), c2_generator=lambda: gen_c2_generator(api), c2_stn=lambda: gen_c2_stn(api),
                 c1=lambda: gen_config(api, 'c1'), c5=lambda: gen_config(api, 'c5'), c4=lambda: gen_config(api, 'c4'),
                 c2=lambda: gen_config(api, 'c2'), c2t=lambda: gen_config(api, 'c2t'), c2r=lambda: gen_config(api, 'c2r'),
                 **{n: (lambda n=n: gen_config(api, n)) for n in ('c4b4', 'c5b4', 'c4b16', 'c5b8')},

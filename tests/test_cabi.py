@@ -38,7 +38,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_ctypes_prototypes_match_header():
     from gangealing_amd import _lib
-    tm = {'float*': 'p', 'const float*': 'p', 'double*': 'p', 'const double*': 'p', 'unsigned short*': 'p', 'unsigned char*': 'p', 'const unsigned char*': 'p',
+    tm = {'float*': 'p', 'const float*': 'p', 'double*': 'p', 'const double*': 'p', 'unsigned short*': 'p', 'unsigned char*': 'p', 'const unsigned char*': 'p', 'const signed char*': 'p',
           'const unsigned short*': 'p', 'const void*': 'p', 'unsigned int*': 'p', 'const unsigned int*': 'p', 'int*': 'p', 'const int*': 'p', 'int': 'i', 'long long': 'q',
           'float': 'f', 'double': 'd', 'void*': 's'}
     for name, args in header_decls():
