@@ -61,6 +61,10 @@ struct ConvArgs {
   // (activations: bit-identical to the unscaled kernel over their usual range), 2^5 for GRADIENT operands (format code
   // bit 5): a chunk is then staged unscaled only where that loses nothing against the normalised form
   float exp_lo;
+  // MEASUREMENT ONLY (gg_debug_set_prelimb, scripts/prelimb_probe.py): the operand x already in MFMA-ready form - style
+  // applied, two binary16 limbs, [image][16-channel chunk][pixel][limb][16 channels] (64 B per pixel and chunk, the LDS
+  // rows of conv_t_c16.hip) - what a producer epilogue would write.  Null in every product launch.
+  const unsigned short* xlimb;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -295,5 +299,6 @@ void s2_patch_launch(const ConvArgs& a, int stride, int tpix, dim3 grid, hipStre
 // a.tiles_co / tiles_pix / nslabs (16-channel chunks) / slabs_per_split / part set by the caller
 bool t16_serves(const ConvArgs& a);
 void t16_launch(const ConvArgs& a, int tco, int tw_log2, int tiles_y, int edge, int pad, dim3 grid, hipStream_t st);
+void t16_limb_convert(unsigned short* out, const float* x, const float* scale, int planes, int hw, hipStream_t st);
 
 }  // namespace gg_conv

@@ -2464,6 +2464,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ 
 
 // Which kernel instantiation the last convolution entry point of this thread launched (gg_last_conv_kernel): what
 // bench.py's per-kernel timing keys on, so that its roofline entries name the kernel that actually ran.
+thread_local const unsigned short* g_prelimb = nullptr;      // gg_debug_set_prelimb (measurement only)
 thread_local char g_last_kernel[96] = "";
 thread_local int g_sign_bits_written = 0;      // the last forward launch wrote the sign plane it was handed (BitArgs)
 #define NOTE_KERNEL(...) snprintf(g_last_kernel, sizeof(g_last_kernel), __VA_ARGS__)
@@ -3352,6 +3353,8 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   a.part = nullptr; a.part_stride = 0;
   a.f16 = f16 ? 1 : 0;
   a.exp_lo = grad_operand ? 32.f : 0.125f;
+  a.xlimb = g_prelimb;              // measurement only: null unless gg_debug_set_prelimb armed the next launch
+  g_prelimb = nullptr;
   a.acc_scale = f16 ? 1.f / kF16WeightScale : 1.f;
   a.mask_ref = mask.ref; a.mask_alpha = mask.alpha; a.mask_gain = mask.gain;
   a.mask_bits = mask.bits;
@@ -3735,6 +3738,22 @@ extern "C" int gg_plane_dot_f32(float* out, const float* a, const float* b, int 
   if (!out || !a || !b || hw < 0) return gg::fail(-2, "plane_dot: bad arguments");
   plane_dot_kernel<<<planes, 256, 0, gg::as_stream(stream)>>>(out, a, b, hw);
   return gg::launch_status("plane_dot");
+}
+
+// MEASUREMENT ONLY (scripts/prelimb_probe.py): gg_debug_limb_convert writes the style-scaled
+// two-binary16-limb, channel-fastest form of an activation; gg_debug_set_prelimb hands it to the NEXT convolution launch
+// of this thread, where the transposed 16-channel-chunk tile (64 co, binary16) stages it with wide loads instead of
+// converting fp32 in its loader.  Not declared in the public header: nothing in the product path calls them.
+extern "C" int gg_debug_limb_convert(unsigned short* out, const float* x, const float* in_scale, int planes,
+                                     long long hw, void* stream) {
+  if (!out || !x || planes <= 0 || planes % 16 != 0 || hw <= 0 || hw >= (1LL << 31))
+    return gg::fail(-2, "debug_limb_convert: bad arguments");
+  t16_limb_convert(out, x, in_scale, planes, (int)hw, gg::as_stream(stream));
+  return gg::launch_status("debug_limb_convert");
+}
+extern "C" int gg_debug_set_prelimb(const unsigned short* xlimb) {
+  g_prelimb = xlimb;
+  return 0;
 }
 
 // Diagnostic: resident workgroups per CU of the main convolution kernels on the current device, as

@@ -44,7 +44,10 @@ __device__ __forceinline__ constexpr int t16_tap(int i) {
 }
 __device__ __forceinline__ constexpr int t16_group(int i) { return i < 4 ? 0 : i < 6 ? 1 : i < 8 ? 2 : 3; }
 
-template <bool IN_SCALE, int TCO, bool F16>
+// PRELIMB (measurement only): the activation arrives as a.xlimb - already style-scaled and split into
+// two binary16 limbs, channel-fastest in the 32-byte rows this kernel keeps in LDS - so the loader is four 16-byte loads
+// and four ds_write_b128 per patch pixel and chunk: no style multiply, no amax, no v_cvt, no block exponent (E = 0).
+template <bool IN_SCALE, int TCO, bool F16, bool PRELIMB = false>
 __global__ __launch_bounds__(TCO * 4, 2) void convT3x3s2_c16_kernel(const ConvArgs a, int tw_log2_in, int tiles_y,
                                                                     int edge_tiles, int pad) {
   using L = Limb<F16>;
@@ -101,6 +104,21 @@ __global__ __launch_bounds__(TCO * 4, 2) void convT3x3s2_c16_kernel(const ConvAr
     const bool pok = pin & ((unsigned)iy < (unsigned)a.h) & ((unsigned)ix < (unsigned)a.w);
     pvoff = pok ? (unsigned)(cpart * CPT * hw + iy * a.w + ix) * 4u : kOobOffset;
   }
+  // PRELIMB: the same patch pixel, as a byte offset into the limb-form tensor (64 B per pixel and chunk)
+  const __amdgpu_buffer_rsrc_t lr = uniform_rsrc(reinterpret_cast<const float*>(PRELIMB ? a.xlimb : nullptr) +
+                                                 (PRELIMB ? (size_t)chan0 * hw : 0), a.cin_g * hw * 4);
+  unsigned plimb = kOobOffset, llimb = kOobOffset;
+  if (PRELIMB) {
+    const int pr = pp / PW, pc = pp - pr * PW;
+    const int iy = y0 + pr - 1, ix = x0 + pc - 1;
+    if (pin && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w) plimb = (unsigned)(iy * a.w + ix) * 64u;
+    const int l2 = 256 + (tid & 1);                      // pixels 256 / 257: threads 0..7 take one 16-byte piece each
+    const int qr = l2 / PW, qc = l2 - qr * PW;
+    const int jy = y0 + qr - 1, jx = x0 + qc - 1;
+    if (tid < 8 && l2 < PP && (unsigned)jy < (unsigned)a.h && (unsigned)jx < (unsigned)a.w)
+      llimb = (unsigned)(jy * a.w + jx) * 64u + (unsigned)((tid >> 1) & 3) * 16u;
+  }
+  U4 xq[4], xlq = U4{0u, 0u, 0u, 0u};
   const int lpp = 256 + (tid & 1), lci = (tid >> 1) & (T_CH - 1);      // patch pixels 256, 257 (128 x 1 and 2 x 128 tiles)
   const bool lin = tid < 2 * T_CH && lpp < PP;
   unsigned lvoff;
@@ -131,16 +149,22 @@ __global__ __launch_bounds__(TCO * 4, 2) void convT3x3s2_c16_kernel(const ConvAr
   // slice i (0..8) of the next chunk's loads: two of the lane's patch channels and the weight piece of order-tap i
   auto load_slice = [&](int chunk, int i) {
     const int cbase = __builtin_amdgcn_readfirstlane(chunk * T_CH * hw * 4);
+    if (PRELIMB) {
+      if (i < 4) xq[i] = buffer_load_u4(lr, plimb, cbase + i * 16);       // (chunk * hw * 64 B == cbase)
+      if (i == 4) xlq = buffer_load_u4(lr, llimb, cbase);
+    } else {
 #pragma unroll
-    for (int j = 0; j < CPT; ++j)
-      if (j >= 2 * i && j < 2 * i + 2) xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
-    if (i == 8) xl = buffer_load_f32(xr, lvoff, cbase);
+      for (int j = 0; j < CPT; ++j)
+        if (j >= 2 * i && j < 2 * i + 2) xa[j] = buffer_load_f32(xr, pvoff, cbase + j * hw * 4);
+      if (i == 8) xl = buffer_load_f32(xr, lvoff, cbase);
+    }
     const int soff = __builtin_amdgcn_readfirstlane((t16_tap(i) * a.cin_g + chunk * T_CH) * 2);
     wv[i] = buffer_load_u4(wr, wvoff, soff);
   };
   // the chunk's registers in their final fp32 form (style); binary16 limbs: + this wave's largest magnitude
   BlockExp bexp;
   auto prep_patch = [&](int chunk) {
+    if (PRELIMB) return;
     if (IN_SCALE) {
       if (pin) {
 #pragma unroll
@@ -156,6 +180,20 @@ __global__ __launch_bounds__(TCO * 4, 2) void convT3x3s2_c16_kernel(const ConvAr
     }
   };
   auto store_patch = [&]() {
+    if (PRELIMB) {
+      if (pin) {
+#pragma unroll
+        for (int l = 0; l < LIMBS; ++l)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            *reinterpret_cast<U4*>(sP + l * P_BYTES + pp * T_RB + (((q ^ (pp >> 3)) & 1) << 4)) = xq[l * 2 + q];
+      }
+      if (tid < 8 && (256 + (tid & 1)) < PP) {
+        const int l2 = 256 + (tid & 1), piece = (tid >> 1) & 3;
+        *reinterpret_cast<U4*>(sP + (piece >> 1) * P_BYTES + l2 * T_RB + ((((piece & 1) ^ (l2 >> 3)) & 1) << 4)) = xlq;
+      }
+      return;
+    }
     if (F16 && bexp.e != 0) {                  // a uniform branch: most tiles never leave E = 0
       const float ps = exp2i(-bexp.e);
 #pragma unroll
@@ -227,10 +265,10 @@ __global__ __launch_bounds__(TCO * 4, 2) void convT3x3s2_c16_kernel(const ConvAr
   if (chunk0 < chunk1) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) load_slice(chunk0, i);
-    if (F16) prep_patch(chunk0);             // published by the chunk loop's first barrier
+    if (F16 && !PRELIMB) prep_patch(chunk0);             // published by the chunk loop's first barrier
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
       __syncthreads();                       // the previous chunk's readers are done with sP / sW
-      if (F16) {          // block exponent of this chunk (rescales the accumulators if it grew)
+      if (F16 && !PRELIMB) {          // block exponent of this chunk (rescales the accumulators if it grew)
         const float f = block_exp_update(bexp, read_block_amax<NW>(sAmax), a.exp_lo);
         if (f != 1.f) {
 #pragma unroll
@@ -240,7 +278,7 @@ __global__ __launch_bounds__(TCO * 4, 2) void convT3x3s2_c16_kernel(const ConvAr
 #pragma unroll
               for (int r = 0; r < 16; ++r) acc[c][j][r] *= f;
         }
-      } else {
+      } else if (!PRELIMB) {
         prep_patch(chunk);
       }
       store_patch();
@@ -286,7 +324,7 @@ __global__ __launch_bounds__(TCO * 4, 2) void convT3x3s2_c16_kernel(const ConvAr
         if (i + 1 < 9 && t16_group(i + 1) != t16_group(i)) fetch_b(t16_group(i + 1));
       }
       // binary16 limbs: the next chunk's registers landed during the nine taps; published by the loop's top barrier
-      if (F16 && more) prep_patch(chunk + 1);
+      if (F16 && !PRELIMB && more) prep_patch(chunk + 1);
     }
   }
   const float esc = F16 ? exp2i(bexp.e) : 1.f;          // undo the block exponent (exact)
@@ -409,8 +447,41 @@ bool t16_serves(const ConvArgs& a) {
 
 #define T16_LAUNCH(SC, TCO, F) convT3x3s2_c16_kernel<SC, TCO, F><<<grid, TCO * 4, 0, st>>>(a, tw_log2, tiles_y, edge, pad)
 #define T16_LAUNCH_F(SC, TCO) do { if (a.f16) T16_LAUNCH(SC, TCO, true); else T16_LAUNCH(SC, TCO, false); } while (0)
+// fp32 NCHW x (x style) -> the limb form of ConvArgs::xlimb (measurement only: what a producer epilogue would write)
+__global__ __launch_bounds__(256) void limb_convert_kernel(unsigned short* __restrict__ out, const float* __restrict__ x,
+                                                           const float* __restrict__ scale, int planes16, int hw) {
+  const long long total = (long long)planes16 * hw;          // (image x chunk) x pixel
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int pc = (int)(i / hw), p = (int)(i - (long long)pc * hw);
+    const float* src = x + ((size_t)pc * 16) * hw + p;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = src[(size_t)j * hw] * (scale ? scale[(size_t)pc * 16 + j] : 1.f);
+    unsigned pk[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pk[0][e] = Limb<true>::pack2(v[2 * e], v[2 * e + 1], true);
+      pk[1][e] = Limb<true>::pack2(v[2 * e] - Limb<true>::lo(pk[0][e]), v[2 * e + 1] - Limb<true>::hi(pk[0][e]), false);
+    }
+    U4* dst = reinterpret_cast<U4*>(out + (size_t)i * 32);
+    dst[0] = U4{pk[0][0], pk[0][1], pk[0][2], pk[0][3]};
+    dst[1] = U4{pk[0][4], pk[0][5], pk[0][6], pk[0][7]};
+    dst[2] = U4{pk[1][0], pk[1][1], pk[1][2], pk[1][3]};
+    dst[3] = U4{pk[1][4], pk[1][5], pk[1][6], pk[1][7]};
+  }
+}
+
+void t16_limb_convert(unsigned short* out, const float* x, const float* scale, int planes, int hw, hipStream_t st) {
+  const long long total = (long long)(planes / 16) * hw;
+  limb_convert_kernel<<<gg::stream_grid(total, 256), 256, 0, st>>>(out, x, scale, planes / 16, hw);
+}
+
 void t16_launch(const ConvArgs& a, int tco, int tw_log2, int tiles_y, int edge, int pad, dim3 grid, hipStream_t st) {
   const bool sc = a.in_scale != nullptr;
+  if (a.xlimb && tco == 64 && a.f16) {          // measurement only
+    convT3x3s2_c16_kernel<false, 64, true, true><<<grid, 256, 0, st>>>(a, tw_log2, tiles_y, edge, pad);
+    return;
+  }
   if (tco == 64) {
     if (sc) T16_LAUNCH_F(true, 64);
     else T16_LAUNCH_F(false, 64);
