@@ -295,7 +295,7 @@ def _measure(device, wl, precision, graph, steps, warmup, world, gdist, profile)
         survey = [dict(kernel=k, launches_per_step=v['launches'] / 2, ms_per_step=round(v['ms'] / 2, 4),
                        rate=round(v['work'] / (v['ms'] * 1e-3) / 1e12, 3) if v['ms'] > 0 else 0.0,
                        unit='TFLOP/s' if v['unit'] == 'flop' else 'TB/s')
-                  for k, v in sorted(table.items(), key=lambda kv: -kv[1]['ms'])[:8]]
+                  for k, v in sorted(table.items(), key=lambda kv: -kv[1]['ms'])[:int(os.environ.get('GG_BENCH_SURVEY_ROWS', 8))]]
         if survey and not (workload_is_c2 and wl['batch'] >= 8):
             dominant = survey[0]['kernel']
         barrier()

@@ -56,6 +56,9 @@ _PROTOS = {
     'gg_modconv3x3_act_f32': 'ppppqipppppffiiiiis',
     'gg_modconv3x3_act_bits_f32': 'ppppqipppppffiiiiips',
     'gg_conv3x3_masked_dgrad_bits_f32': 'pppffpqippiiiiis',
+    'gg_modconv3x3_act_amax_f32': 'ppppqipppppffiiiiipps',
+    'gg_torgb_limb_f32': 'pppppppppiiqs',
+    'gg_convT3x3s2_prelimb_f32': 'ppppqppiiiiiiiis',
     'gg_conv2d_wgrad_f32': 'pppiiiiiiiiifs',
     'gg_conv2d_wgrad_split_f32': 'pppiiiiiiiiifis',
     'gg_conv2d_wgrad_acc_f32': 'pppiiiiiiiiifis',
@@ -88,7 +91,7 @@ class HipLibraryError(RuntimeError):
 
 def exported_symbols():
     return ['gg_abi_version', 'gg_last_error', 'gg_build_arch', 'gg_scratch_release', 'gg_set_allocator',
-            'gg_last_conv_kernel', 'gg_set_tuning', 'gg_last_sign_bits_written'] + sorted(_PROTOS)
+            'gg_last_conv_kernel', 'gg_set_tuning', 'gg_last_sign_bits_written', 'gg_last_amax_written'] + sorted(_PROTOS)
 
 
 def load():

@@ -65,6 +65,12 @@ struct ConvArgs {
   // applied, two binary16 limbs, [image][16-channel chunk][pixel][limb][16 channels] (64 B per pixel and chunk, the LDS
   // rows of conv_t_c16.hip) - what a producer epilogue would write.  Null in every product launch.
   const unsigned short* xlimb;
+  // round 6, production form of the same: xlimb_e[image] = the power-of-two exponent the limbs were scaled by (the consumer's
+  // block exponent, one per image: 2^-E applied by the producer pass, 2^E by this kernel's epilogue)
+  const int* xlimb_e;
+  // forward launches with the fused activation: amax_out[image] receives max |stored output| (atomic max on the bit
+  // pattern of a non-negative float: order-independent, so reproducible) - what the limb-writing pass takes its exponent from
+  float* amax_out;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -300,5 +306,9 @@ void s2_patch_launch(const ConvArgs& a, int stride, int tpix, dim3 grid, hipStre
 bool t16_serves(const ConvArgs& a);
 void t16_launch(const ConvArgs& a, int tco, int tw_log2, int tiles_y, int edge, int pad, dim3 grid, hipStream_t st);
 void t16_limb_convert(unsigned short* out, const float* x, const float* scale, int planes, int hw, hipStream_t st);
+// ToRGB (3 outputs) + limb form of the same activation for the next up-convolution; -1: shape not served
+int t16_torgb_limb(float* rgb, unsigned short* xlimb, int* xexp, const float* x, const float* wmat,
+                   const float* rgb_style, const float* bias, const float* next_style, const float* amax, int batch,
+                   int cin, long long hw, hipStream_t st);
 
 }  // namespace gg_conv

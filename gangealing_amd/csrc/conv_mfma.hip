@@ -989,6 +989,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
   // - one LDS round trip per accumulator register and per store in the interleaved form (24 per 32-channel sub-tile)
   const int pq = wpix * 64 + (lane & 15) * 4;                 // this lane's four pixels in every store of the loop below
   const float4 nz = *reinterpret_cast<const float4*>(ep_noise + pq);
+  float tmax = 0.f;                         // amax_out: largest stored magnitude seen by this lane
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     float4 sc4[4], bi4[4];
@@ -1032,6 +1033,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
           t = v4.z + anw * nz.z + ab; v4.z = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
           t = v4.w + anw * nz.w + ab; v4.w = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
         }
+        if (a.amax_out) tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(v4.x), fabsf(v4.y))), fmaxf(fabsf(v4.z), fabsf(v4.w)));
         if (a.sign_bits) {       // exactly the test the backward applies to the STORED value (fused_act.py:33-38)
           sgn[0] |= (v4.x > 0.f ? 1u : 0u) << row;
           sgn[1] |= (v4.y > 0.f ? 1u : 0u) << row;
@@ -1060,6 +1062,27 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv3x3_patch_kernel(const ConvAr
         a.sign_bits[((size_t)pn * hw + (size_t)oy * a.w + ox) * a.bit_words + cb] = word;
     }
     wave_lds_sync();                // the staging rows are this wave's own
+  }
+  if (a.amax_out) {
+    // ONE atomic per tile (a tile lies inside one image), and only when it can raise the value: per-wave atomics of all
+    // tiles of an image onto one address serialised in the L2 (+6 % on the 256^2 layer)
+    float m = tmax;
+    m = dpp_max<0x128, 0xf>(m);
+    m = dpp_max<0x124, 0xf>(m);
+    m = dpp_max<0x122, 0xf>(m);
+    m = dpp_max<0x121, 0xf>(m);
+    m = dpp_max<0x142, 0xa>(m);
+    m = dpp_max<0x143, 0xc>(m);
+    __syncthreads();                        // every wave is done with its staging rows: ep_scale may be reused
+    if (lane == 63) ep_scale[wid] = m;
+    __syncthreads();
+    if (tid == 0) {
+      float bm = ep_scale[0];
+      for (int q = 1; q < NT / 64; ++q) bm = fmaxf(bm, ep_scale[q]);
+      unsigned* dst = reinterpret_cast<unsigned*>(a.amax_out) + pn;
+      const unsigned bits = __builtin_bit_cast(unsigned, bm);
+      if (bm > 0.f && __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bits) atomicMax(dst, bits);
+    }
   }
 }
 
@@ -2465,8 +2488,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ 
 // Which kernel instantiation the last convolution entry point of this thread launched (gg_last_conv_kernel): what
 // bench.py's per-kernel timing keys on, so that its roofline entries name the kernel that actually ran.
 thread_local const unsigned short* g_prelimb = nullptr;      // gg_debug_set_prelimb (measurement only)
+thread_local int g_prelimb_served = 0;
 thread_local char g_last_kernel[96] = "";
 thread_local int g_sign_bits_written = 0;      // the last forward launch wrote the sign plane it was handed (BitArgs)
+thread_local int g_amax_written = 0;           // ... and the per-image output maxima (BitArgs::amax)
 #define NOTE_KERNEL(...) snprintf(g_last_kernel, sizeof(g_last_kernel), __VA_ARGS__)
 
 // Scratch for `splits` partial copies of the output of `a`; sets a.part / a.part_stride.  zero: clear it first
@@ -2685,6 +2710,8 @@ int launch_conv_patch(ConvArgs a, int limbs, int tw_log2, int tpix, hipStream_t 
   // the activation)
   if (a.splitk > 1 || !a.act) a.sign_bits = nullptr;
   g_sign_bits_written = a.sign_bits ? 1 : 0;
+  if (a.splitk > 1 || !a.act) a.amax_out = nullptr;
+  g_amax_written = a.amax_out ? 1 : 0;
   NOTE_KERNEL("conv3x3_patch<limbs%d,%dpx,%dco,%s,%s>", limbs, tpix, narrow ? 64 : 128,
               a.mask_bits ? "bitmasked" : a.mask_ref ? "masked" : "plain", a.f16 ? "f16" : "bf16");
   if (a.mask_bits) {             // masked data gradient, the mask from the 1-bit sign plane (binary16 limbs)
@@ -2856,7 +2883,8 @@ int launch_convT_patch(ConvArgs a, int limbs, int pad, hipStream_t st) {
         if (e != hipSuccess) return gg::fail((int)e, "conv2d: memset failed");
       }
       dim3 grid16((unsigned)(a.tiles_pix * a.tiles_co), (unsigned)a.splitk, (unsigned)a.groups);
-      NOTE_KERNEL("convT3x3s2_c16<limbs2,%dco,128q,%s>", tco, a.f16 ? "f16" : "bf16");
+      NOTE_KERNEL("convT3x3s2_c16<limbs2,%dco,128q,%s%s>", tco, a.f16 ? "f16" : "bf16", a.xlimb ? ",prelimb" : "");
+      if (a.xlimb) g_prelimb_served = 1;
       t16_launch(a, tco, tw16_log2, ty16, edge16, pad, grid16, st);
       const int rc = gg::launch_status("convT3x3s2_c16");
       if (rc || a.splitk <= 1) return rc;
@@ -3160,6 +3188,13 @@ constexpr int kNotFused = GG_NOT_SERVED;      // masked-input request that no ke
 
 template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {
+  if (a.xlimb && a.xlimb_e) {
+    // the operand exists in limb form only: exactly one kernel reads that (conv_t_c16.hip, 64 output channels per block)
+    if (!(KS == 3 && limbs == 2 && a.f16 && mode == 1 && stride == 2 && pad <= 1 && !a.act && !a.in_scale && a.groups == 1 &&
+          a.w >= 8 && (a.w & (a.w - 1)) == 0 && tuning(kTunConvT16) == 1 && t16_serves(a)))
+      return kNotFused;
+    return launch_convT_patch(a, limbs, pad, st);
+  }
   if (a.mask_ref || a.mask_bits) {
     int tw_log2;
     if (!((limbs == 1 || limbs == 2) && KS == 3 && mode == 0 && stride == 1 && pad == 1)) return kNotFused;
@@ -3274,6 +3309,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
 
 extern "C" const char* gg_last_conv_kernel(void) { return g_last_kernel; }
 extern "C" int gg_last_sign_bits_written(void) { return g_sign_bits_written; }
+extern "C" int gg_last_amax_written(void) { return g_amax_written; }
 
 extern "C" int gg_set_tuning(const char* name, int value) {
   if (!name) return gg::fail(-2, "set_tuning: null name");
@@ -3308,6 +3344,9 @@ struct MaskArgs {
 // served the launch produced it (only the 3x3 patch tile without split-K does): gg_last_sign_bits_written
 struct BitArgs {
   unsigned* sign = nullptr;
+  float* amax = nullptr;               // per-image max |output| (ConvArgs::amax_out)
+  const unsigned short* xlimb = nullptr;    // operand in limb form + its per-image exponents (ConvArgs::xlimb, xlimb_e)
+  const int* xlimb_e = nullptr;
 };
 
 struct ActArgs {
@@ -3324,6 +3363,7 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
                  void* stream, const ActArgs& act = ActArgs(), const MaskArgs& mask = MaskArgs(),
                  const BitArgs& bits = BitArgs()) {
   g_sign_bits_written = 0;
+  g_amax_written = 0;
   if (batch <= 0 || groups <= 0 || cin_g <= 0 || cout_g <= 0) return 0;
   if (!y || !x || (!wmat && !wsplit) || h <= 0 || w <= 0) return gg::fail(-2, "conv2d: bad arguments");
   if (ksize != 1 && ksize != 3) return gg::fail(-2, "conv2d: kernel size %d not supported (1 or 3)", ksize);
@@ -3353,8 +3393,10 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   a.part = nullptr; a.part_stride = 0;
   a.f16 = f16 ? 1 : 0;
   a.exp_lo = grad_operand ? 32.f : 0.125f;
-  a.xlimb = g_prelimb;              // measurement only: null unless gg_debug_set_prelimb armed the next launch
+  a.xlimb = bits.xlimb ? bits.xlimb : g_prelimb;      // (g_prelimb: measurement only, gg_debug_set_prelimb)
+  a.xlimb_e = bits.xlimb ? bits.xlimb_e : nullptr;
   g_prelimb = nullptr;
+  a.amax_out = (act.on && groups == 1) ? bits.amax : nullptr;
   a.acc_scale = f16 ? 1.f / kF16WeightScale : 1.f;
   a.mask_ref = mask.ref; a.mask_alpha = mask.alpha; a.mask_gain = mask.gain;
   a.mask_bits = mask.bits;
@@ -3380,7 +3422,7 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
                            : ((long long)batch * groups * cout_g * a.oh * a.ow * 4 > kNtStoreBytes ? 1 : 0);
   hipStream_t st = gg::as_stream(stream);
   const int rc = ksize == 3 ? conv_dispatch<3>(a, stride, pad, mode, st, limbs) : conv_dispatch<1>(a, stride, pad, mode, st, limbs);
-  if (rc != 0) g_sign_bits_written = 0;
+  if (rc != 0) g_sign_bits_written = g_amax_written = 0;
   return rc;
 }
 }  // namespace
@@ -3426,6 +3468,65 @@ extern "C" int gg_modconv3x3_act_bits_f32(float* y, const float* x, const float*
   bits.sign = sign_bits;
   return conv2d_entry(y, x, limbs ? nullptr : wmat, limbs ? wsplit : nullptr, limb_stride, limbs, in_scale, out_scale,
                       nullptr, batch, 1, cin, cout, h, w, 3, 1, 1, 0, 0, 0, stream, act, MaskArgs(), bits);
+}
+
+extern "C" int gg_modconv3x3_act_amax_f32(float* y, const float* x, const float* wmat, const unsigned short* wsplit,
+                                          long long limb_stride, int limbs, const float* in_scale,
+                                          const float* out_scale, const float* noise, const float* noise_weight,
+                                          const float* act_bias, float alpha, float gain, int batch, int cin,
+                                          int cout, int h, int w, unsigned int* sign_bits, float* amax_out,
+                                          void* stream) {
+  if (noise && !noise_weight) return gg::fail(-2, "modconv3x3_act: noise without its weight");
+  if ((h * w) % 4 != 0 || (reinterpret_cast<uintptr_t>(noise) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
+    return gg::fail(-2, "modconv3x3_act: H*W must be a multiple of 4 and y / noise 16-byte aligned");
+  if (limbs == 0 && !wmat) return gg::fail(-2, "modconv3x3_act: fp32 weights missing");
+  if (limbs != 0 && !wsplit) return gg::fail(-2, "modconv3x3_act: split weights missing");
+  ActArgs act;
+  act.on = 1; act.noise = noise; act.noise_w = noise_weight; act.bias = act_bias; act.alpha = alpha; act.gain = gain;
+  BitArgs bits;
+  bits.sign = sign_bits;
+  bits.amax = amax_out;
+  return conv2d_entry(y, x, limbs ? nullptr : wmat, limbs ? wsplit : nullptr, limb_stride, limbs, in_scale, out_scale,
+                      nullptr, batch, 1, cin, cout, h, w, 3, 1, 1, 0, 0, 0, stream, act, MaskArgs(), bits);
+}
+
+// Transposed 3x3 / stride 2 convolution of an operand that arrives in limb form (gg_torgb_limb_f32): GG_NOT_SERVED, and
+// nothing launched, unless the 16-channel-chunk tile with 64 output channels per block serves the shape.
+extern "C" int gg_convT3x3s2_prelimb_f32(float* y, const unsigned short* xlimb, const int* xlimb_exp,
+                                         const unsigned short* wsplit, long long limb_stride, const float* out_scale,
+                                         const float* bias, int batch, int cin, int cout, int h, int w, int pad,
+                                         int out_h, int out_w, void* stream) {
+  if (!xlimb || !xlimb_exp || !wsplit) return gg::fail(-2, "convT3x3s2_prelimb: null pointer");
+  if ((reinterpret_cast<uintptr_t>(xlimb) & 15)) return gg::fail(-2, "convT3x3s2_prelimb: xlimb must be 16-byte aligned");
+  if (cin % BKS != 0) return kNotFused;
+  BitArgs bits;
+  bits.xlimb = xlimb;
+  bits.xlimb_e = xlimb_exp;
+  g_prelimb_served = 0;
+  // x is never read on this path; the entry's null check wants a pointer
+  const int rc = conv2d_entry(y, reinterpret_cast<const float*>(xlimb), nullptr, wsplit, limb_stride, 18, nullptr,
+                              out_scale, bias, batch, 1, cin, cout, h, w, 3, 2, pad, 1, out_h, out_w, stream, ActArgs(),
+                              MaskArgs(), bits);
+  if (rc != 0) return rc;
+  return g_prelimb_served ? 0 : gg::fail(-5, "convT3x3s2_prelimb: the launch was not served by the limb-form tile");
+}
+
+// ToRGB (modulated 1x1 convolution to 3 channels, no demodulation, + bias: networks.py:352-372) of y AND y's limb form for
+// the next resolution's up-sampling convolution (style `next_style`, per-image exponent into xlimb_exp), one read of y.
+extern "C" int gg_torgb_limb_f32(float* rgb, unsigned short* xlimb, int* xlimb_exp, const float* y,
+                                 const float* rgb_wmat, const float* rgb_style, const float* rgb_bias,
+                                 const float* next_style, const float* amax, int batch, int cin, long long hw,
+                                 void* stream) {
+  if (batch <= 0) return 0;
+  if (!rgb || !xlimb || !xlimb_exp || !y || !rgb_wmat || !rgb_style || !next_style || !amax)
+    return gg::fail(-2, "torgb_limb: null pointer");
+  if ((reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(rgb) & 15) ||
+      (reinterpret_cast<uintptr_t>(xlimb) & 15))
+    return gg::fail(-2, "torgb_limb: y, rgb and xlimb must be 16-byte aligned");
+  if (t16_torgb_limb(rgb, xlimb, xlimb_exp, y, rgb_wmat, rgb_style, rgb_bias, next_style, amax, batch, cin, hw,
+                     gg::as_stream(stream)) != 0)
+    return kNotFused;
+  return gg::launch_status("torgb_limb");
 }
 
 extern "C" int gg_conv3x3_masked_dgrad_f32(float* y, const float* x, const float* mask_ref, float alpha, float gain,

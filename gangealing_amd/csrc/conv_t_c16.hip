@@ -163,6 +163,7 @@ __global__ __launch_bounds__(TCO * 4, 2) void convT3x3s2_c16_kernel(const ConvAr
   };
   // the chunk's registers in their final fp32 form (style); binary16 limbs: + this wave's largest magnitude
   BlockExp bexp;
+  if (PRELIMB && a.xlimb_e) bexp.e = a.xlimb_e[pn];          // the producer pass scaled the whole image by 2^-E
   auto prep_patch = [&](int chunk) {
     if (PRELIMB) return;
     if (IN_SCALE) {
@@ -469,6 +470,125 @@ __global__ __launch_bounds__(256) void limb_convert_kernel(unsigned short* __res
     dst[2] = U4{pk[1][0], pk[1][1], pk[1][2], pk[1][3]};
     dst[3] = U4{pk[1][4], pk[1][5], pk[1][6], pk[1][7]};
   }
+}
+
+// ---- round 6: ToRGB + limb form in ONE pass over the activation ----------------------------------------------------------
+// The output y of a resolution's second StyledConv has two readers: the ToRGB layer (modulated 1x1, 3 outputs: a streaming
+// reduction over the channels, conv1x1_fewout_kernel) and the next resolution's up-sampling convolution (the transposed
+// tile above).  This kernel is the former with the latter's operand as a by-product: while a wave holds 16 channels x 4
+// pixels of y for the RGB dot products, it also multiplies them by the UP-CONVOLUTION's style, splits them into two
+// binary16 limbs and stores them channel-fastest, 64 bytes per pixel and chunk - the LDS rows of the PRELIMB loader.  y is
+// read once (as before); the limb form costs its write.
+// Exponent: one per image, E[n] = f16_block_exp(amax_y[n] * max_c |style[n][c]|) (>= the true largest operand: the band
+// rule of conv_common.h on an upper bound); amax_y[n] comes from the producing convolution's epilogue (ConvArgs::amax_out).
+// Block = 256 pixels of one image (lane: 4 consecutive pixels); the four waves split the channels into four contiguous
+// ranges and meet in LDS - the summation order of conv1x1_fewout_kernel, so the RGB output is bitwise that kernel's.
+constexpr int TL_MAX_CIN = 1024;
+template <int NCO>
+__global__ __launch_bounds__(256) void torgb_limb_kernel(float* __restrict__ rgb, unsigned short* __restrict__ xlimb,
+                                                         int* __restrict__ xexp, const float* __restrict__ x,
+                                                         const float* __restrict__ wmat,
+                                                         const float* __restrict__ rgb_style,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ next_style,
+                                                         const float* __restrict__ amax, int cin, long long hw) {
+  __shared__ float sw[NCO][TL_MAX_CIN];
+  __shared__ float ss[TL_MAX_CIN];
+  __shared__ float4 red[4][NCO][64];
+  __shared__ float smax[4];
+  const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  float m = 0.f;
+  for (int i = tid; i < cin; i += 256) {
+    const float sv = next_style[(size_t)n * cin + i];
+    ss[i] = sv;
+    m = fmaxf(m, fabsf(sv));
+  }
+  for (int i = tid; i < cin * NCO; i += 256) {
+    const int ci = i / NCO, j = i - ci * NCO;
+    sw[j][ci] = wmat[i] * rgb_style[(size_t)n * cin + ci];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if (lane == 0) smax[g] = m;
+  __syncthreads();
+  const float bound = amax[n] * fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+  const int e = bound > 0.f ? f16_block_exp(bound, 0.125f) : 0;
+  if (blockIdx.x == 0 && tid == 0) xexp[n] = e;
+  const float ps = exp2i(-e);
+  const long long p = (long long)blockIdx.x * 256 + lane * 4;
+  const bool ok = p < hw;                                   // hw % 4 == 0: a lane's four pixels are in or out together
+  float4 acc[NCO];
+#pragma unroll
+  for (int j = 0; j < NCO; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nchunks = cin / T_CH;
+  if (ok) {
+    const int cpw = (nchunks + 3) / 4, c0 = g * cpw, c1 = (c0 + cpw < nchunks) ? c0 + cpw : nchunks;
+    for (int chunk = c0; chunk < c1; ++chunk) {
+      const float* src = x + ((size_t)n * cin + (size_t)chunk * T_CH) * hw + p;
+      float4 v[T_CH];
+#pragma unroll
+      for (int k = 0; k < T_CH; ++k) v[k] = *reinterpret_cast<const float4*>(src + (size_t)k * hw);
+#pragma unroll
+      for (int k = 0; k < T_CH; ++k) {
+#pragma unroll
+        for (int j = 0; j < NCO; ++j) {
+          const float wj = sw[j][chunk * T_CH + k];
+          acc[j].x += v[k].x * wj; acc[j].y += v[k].y * wj; acc[j].z += v[k].z * wj; acc[j].w += v[k].w * wj;
+        }
+      }
+      // the limb form: exactly the arithmetic of the fp32 loader (style multiply, power-of-two scale when E != 0, leading
+      // limb rounded toward zero, residual to nearest)
+#pragma unroll
+      for (int k = 0; k < T_CH; ++k) {
+        const float sv = ss[chunk * T_CH + k];
+        v[k].x *= sv; v[k].y *= sv; v[k].z *= sv; v[k].w *= sv;
+      }
+      if (e != 0) {
+#pragma unroll
+        for (int k = 0; k < T_CH; ++k) { v[k].x *= ps; v[k].y *= ps; v[k].z *= ps; v[k].w *= ps; }
+      }
+      U4* dst = reinterpret_cast<U4*>(xlimb + (((size_t)n * nchunks + chunk) * hw + p) * 32);
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        unsigned l0[8], l1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float a0 = px == 0 ? v[2 * q].x : px == 1 ? v[2 * q].y : px == 2 ? v[2 * q].z : v[2 * q].w;
+          const float a1 = px == 0 ? v[2 * q + 1].x : px == 1 ? v[2 * q + 1].y : px == 2 ? v[2 * q + 1].z : v[2 * q + 1].w;
+          l0[q] = Limb<true>::pack2(a0, a1, true);
+          l1[q] = Limb<true>::pack2(a0 - Limb<true>::lo(l0[q]), a1 - Limb<true>::hi(l0[q]), false);
+        }
+        dst[px * 4 + 0] = U4{l0[0], l0[1], l0[2], l0[3]};
+        dst[px * 4 + 1] = U4{l0[4], l0[5], l0[6], l0[7]};
+        dst[px * 4 + 2] = U4{l1[0], l1[1], l1[2], l1[3]};
+        dst[px * 4 + 3] = U4{l1[4], l1[5], l1[6], l1[7]};
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NCO; ++j) red[g][j][lane] = acc[j];
+  __syncthreads();
+  if (g < NCO && ok) {                                      // wave j finishes output channel j
+    const int j = g;
+    float4 r = red[0][j][lane];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      const float4 t = red[q][j][lane];
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    const float bi = bias ? bias[j] : 0.f;
+    r.x += bi; r.y += bi; r.z += bi; r.w += bi;
+    *reinterpret_cast<float4*>(rgb + ((size_t)n * NCO + j) * hw + p) = r;
+  }
+}
+
+int t16_torgb_limb(float* rgb, unsigned short* xlimb, int* xexp, const float* x, const float* wmat,
+                   const float* rgb_style, const float* bias, const float* next_style, const float* amax, int batch,
+                   int cin, long long hw, hipStream_t st) {
+  if (cin % T_CH != 0 || cin > TL_MAX_CIN || hw % 4 != 0 || batch > 65535) return -1;
+  dim3 grid((unsigned)((hw + 255) / 256), (unsigned)batch);
+  torgb_limb_kernel<3><<<grid, 256, 0, st>>>(rgb, xlimb, xexp, x, wmat, rgb_style, bias, next_style, amax, cin, hw);
+  return 0;
 }
 
 void t16_limb_convert(unsigned short* out, const float* x, const float* scale, int planes, int hw, hipStream_t st) {

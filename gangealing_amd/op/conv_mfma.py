@@ -64,6 +64,10 @@ class LaunchProfiler:
         return out
 
 
+def last_amax_written():
+    return bool(_lib.load().gg_last_amax_written())
+
+
 def last_conv_kernel():
     lib = _lib.load()
     return lib.gg_last_conv_kernel().decode() if hasattr(lib, 'gg_last_conv_kernel') else 'unknown'
@@ -80,10 +84,10 @@ def _prof_begin(sig):
     return p, p.begin()
 
 
-def _prof_end(p, start, sig, work, name):
+def _prof_end(p, start, sig, work, name, unit='flop'):
     if p is not None:
         p.names[sig] = name
-        p.end(start, work, name)
+        p.end(start, work, name, unit)
 
 # Arithmetic of the implicit-GEMM convolutions:
 #   'fp32'   v_mfma_f32_32x32x2_f32 - exact fp32 products (the parity mode, default)
@@ -340,13 +344,17 @@ def pack_weight(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0)
 
 
 def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in_scale=None, out_scale=None,
-                 bias=None, out_hw=None, act=None, grad=False, want_sign_bits=None):
+                 bias=None, out_hw=None, act=None, grad=False, want_sign_bits=None, amax_out=None, prelimb=None):
     """act = (noise (N,1,OH,OW), noise_weight (1,), act_bias (Cout,), alpha, gain): the StyledConv tail
     lrelu(y + noise_weight*noise + act_bias)*gain fused behind a 3x3/stride-1/pad-1 convolution
     (gg_modconv3x3_act_f32).  grad: this launch is a gradient convolution (data gradient): bf16 limbs in every
     split-precision mode.  want_sign_bits (with act; True / False, not None): the call returns (y, bits) - bits = the
     1-bit sign plane of y (int32 (N, OH*OW, Cout/32), gg_modconv3x3_act_bits_f32) for the layer's masked data gradient when
-    asked for with True, None when not asked for or when the kernel that served the launch does not write it."""
+    asked for with True, None when not asked for or when the kernel that served the launch does not write it.
+    amax_out (with act; zeroed float32 (N,)): receives max |y[n]| when the launch's own epilogue wrote y
+    (gg_modconv3x3_act_amax_f32; ask last_amax_written()).  prelimb = (xlimb, xexp) (transposed 3x3 / stride 2 only): the
+    operand in limb form with the style already applied (torgb_limb) - x / in_scale are then the fallback if the limb-form
+    tile does not serve the shape."""
     sign_bits = None
     h, w = x.shape[-2], x.shape[-1]
     if mode == 0:
@@ -391,6 +399,12 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             if (want_sign_bits and use_split and pack_code == 18 and cout_g % 32 == 0 and 'sign_bits' not in DISABLED
                     and ACT_OBSERVER is None):
                 sign_bits = torch.empty((batch, oh * ow, cout_g // 32), dtype=torch.int32, device=x.device)
+            if amax_out is not None and use_split and pack_code == 18:
+                _lib.call('gg_modconv3x3_act_amax_f32', y, x, wm, wbuf, stride_l, code, in_scale, out_scale,
+                          noise, noise_weight, act_bias, alpha, gain, batch, cin_g, cout_g, h, w, sign_bits, amax_out)
+                if sign_bits is not None and not _lib.load().gg_last_sign_bits_written():
+                    sign_bits = None
+            elif sign_bits is not None:
                 _lib.call('gg_modconv3x3_act_bits_f32', y, x, wm, wbuf, stride_l, code, in_scale, out_scale,
                           noise, noise_weight, act_bias, alpha, gain, batch, cin_g, cout_g, h, w, sign_bits)
                 if not _lib.load().gg_last_sign_bits_written():
@@ -400,8 +414,15 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
                           noise, noise_weight, act_bias, alpha, gain, batch, cin_g, cout_g, h, w)
         elif use_split:
             wbuf, stride_l = wmat.split(code)
-            _lib.call('gg_conv2d_split_f32', y, x, wbuf, stride_l, code, in_scale, out_scale, bias, batch, groups,
-                      cin_g, cout_g, h, w, k, stride, pad, mode, oh if mode == 1 else 0, ow if mode == 1 else 0)
+            served = False
+            if prelimb is not None and mode == 1 and k == 3 and stride == 2 and pack_code == 18 and groups == 1:
+                # the operand already exists style-scaled, split into limbs, channel-fastest (torgb_limb)
+                rc = _lib.call('gg_convT3x3s2_prelimb_f32', y, prelimb[0], prelimb[1], wbuf, stride_l, out_scale, bias,
+                               batch, cin_g, cout_g, h, w, pad, oh, ow, allow=(_lib.NOT_SERVED,))
+                served = rc == 0
+            if not served:
+                _lib.call('gg_conv2d_split_f32', y, x, wbuf, stride_l, code, in_scale, out_scale, bias, batch, groups,
+                          cin_g, cout_g, h, w, k, stride, pad, mode, oh if mode == 1 else 0, ow if mode == 1 else 0)
         else:
             wm = wmat.fp32() if isinstance(wmat, PackedWeight) else wmat
             _lib.call('gg_conv2d_f32', y, x, wm, in_scale, out_scale, bias, batch, groups, cin_g, cout_g, h, w,
@@ -715,6 +736,34 @@ def plane_dot(a, b):
     return out
 
 
+def prelimb_wanted(cin, res):
+    """Write the next up-sampling convolution's operand in limb form (round 6, csrc/conv_t_c16.hip: PRELIMB)?  The
+    binary16 forward arithmetic, a shape the 16-channel-chunk transposed tile serves and the fused ToRGB pass measured
+    (profiles/r06_c_prelimb_probe.txt: input resolutions 32 - 128; 256 for the 512^2 generators), no diagnostics hook that
+    might edit the activation afterwards."""
+    return (PRECISION in _F16_FORWARD and 'prelimb' not in DISABLED and ACT_OBSERVER is None and cin % 32 == 0
+            and cin <= 1024 and res >= 32 and (res & (res - 1)) == 0)
+
+
+def torgb_limb(y, rgb_wmat, rgb_style, rgb_bias, next_style, amax):
+    """-> (rgb (N,3,H,W), xlimb, xexp) or None: ToRGB of y (modulated 1x1, no demodulation, bias in the epilogue) and y's
+    limb form for the next layer's transposed convolution with style `next_style`, in one pass (gg_torgb_limb_f32)."""
+    n, cin, h, w = y.shape
+    if rgb_bias is None or not isinstance(rgb_wmat, PackedWeight):
+        return None
+    rgb = torch.empty((n, 3, h, w), dtype=torch.float32, device=y.device)
+    xlimb = torch.empty(n * cin * h * w * 2, dtype=torch.int16, device=y.device)
+    xexp = torch.empty(n, dtype=torch.int32, device=y.device)
+    sig = ('torgb_limb', n, cin, h, w)
+    prof, start = _prof_begin(sig)
+    rc = _lib.call('gg_torgb_limb_f32', rgb, xlimb, xexp, y, rgb_wmat.fp32(), rgb_style.contiguous(), rgb_bias.contiguous(),
+                   next_style.contiguous(), amax, n, cin, h * w, allow=(_lib.NOT_SERVED,))
+    if rc != 0:
+        return None
+    _prof_end(prof, start, sig, 4.0 * (2 * y.numel() + rgb.numel()), 'torgb_limb', 'byte')
+    return rgb, xlimb, xexp
+
+
 class _ModulatedConv(Function):
     """y[n,co] = demod[n,co] * conv(W*scale, style[n,ci] * x[n,ci])  - one dense conv with shared weights.
 
@@ -727,8 +776,10 @@ class _ModulatedConv(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate, demod_pre=None, bias=None):
-        """bias: (Cout,) frozen per-channel bias added in the convolution's epilogue (ToRGB's bias, networks.py:366)."""
+    def forward(ctx, x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate, demod_pre=None, bias=None,
+                prelimb=None):
+        """bias: (Cout,) frozen per-channel bias added in the convolution's epilogue (ToRGB's bias, networks.py:366).
+        prelimb: (xlimb, xexp) of x * style (torgb_limb) for an up-sampling layer."""
         x = x.contiguous()
         style = style.contiguous()
         n, cin, h, w = x.shape
@@ -737,7 +788,8 @@ class _ModulatedConv(Function):
         if demodulate:
             demod = demod_pre if demod_pre is not None else torch.rsqrt((style * style) @ wsq.t() + 1e-8)
         if upsample:
-            y = conv_forward(x, wmat_fwd, n, 1, cin, cout, k, 2, 0, 1, in_scale=style, out_scale=demod, bias=bias)
+            y = conv_forward(x, wmat_fwd, n, 1, cin, cout, k, 2, 0, 1, in_scale=style, out_scale=demod, bias=bias,
+                             prelimb=prelimb)
         else:
             y = conv_forward(x, wmat_fwd, n, 1, cin, cout, k, 1, k // 2, 0, in_scale=style, out_scale=demod, bias=bias)
         ctx.save_for_backward(x, style, demod if demod is not None else style.new_empty(0), y, wsq)
@@ -784,7 +836,7 @@ class _ModulatedConv(Function):
                 dx = dxt * style.view(n, cin, 1, 1) if ctx.needs_input_grad[0] else None
             else:
                 dx = dxt
-        return dx, dstyle, None, None, None, None, None, None, None, None
+        return dx, dstyle, None, None, None, None, None, None, None, None, None
 
 
 def masked_dgrad(dy, y_act, alpha, gain, wmat_bwd, n, cin, cout, h, w, in_scale=None, out_scale=None, sign_bits=None):
@@ -867,31 +919,27 @@ class _StyledConvToRGB(Function):
 
     @staticmethod
     def forward(ctx, x, style, wmat_fwd, wmat_bwd, wsq, demodulate, noise, noise_weight, act_bias, alpha, gain,
-                demod_pre, rgb_style, rgb_wmat, rgb_weight, rgb_scale, rgb_bias=None):
-        x = x.contiguous()
-        style = style.contiguous()
-        n, cin, h, w = x.shape
-        cout = wmat_fwd.cout_g
-        demod = None
-        if demodulate:
-            demod = demod_pre if demod_pre is not None else torch.rsqrt((style * style) @ wsq.t() + 1e-8)
-        y, ctx.sign_bits = conv_forward(x, wmat_fwd, n, 1, cin, cout, 3, 1, 1, 0, in_scale=style, out_scale=demod,
-                                        act=(noise.contiguous(), noise_weight.contiguous(), act_bias.contiguous(), alpha,
-                                             gain), want_sign_bits=bool(ctx.needs_input_grad[0]))
-        observe_activation('styled_conv', y)
-        rgb_style = rgb_style.contiguous()
-        rgb = conv_forward(y, rgb_wmat, n, 1, cout, 3, 1, 1, 0, 0, in_scale=rgb_style, bias=rgb_bias)
-        ctx.save_for_backward(style, demod if demod is not None else style.new_empty(0), y, rgb_style, rgb_weight)
+                demod_pre, rgb_style, rgb_wmat, rgb_weight, rgb_scale, rgb_bias=None, next_style=None):
+        y, rgb, ctx.sign_bits, demod, rgb_style, limb = styled_conv_torgb_launches(
+            x, style, wmat_fwd, wsq, demodulate, noise, noise_weight, act_bias, alpha, gain, demod_pre, rgb_style, rgb_wmat,
+            rgb_bias, next_style, bool(ctx.needs_input_grad[0]))
+        ctx.save_for_backward(style.contiguous(), demod if demod is not None else style.new_empty(0), y, rgb_style,
+                              rgb_weight)
         ctx.wmat_bwd = wmat_bwd
-        ctx.conf = (demodulate, alpha, gain, cin, rgb_scale)
-        return y, rgb
+        ctx.conf = (demodulate, alpha, gain, x.shape[1], rgb_scale)
+        if limb is None:
+            limb = (y.new_empty(0, dtype=torch.int16), y.new_empty(0, dtype=torch.int32))
+        ctx.mark_non_differentiable(*limb)
+        # (otherwise autograd hands backward() ZERO tensors for the limb-form outputs: a 270 MB fill per layer)
+        ctx.set_materialize_grads(False)
+        return (y, rgb) + limb
 
     @staticmethod
-    def backward(ctx, gy, grgb):
+    def backward(ctx, gy, grgb, _gl=None, _ge=None):
         style, demod, y, rgb_style, rgb_weight = ctx.saved_tensors
         demodulate, alpha, gain, cin, rgb_scale = ctx.conf
         if not ctx.needs_input_grad[0]:
-            return (None,) * 17
+            return (None,) * 18
         n, cout, h, w = y.shape
         if gy is None:
             g = torch.zeros_like(y)
@@ -906,14 +954,53 @@ class _StyledConvToRGB(Function):
             _lib.call('gg_fused_lrelu_bwd_f32', gm, None, g, y, alpha, gain, n, cout, h * w)
             dx = conv_forward(gm, ctx.wmat_bwd, n, 1, cout, cin, 3, 1, 1, 0, in_scale=demod if demodulate else None,
                               out_scale=style, grad=True)
-        return (dx,) + (None,) * 16
+        return (dx,) + (None,) * 17
+
+
+def styled_conv_torgb_launches(x, style, wmat_fwd, wsq, demodulate, noise, noise_weight, act_bias, alpha, gain,
+                               demod_pre, rgb_style, rgb_wmat, rgb_bias, next_style, want_sign_bits):
+    """The launches of one resolution's second StyledConv + its ToRGB layer (no autograd here: _StyledConvToRGB wraps
+    them when a gradient is wanted, the no-grad generator pass calls them directly).
+    -> (y, rgb, sign plane or None, demodulation, rgb style, (xlimb, xexp) or None).
+    next_style: the style vectors of the NEXT resolution's up-sampling convolution - when given (prelimb_wanted) the
+    convolution's epilogue also leaves max |y| per image and the ToRGB pass writes y's limb form for that layer."""
+    x = x.contiguous()
+    style = style.contiguous()
+    n, cin, h, w = x.shape
+    cout = wmat_fwd.cout_g
+    demod = None
+    if demodulate:
+        demod = demod_pre if demod_pre is not None else torch.rsqrt((style * style) @ wsq.t() + 1e-8)
+    amax = torch.zeros(n, dtype=torch.float32, device=x.device) if next_style is not None else None
+    y, sign_bits = conv_forward(x, wmat_fwd, n, 1, cin, cout, 3, 1, 1, 0, in_scale=style, out_scale=demod,
+                                act=(noise.contiguous(), noise_weight.contiguous(), act_bias.contiguous(), alpha, gain),
+                                want_sign_bits=want_sign_bits, amax_out=amax)
+    have_amax = amax is not None and last_amax_written()
+    observe_activation('styled_conv', y)
+    rgb_style = rgb_style.contiguous()
+    limb = None
+    if have_amax:
+        res = torgb_limb(y, rgb_wmat, rgb_style, rgb_bias, next_style, amax)
+        if res is not None:
+            rgb, limb = res[0], (res[1], res[2])
+    if limb is None:
+        rgb = conv_forward(y, rgb_wmat, n, 1, cout, 3, 1, 1, 0, 0, in_scale=rgb_style, bias=rgb_bias)
+    return y, rgb, sign_bits, demod, rgb_style, limb
 
 
 def styled_conv_torgb(x, style, wmat_fwd, wmat_bwd, wsq, demodulate, act, demod, rgb_style, rgb_wmat, rgb_weight,
-                      rgb_scale, rgb_bias=None):
+                      rgb_scale, rgb_bias=None, next_style=None):
+    """-> (y, rgb, (xlimb, xexp) or None)"""
     noise, noise_weight, act_bias, alpha, gain = act
-    return _StyledConvToRGB.apply(x, style, wmat_fwd, wmat_bwd, wsq, demodulate, noise, noise_weight, act_bias, alpha,
-                                  gain, demod, rgb_style, rgb_wmat, rgb_weight, float(rgb_scale), rgb_bias)
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        y, rgb, _, _, _, limb = styled_conv_torgb_launches(x, style, wmat_fwd, wsq, demodulate, noise, noise_weight,
+                                                           act_bias, alpha, gain, demod, rgb_style, rgb_wmat, rgb_bias,
+                                                           next_style, False)
+        return y, rgb, limb
+    y, rgb, xlimb, xexp = _StyledConvToRGB.apply(x, style, wmat_fwd, wmat_bwd, wsq, demodulate, noise, noise_weight,
+                                                 act_bias, alpha, gain, demod, rgb_style, rgb_wmat, rgb_weight,
+                                                 float(rgb_scale), rgb_bias, next_style)
+    return y, rgb, ((xlimb, xexp) if xlimb.numel() else None)
 
 
 def style_demod(latent, weight, bias, w_scale, b_scale, wsq=None, eps=1e-8):
@@ -963,7 +1050,7 @@ def style_demod_grad(latent, weight, bias, w_scaled, w_scale, b_scale, wsq=None,
 
 
 def modulated_conv2d(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample=False, demodulate=True, act=None, demod=None,
-                     bias=None):
+                     bias=None, prelimb=None):
     """act = (noise, noise_weight, act_bias, alpha, gain) fuses the StyledConv tail (3x3, no upsampling, and no
     gradient wanted for style / noise weight / bias).  demod: precomputed demodulation (style_demod)."""
     if act is not None:
@@ -974,7 +1061,7 @@ def modulated_conv2d(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample=False, demod
                                        alpha, gain, demod)
     if bias is not None and bias.requires_grad and torch.is_grad_enabled():
         raise NotImplementedError('modulated_conv2d: the epilogue bias is for frozen layers')
-    return _ModulatedConv.apply(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate, demod, bias)
+    return _ModulatedConv.apply(x, style, wmat_fwd, wmat_bwd, wsq, k, upsample, demodulate, demod, bias, prelimb)
 
 
 class _AddScale(Function):

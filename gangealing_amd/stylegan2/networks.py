@@ -256,10 +256,11 @@ class ModulatedConv2d(nn.Module):
                                     padding=self.padding, groups=n)
         return out.view(n, cout, out.shape[-2], out.shape[-1])
 
-    def forward(self, input, style, act=None, pre=None, bias=None):
+    def forward(self, input, style, act=None, pre=None, bias=None, prelimb=None):
         """act = (noise, noise_weight, bias, negative_slope, scale): fuse StyledConv's NoiseInjection +
         FusedLeakyReLU into the convolution (callers check `can_fuse_act` first).  pre = (style vector, demodulation)
-        already computed for this layer (Generator's style bank); bias: frozen per-channel bias for the epilogue."""
+        already computed for this layer (Generator's style bank); bias: frozen per-channel bias for the epilogue.
+        prelimb (up-sampling layers): `input` x this layer's style already in limb form (conv_mfma.torgb_limb)."""
         if MODCONV_FORM == 'grouped':
             if act is not None or pre is not None or bias is not None:
                 raise RuntimeError('grouped (reference-form) modulated convolution: the fused paths do not apply')
@@ -272,12 +273,12 @@ class ModulatedConv2d(nn.Module):
         if self.upsample and act is not None:
             # up-sampling layer: the activation follows the blur, so it rides in the blur kernel instead
             out = conv_mfma.modulated_conv2d(input, style, wmat_fwd, wmat_bwd, wsq, self.kernel_size,
-                                             upsample=True, demodulate=self.demodulate, demod=demod)
+                                             upsample=True, demodulate=self.demodulate, demod=demod, prelimb=prelimb)
             noise, noise_weight, bias, negative_slope, scale = act
             return blur_noise_act(out, self.blur.kernel, self.blur.pad, noise, noise_weight, bias, negative_slope, scale)
         out = conv_mfma.modulated_conv2d(input, style, wmat_fwd, wmat_bwd, wsq, self.kernel_size,
                                          upsample=self.upsample, demodulate=self.demodulate, act=act, demod=demod,
-                                         bias=bias)
+                                         bias=bias, prelimb=prelimb if self.upsample else None)
         if self.upsample:
             out = self.blur(out)
         return out
@@ -333,7 +334,7 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None, pre=None):
+    def forward(self, input, style, noise=None, pre=None, prelimb=None):
         if self.conv.can_fuse_act(input, style, self.noise.weight, self.activate.bias):
             n, _, h, w = input.shape
             if self.conv.upsample:
@@ -343,8 +344,9 @@ class StyledConv(nn.Module):
             elif noise.shape[0] != n:
                 noise = noise.expand(n, -1, -1, -1)
             return self.conv(input, style, act=(noise.type(input.dtype), self.noise.weight, self.activate.bias,
-                                                self.activate.negative_slope, self.activate.scale), pre=pre)
-        out = self.conv(input, style, pre=pre)
+                                                self.activate.negative_slope, self.activate.scale), pre=pre,
+                             prelimb=prelimb)
+        out = self.conv(input, style, pre=pre, prelimb=prelimb)
         n, _, h, w = out.shape
         if out.dtype == torch.float32 and (h * w) % 4 == 0 and MODCONV_FORM != 'grouped':
             # NoiseInjection + FusedLeakyReLU in one pass over the activation (csrc/fused_bias_act.hip)
@@ -358,13 +360,18 @@ class StyledConv(nn.Module):
         return self.activate(out)
 
 
-def styled_conv_with_rgb(styled, to_rgb, input, style, rgb_latent, noise=None, pre=None, pre_rgb=None):
+def styled_conv_with_rgb(styled, to_rgb, input, style, rgb_latent, noise=None, pre=None, pre_rgb=None, next_up=None):
     """StyledConv (no up-sampling) + the ToRGB convolution of the same resolution as ONE autograd node
-    (conv_mfma._StyledConvToRGB); returns (activation, raw rgb) or None when the pair cannot be fused (a style that
-    needs a gradient, trainable generator weights, shapes off the fused path)."""
+    (conv_mfma._StyledConvToRGB); returns (activation, raw rgb, prelimb) or None when the pair cannot be fused (a style
+    that needs a gradient, trainable generator weights, shapes off the fused path).
+    next_up = (the next resolution's up-sampling ModulatedConv2d, its (style, demodulation) from the style bank): the
+    ToRGB pass then also writes the activation in that layer's limb form (prelimb = (xlimb, xexp), else None).  Without
+    a gradient to carry (generator pass 1) the pair is fused only for that purpose."""
     conv, rgb_conv = styled.conv, to_rgb.conv
-    if ('torgb_fuse' in conv_mfma.DISABLED or not torch.is_grad_enabled() or not input.requires_grad
-            or MODCONV_FORM == 'grouped'):
+    want_limb = (next_up is not None and next_up[1] is not None and to_rgb.epilogue_bias() is not None and
+                 conv_mfma.prelimb_wanted(next_up[0].in_channel, input.shape[-1]) and input.shape[-1] == input.shape[-2])
+    needs_node = torch.is_grad_enabled() and input.requires_grad
+    if 'torgb_fuse' in conv_mfma.DISABLED or MODCONV_FORM == 'grouped' or not (needs_node or want_limb):
         return None
     if not conv.can_fuse_act(input, style, styled.noise.weight, styled.activate.bias) or conv.upsample:
         return None
@@ -383,7 +390,8 @@ def styled_conv_with_rgb(styled, to_rgb, input, style, rgb_latent, noise=None, p
            styled.activate.scale)
     w_rgb = rgb_conv.weight.detach().reshape(3, rgb_conv.in_channel).contiguous()
     return conv_mfma.styled_conv_torgb(input, s_c, wmat_fwd, wmat_bwd, wsq, conv.demodulate, act, demod, s_rgb, rgb_fwd,
-                                       w_rgb, rgb_conv.scale, to_rgb.epilogue_bias())
+                                       w_rgb, rgb_conv.scale, to_rgb.epilogue_bias(),
+                                       next_style=next_up[1][0] if want_limb else None)
 
 
 class ToRGB(nn.Module):
@@ -563,15 +571,20 @@ class Generator(nn.Module):
         out = self.conv1(self.input(latent), lat[0], noise=noise[0], pre=pre.get(self.conv1.conv))
         skip = self.to_rgb1(out, lat[1], pre=pre.get(self.to_rgb1.conv))
         i = 1
-        for conv_up, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2],
-                                                       self.to_rgbs):
-            out = conv_up(out, lat[i], noise=n_up, pre=pre.get(conv_up.conv))
+        prelimb = None                      # the next up-sampling layer's operand in limb form (conv_mfma.torgb_limb)
+        ups = list(self.convs[::2])
+        for k, (conv_up, conv, n_up, n_conv, to_rgb) in enumerate(zip(ups, self.convs[1::2], noise[1::2], noise[2::2],
+                                                                      self.to_rgbs)):
+            out = conv_up(out, lat[i], noise=n_up, pre=pre.get(conv_up.conv), prelimb=prelimb)
+            prelimb = None
             last = to_rgb is self.to_rgbs[-1]
             # every resolution but the last: the activation feeds ToRGB AND the next up-sampling layer -> one node
+            next_up = None if last else (ups[k + 1].conv, pre.get(ups[k + 1].conv))
             pair = None if last else styled_conv_with_rgb(conv, to_rgb, out, lat[i + 1], lat[i + 2], noise=n_conv,
-                                                          pre=pre.get(conv.conv), pre_rgb=pre.get(to_rgb.conv))
+                                                          pre=pre.get(conv.conv), pre_rgb=pre.get(to_rgb.conv),
+                                                          next_up=next_up)
             if pair is not None:
-                out, rgb = pair
+                out, rgb, prelimb = pair
                 skip = to_rgb.finish(rgb, skip, bias_done=to_rgb.epilogue_bias() is not None)
             else:
                 out = conv(out, lat[i + 1], noise=n_conv, pre=pre.get(conv.conv))

@@ -383,6 +383,42 @@ int gg_modconv3x3_act_bits_f32(float* y, const float* x, const float* wmat, cons
                                float gain, int batch, int cin, int cout, int h, int w, unsigned int* sign_bits,
                                void* stream);
 int gg_last_sign_bits_written(void);
+
+/* ------------------------------------------------------------------------------------------
+ * ABI 5 (round 6): the up-sampling convolution's operand written ONCE in MFMA-ready form.
+ * Every consumer tile of the split-precision kernels re-does, per 16 / 32-channel chunk of its patch, what turns an fp32
+ * activation into matrix-pipe operands: multiply by the layer's style, reduce the largest magnitude (block exponent),
+ * split into two binary16 limbs, transpose NCHW -> channel-fastest LDS rows.  For the generator's transposed 3x3 /
+ * stride-2 convolutions (networks.py:254-266) that work is moved into the pass that ALREADY streams the same activation
+ * for the ToRGB layer (networks.py:352-372):
+ *   gg_modconv3x3_act_amax_f32   the fused StyledConv launch of gg_modconv3x3_act_bits_f32, additionally leaving
+ *                                amax_out[n] = max |y[n]| (atomic max of non-negative bit patterns: order-independent;
+ *                                the caller zeroes amax_out; gg_last_amax_written() = 1 when the 3x3 patch tile without
+ *                                split-K served the launch and wrote it - else the caller keeps the fp32 route)
+ *   gg_torgb_limb_f32            rgb = ToRGB(y) (modulated 1x1 to 3 channels + bias) AND y's limb form for the next
+ *                                layer: xlimb[n][cin/16][pixel][limb 0|1][16 channels] binary16 = split(y * next_style[n]
+ *                                * 2^-E[n]), xlimb_exp[n] = E[n] = the block-exponent rule of the consumer applied to
+ *                                amax[n] * max_c |next_style[n][c]|.  cin % 16 == 0, cin <= 1024, hw % 4 == 0, else
+ *                                GG_NOT_SERVED
+ *   gg_convT3x3s2_prelimb_f32    conv_transpose2d(3x3, stride 2) of that operand with the binary16 pack `wsplit` (code
+ *                                18), epilogue scale 2^E[n] * out_scale + bias; served by the 16-channel-chunk tile only
+ *                                (power-of-two w >= 8, cin % 32 == 0): GG_NOT_SERVED, nothing launched, otherwise.
+ * With E = 0 (activations within [2^-3, 2^11]) the result is BITWISE the fp32-operand kernel's; measured on the consumer:
+ * 1.16 - 1.27x, VALU instructions per MFMA 3.18 -> 1.48 (profiles/r06_c_prelimb_probe.txt).
+ * ------------------------------------------------------------------------------------------ */
+int gg_modconv3x3_act_amax_f32(float* y, const float* x, const float* wmat, const unsigned short* wsplit,
+                               long long limb_stride, int limbs, const float* in_scale, const float* out_scale,
+                               const float* noise, const float* noise_weight, const float* act_bias, float alpha,
+                               float gain, int batch, int cin, int cout, int h, int w, unsigned int* sign_bits,
+                               float* amax_out, void* stream);
+int gg_last_amax_written(void);
+int gg_torgb_limb_f32(float* rgb, unsigned short* xlimb, int* xlimb_exp, const float* y, const float* rgb_wmat,
+                      const float* rgb_style, const float* rgb_bias, const float* next_style, const float* amax,
+                      int batch, int cin, long long hw, void* stream);
+int gg_convT3x3s2_prelimb_f32(float* y, const unsigned short* xlimb, const int* xlimb_exp,
+                              const unsigned short* wsplit, long long limb_stride, const float* out_scale,
+                              const float* bias, int batch, int cin, int cout, int h, int w, int pad, int out_h,
+                              int out_w, void* stream);
 /* gg_conv3x3_masked_dgrad_f32 with the mask taken from the sign plane of gg_modconv3x3_act_bits_f32 (words per pixel =
  * cin / 32; cin = the reduction channels of this launch = the layer's output channels).  limbs = 18 only (the
  * binary16-limb patch tiles); GG_NOT_SERVED otherwise and when the patch tile does not cover the shape.  Results are
