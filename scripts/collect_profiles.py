@@ -10,7 +10,7 @@ import shutil
 import subprocess
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get('ROUND', 'r05')
+ROUND = os.environ.get('ROUND', 'r06')
 O = os.path.join(R, 'gpurun_out', ROUND)
 P = os.path.join(R, 'profiles')
 DOM = 'conv3x3_patch_kernel<2, true, 256, 2, 0,'        # (MASK = 0: the plain tile; round 4's bool printed as false)
@@ -141,3 +141,31 @@ json.dump({
     'reading': f'reads = {fetch_b / 313174698:.2f}x the input tensor (tile halos), writes = {write_b / 313174698:.2f}x the output',
 }, open(os.path.join(P, f'{ROUND}_pmc_traffic.json'), 'w'), indent=1)
 print(open(os.path.join(P, f'{ROUND}_pmc_traffic.json')).read())
+
+# C4 / C5 (round 6): HBM traffic of the kernel that tops the workload's own kernel-stats table
+for w in ('c4', 'c5'):
+    if not os.path.exists(os.path.join(O, f'pmc_fetch_{w}.txt')):
+        continue
+    try:
+        _collect_w = True
+        top = next(l for l in open(os.path.join(O, f'kernel_stats_{w}.txt')).read().splitlines()
+                   if re.match(r'\s*\d+\s+[\d.]+\s+[\d.]+', l))
+        name = top.split(None, 6)[6].strip()
+        needle = name[:70].strip()
+        fw, ww = rows(f'pmc_fetch_{w}.txt'), rows(f'pmc_write_{w}.txt')
+        fn2, fv2 = find(fw, needle, 'FETCH_SIZE')
+        wn2, wv2 = find(ww, needle, 'WRITE_SIZE')
+        fb, wb = int(fv2 * 1024 * round(scale_f)), int(wv2 * 1024)
+        json.dump({'kernel': name[:140], 'precision': 'fp16x3', 'workload': w, 'batch': 16, 'kernel_source_sha16': sha,
+                   'commit': commit,
+                   'command': f'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python bench.py '
+                              f'--workload {w} --batch 16 --steps 2 --warmup 1 --no-cpu-baseline --no-extras',
+                   'launches_averaged': fn2, 'FETCH_SIZE_KB_per_launch': fv2, 'WRITE_SIZE_KB_per_launch': wv2,
+                   'calibration': f'as profiles/{ROUND}_pmc_traffic.json (same session): FETCH_SIZE x{round(scale_f)}, WRITE_SIZE exact',
+                   'fetch_bytes_per_launch': fb, 'write_bytes_per_launch': wb, 'hbm_bytes_per_launch': fb + wb,
+                   'note': 'mean over every launch of the kernel instantiation with the largest share of the workload\'s GPU '
+                           f'time (profiles/{ROUND}_a_kernel_stats_{w}.txt, first row)'},
+                  open(os.path.join(P, f'{ROUND}_pmc_traffic_{w}.json'), 'w'), indent=1)
+        print(w, name[:90], fb + wb)
+    except Exception as e:            # noqa: BLE001 - the C2 record must not depend on these
+        print(f'{w}: traffic record not written ({e})')

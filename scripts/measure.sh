@@ -15,7 +15,7 @@
 #   reference    the reference's own modules on the HIP operators (literal drop-in) + the 1-rank RCCL trainer test
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
 export GANGEALING_SYNTHETIC=1 TMPDIR=/tmp
@@ -101,6 +101,17 @@ sec_pmc() {
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/splat_write -- python $R/scripts/splat_bench.py > /dev/null 2>&1
   fi
   cd $R
+  # round 6: the same two passes for C4 / C5 at the recipes' per-GPU batch (roofline.traffic of extras.c4_batch16 / c5_batch16)
+  for w in c4 c5; do
+    WCMD="python $R/bench.py --workload $w --batch 16 --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$w -- $WCMD > /dev/null 2>&1
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$w -- $WCMD > /dev/null 2>&1
+  done
+  cd $R
+  for d in pmc_fetch_c4 pmc_write_c4 pmc_fetch_c5 pmc_write_c5; do
+    python scripts/pmc_kernel.py $O/$d "" > $O/$d.txt 2>&1
+    rm -rf $O/$d
+  done
   for d in pmc_fetch pmc_write cal_fetch cal_write pmc_sq; do
     python scripts/pmc_kernel.py $O/$d "" > $O/$d.txt 2>&1
     rm -rf $O/$d

@@ -497,7 +497,9 @@ def test_committed_pmc_traffic_belongs_to_this_trees_kernels():
     import json
     sys.path.insert(0, REPO)
     import bench
-    with open(os.path.join(REPO, 'profiles', 'r05_pmc_traffic.json')) as f:
+    name = 'r06_pmc_traffic.json' if os.path.exists(os.path.join(REPO, 'profiles', 'r06_pmc_traffic.json')) else \
+        'r05_pmc_traffic.json'
+    with open(os.path.join(REPO, 'profiles', name)) as f:
         rec = json.load(f)
     traffic = bench.pmc_traffic('fp16x3', 'c2', 16)
     if rec['kernel_source_sha16'] != bench.kernel_source_hash():
