@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's measurement session on the GPU box, in SECTIONS (one gpurun call runs the sections named on the command line; no
 # arguments = the full session behind profiles/<round>_* and profiles/bench_<round>_*, copied by scripts/collect_profiles.py).
-# ROUND=r05 (default) names the output directory gpurun_out/$ROUND and the files; rounds 2 - 4 used earlier forms of this script:
+# ROUND=r06 (default) names the output directory gpurun_out/$ROUND and the files; rounds 2 - 4 used earlier forms of this script:
 #
 #   smoke        __graft_entry__.smoke()
 #   suite        GPU test suite + parity report (-> parity_$ROUND.json)
