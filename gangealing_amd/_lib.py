@@ -37,6 +37,8 @@ _PROTOS = {
     'gg_mipmap_warp_fwd_f32': 'ppppipiiiiiiiiiffiis',
     'gg_mipmap_warp_bwd_f32': 'ppppppipiiiiiiiiiffiips',
     'gg_mipmap_warp_indices_f32': 'ppppppiiiiiffiis',
+    'gg_similarity_matrix_f32': 'ppiis',
+    'gg_similarity_matrix_bwd_f32': 'pppiis',
     'gg_affine_grid_f32': 'ppiiis',
     'gg_affine_grid_bwd_f32': 'ppiiis',
     'gg_flow_compose_fwd_f32': 'pppppiiiis',
@@ -57,6 +59,7 @@ _PROTOS = {
     'gg_modconv3x3_act_bits_f32': 'ppppqipppppffiiiiips',
     'gg_conv3x3_masked_dgrad_bits_f32': 'pppffpqippiiiiis',
     'gg_modconv3x3_act_amax_f32': 'ppppqipppppffiiiiipps',
+    'gg_conv3x3_fewout_masked_bits_f32': 'pppffpiiiiis',
     'gg_torgb_limb_f32': 'pppppppppiiqs',
     'gg_convT3x3s2_prelimb_f32': 'ppppqppiiiiiiiis',
     'gg_conv2d_wgrad_f32': 'pppiiiiiiiiifs',

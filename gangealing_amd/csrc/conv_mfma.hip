@@ -3069,6 +3069,115 @@ int launch_conv1x1_fewin(const ConvArgs& a, hipStream_t st) {
   return gg::launch_status("conv1x1_fewin");
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with <= 4 INPUT channels and its bias + (leaky) ReLU: the perceptual trunk's RGB stem
+// (3 -> 64 @128^2 over 32 images; lpips_backbones.py:109).  K = 27: on the fp32 MFMA tile the launch was a 134 MB
+// scalar-store stream at 1.8 TB/s (74 us) followed by a separate activation pass (42 us).  Here a lane owns 4 consecutive
+// pixels of one image row, keeps the 3 x 6 x NCI input window in registers and walks the block's 32 output channels with
+// the 9 * NCI weights broadcast from LDS (108 FMAs per channel): one float4 store per channel, the activation in registers,
+// and - for the layer's masked data gradient - bit j of the lane's four words = (stored output of channel co0 + j > 0),
+// the sign plane of conv_common.h (ConvArgs::sign_bits).  Exact fp32 products, k ascending.
+// wmat: [(ci, ky, kx)][co] (fp32 GEMM layout of pack_weight_kernel).
+// ------------------------------------------------------------------------------------------------
+constexpr int FEWIN3_CO = 32;
+template <int NCI>
+__global__ __launch_bounds__(256) void conv3x3_fewin_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                            const float* __restrict__ wmat,
+                                                            const float* __restrict__ bias, int cout, int h, int w,
+                                                            int act, float alpha, float gain,
+                                                            unsigned* __restrict__ sign_bits, int bit_words, int nt) {
+  __shared__ float sw[FEWIN3_CO][NCI * 9 + 1];             // [co][k], [co][NCI * 9] = bias
+  const int n = blockIdx.z, co0 = blockIdx.y * FEWIN3_CO, tid = threadIdx.x;
+  const long long hw = (long long)h * w;
+  for (int i = tid; i < FEWIN3_CO * (NCI * 9 + 1); i += 256) {
+    const int j = i / (NCI * 9 + 1), k = i - j * (NCI * 9 + 1), co = co0 + j;
+    sw[j][k] = co < cout ? (k < NCI * 9 ? wmat[(size_t)k * cout + co] : (bias ? bias[co] : 0.f)) : 0.f;
+  }
+  __syncthreads();
+  const long long p = ((long long)blockIdx.x * 256 + tid) * 4;
+  if (p >= hw) return;                                      // w % 4 == 0: the four pixels share a row
+  const int py = (int)(p / w), px = (int)(p - (long long)py * w);
+  const bool left = px > 0, right = px + 4 < w;
+  float v[NCI][3][6];
+#pragma unroll
+  for (int ci = 0; ci < NCI; ++ci) {
+    const float* plane = x + ((size_t)n * NCI + ci) * hw;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = py + dy - 1;
+      if ((unsigned)yy < (unsigned)h) {
+        const float* row = plane + (size_t)yy * w + px;
+        const float4 c = *reinterpret_cast<const float4*>(row);
+        v[ci][dy][0] = left ? row[-1] : 0.f;
+        v[ci][dy][1] = c.x; v[ci][dy][2] = c.y; v[ci][dy][3] = c.z; v[ci][dy][4] = c.w;
+        v[ci][dy][5] = right ? row[4] : 0.f;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[ci][dy][q] = 0.f;
+      }
+    }
+  }
+  unsigned sgn[4] = {0u, 0u, 0u, 0u};
+  const int jn = cout - co0 < FEWIN3_CO ? cout - co0 : FEWIN3_CO;
+  for (int j = 0; j < jn; ++j) {
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float wj = sw[j][(ci * 3 + dy) * 3 + dx];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) r[q] = fmaf(v[ci][dy][dx + q], wj, r[q]);
+        }
+    const float bi = sw[j][NCI * 9];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float t = r[q] + bi;
+      if (act) t = (t > 0.f ? t : t * alpha) * gain;
+      r[q] = t;
+      sgn[q] |= (t > 0.f ? 1u : 0u) << j;
+    }
+    float* dst = y + ((size_t)n * cout + co0 + j) * hw + p;
+    if (nt) __builtin_nontemporal_store(f32x4{r[0], r[1], r[2], r[3]}, reinterpret_cast<f32x4*>(dst));
+    else *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+  if (sign_bits) {
+    unsigned* dst = sign_bits + ((size_t)n * hw + p) * bit_words + blockIdx.y;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[(size_t)q * bit_words] = sgn[q];
+  }
+}
+
+bool fewin3_serves(const ConvArgs& a, int stride, int pad, int mode) {
+  static const bool off = getenv("GG_NO_FEWIN3") != nullptr;      // measurement switch
+  const long long hw = (long long)a.h * a.w;
+  return !off && mode == 0 && stride == 1 && pad == 1 && a.groups == 1 && a.cin_g >= 1 && a.cin_g <= 4 && a.cout_g >= 16 &&
+         a.wmat && !a.in_scale && !a.out_scale && !a.mask_ref && !a.mask_bits && !(a.act && a.act_noise) &&
+         a.w % 4 == 0 && (long long)a.batch * hw >= 65536 && a.batch <= 65535 &&
+         (a.cout_g + FEWIN3_CO - 1) / FEWIN3_CO <= 65535 && (!a.sign_bits || a.cout_g % 32 == 0) &&
+         (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
+}
+
+int launch_conv3x3_fewin(const ConvArgs& a, hipStream_t st) {
+  NOTE_KERNEL("conv3x3_fewin%s", a.act ? "+bias+lrelu" : "");
+  const long long hw = (long long)a.h * a.w;
+  dim3 grid((unsigned)((hw / 4 + 255) / 256), (unsigned)((a.cout_g + FEWIN3_CO - 1) / FEWIN3_CO), (unsigned)a.batch);
+  const float* bias = a.act ? a.act_bias : a.bias;
+#define GG_FEWIN3(N) conv3x3_fewin_kernel<N><<<grid, 256, 0, st>>>(a.y, a.x, a.wmat, bias, a.cout_g, a.h, a.w, a.act, \
+                                                                   a.act_alpha, a.act_gain, a.sign_bits, a.bit_words, a.nt_store)
+  switch (a.cin_g) {
+    case 1: GG_FEWIN3(1); break;
+    case 2: GG_FEWIN3(2); break;
+    case 3: GG_FEWIN3(3); break;
+    default: GG_FEWIN3(4); break;
+  }
+#undef GG_FEWIN3
+  g_sign_bits_written = a.sign_bits ? 1 : 0;
+  return gg::launch_status("conv3x3_fewin");
+}
+
 bool fewout_serves(const ConvArgs& a, int stride, int pad, int mode) {
   const long long hw = (long long)a.h * a.w;
   static const bool off = getenv("GG_NO_FEWOUT") != nullptr;      // measurement switch
@@ -3099,12 +3208,19 @@ int launch_conv1x1_fewout(const ConvArgs& a, hipStream_t st) {
 // waves of a block split the input channels and meet in LDS.  HBM-bound: 4 * Cin bytes per pixel in.
 // wmat: [(ci, ky, kx)][co] (fp32 GEMM layout of pack_weight_kernel).
 // ------------------------------------------------------------------------------------------------
-template <int NCO>
+// MASKB (round 6): x is the gradient of a conv + leaky-ReLU layer's OUTPUT and the activation's backward is applied as it is
+// read - x * (bit ? gain : alpha * gain), bit (k & 31) of word [(n * H * W + pixel) * bit_words + k / 32] of the sign plane
+// the layer's forward wrote (ConvArgs::sign_bits): 18 words per lane and 32 channels instead of a separate masked-gradient
+// pass over the 134 MB tensor (the stem's ReLU backward: 57 us).
+template <int NCO, bool MASKB = false>
 __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                              const float* __restrict__ wmat,
                                                              const float* __restrict__ in_scale,
                                                              const float* __restrict__ out_scale,
-                                                             const float* __restrict__ bias, int cin, int h, int w) {
+                                                             const float* __restrict__ bias, int cin, int h, int w,
+                                                             const unsigned* __restrict__ mask_bits = nullptr,
+                                                             int bit_words = 0, float mask_alpha = 0.f,
+                                                             float mask_gain = 1.f) {
   extern __shared__ __attribute__((aligned(16))) float sw[];                     // cin * 9 * NCO style-scaled weights
   __shared__ float4 red[4][NCO][64];
   const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
@@ -3123,9 +3239,24 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(float* __restrict__
     const int py = (int)(p / w), px = (int)(p - (long long)py * w);
     const int per = (cin + 3) / 4, k0 = g * per, k1 = (k0 + per < cin) ? k0 + per : cin;
     const bool left = px > 0, right = px + 4 < w;
+    unsigned wd[3][6];                                       // MASKB: sign words of the 3 x 6 window, current 32-channel group
+    const float m_neg = mask_alpha * mask_gain;
     for (int k = k0; k < k1; ++k) {
       const float* plane = x + ((size_t)n * cin + k) * hw;
       const float* wk = sw + (size_t)k * 9 * NCO;
+      if (MASKB && (k == k0 || (k & 31) == 0)) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int yy = py + dy - 1;
+          const bool rok = (unsigned)yy < (unsigned)h;
+          const unsigned* brow = mask_bits + ((size_t)n * hw + (size_t)(rok ? yy : py) * w + px) * bit_words + (k >> 5);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            const bool cok = rok && (q == 0 ? left : (q == 5 ? right : true));
+            wd[dy][q] = cok ? brow[(long long)(q - 1) * bit_words] : 0u;
+          }
+        }
+      }
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
         const int yy = py + dy - 1;
@@ -3133,7 +3264,11 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(float* __restrict__
         const float* row = plane + (size_t)yy * w + px;
         const float4 c = *reinterpret_cast<const float4*>(row);
         const float l = left ? row[-1] : 0.f, r = right ? row[4] : 0.f;
-        const float v[6] = {l, c.x, c.y, c.z, c.w, r};
+        float v[6] = {l, c.x, c.y, c.z, c.w, r};
+        if (MASKB) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) v[q] *= ((wd[dy][q] >> (k & 31)) & 1u) ? mask_gain : m_neg;
+        }
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
@@ -3186,6 +3321,24 @@ int launch_conv3x3_fewout(const ConvArgs& a, hipStream_t st) {
 
 constexpr int kNotFused = GG_NOT_SERVED;      // masked-input request that no kernel serves: nothing was launched
 
+// the data gradient of a few-input-channel conv + (leaky) ReLU layer with the activation's backward read from the sign plane
+int launch_conv3x3_fewout_masked(const ConvArgs& a, hipStream_t st) {
+  NOTE_KERNEL("conv3x3_fewout+lrelu-mask(sign plane)");
+  const long long hw = (long long)a.h * a.w;
+  dim3 grid((unsigned)((hw + 255) / 256), (unsigned)a.batch);
+  const size_t smem = sizeof(float) * (size_t)a.cin_g * 9 * a.cout_g;
+#define GG_FEWOUT3M(N) conv3x3_fewout_kernel<N, true><<<grid, 256, smem, st>>>(a.y, a.x, a.wmat, a.in_scale, a.out_scale, \
+                         a.bias, a.cin_g, a.h, a.w, a.mask_bits, a.bit_words, a.mask_alpha, a.mask_gain)
+  switch (a.cout_g) {
+    case 1: GG_FEWOUT3M(1); break;
+    case 2: GG_FEWOUT3M(2); break;
+    case 3: GG_FEWOUT3M(3); break;
+    default: GG_FEWOUT3M(4); break;
+  }
+#undef GG_FEWOUT3M
+  return gg::launch_status("conv3x3_fewout_masked");
+}
+
 template <int KS>
 int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int limbs = 0) {
   if (a.xlimb && a.xlimb_e) {
@@ -3208,6 +3361,7 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
   if (KS == 1 && limbs == 0 && fewout_serves(a, stride, pad, mode)) return launch_conv1x1_fewout(a, st);
   if (KS == 1 && limbs == 0 && fewin_serves(a, stride, pad, mode)) return launch_conv1x1_fewin(a, st);
   if (KS == 3 && limbs == 0 && fewout3_serves(a, stride, pad, mode)) return launch_conv3x3_fewout(a, st);
+  if (KS == 3 && limbs == 0 && fewin3_serves(a, stride, pad, mode)) return launch_conv3x3_fewin(a, st);
   if (!a.act && limbs && KS == 3 && mode == 1 && pad <= 1 && a.w >= 4 && (a.w & (a.w - 1)) == 0 &&
       (long long)a.cin_g * a.h * a.w * 4 < (1LL << 31) && (long long)a.cout_g * a.oh * a.ow * 4 < (1LL << 31))
     return launch_convT_patch(a, limbs, pad, st);
@@ -3551,6 +3705,24 @@ extern "C" int gg_conv3x3_masked_dgrad_bits_f32(float* y, const float* x, const 
   mask.bits = mask_bits; mask.alpha = alpha; mask.gain = gain;
   return conv2d_entry(y, x, nullptr, wsplit, limb_stride, limbs, in_scale, out_scale, nullptr, batch, 1, cin, cout, h,
                       w, 3, 1, 1, 0, 0, 0, stream, ActArgs(), mask);
+}
+
+// Masked data gradient of a 3x3 conv + (leaky) ReLU layer with <= 4 INPUT channels (the perceptual trunk's RGB stem):
+// dx (N, cout <= 4, H, W) = conv3x3(dy * lrelu'(y), wmat), lrelu'(y) from the sign plane.  wmat: fp32 GEMM layout
+// [(ci, ky, kx)][co] of the DATA-GRADIENT convolution (gg_conv_pack_weight_f32 with transpose_io = flip = 1).
+extern "C" int gg_conv3x3_fewout_masked_bits_f32(float* dx, const float* dy, const unsigned int* mask_bits, float alpha,
+                                                 float gain, const float* wmat, int batch, int cin, int cout, int h,
+                                                 int w, void* stream) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+  if (!dx || !dy || !mask_bits || !wmat) return gg::fail(-2, "conv3x3_fewout_masked_bits: null pointer");
+  ConvArgs a = {};
+  a.y = dx; a.x = dy; a.wmat = wmat;
+  a.batch = batch; a.groups = 1; a.cin_g = cin; a.cout_g = cout; a.h = h; a.w = w; a.oh = h; a.ow = w;
+  if (cin % 32 != 0 || !fewout3_serves(a, 1, 1, 0)) return kNotFused;
+  a.mask_bits = mask_bits; a.bit_words = cin / 32; a.mask_alpha = alpha; a.mask_gain = gain;
+  g_sign_bits_written = 0;
+  g_amax_written = 0;
+  return launch_conv3x3_fewout_masked(a, gg::as_stream(stream));
 }
 
 extern "C" int gg_conv_pack_weights_many(const void* jobs, int njobs, void* stream) {

@@ -58,6 +58,54 @@ __global__ __launch_bounds__(256) void affine_grid_bwd_kernel(float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------- similarity matrix
+// SimilarityHead.make_affine_matrix (warping_heads.py:36-56): the regressed (N, 4K) row [rot | log-scale | shift_x |
+// shift_y] (K heads each) -> K matrices [[s cos r, -s sin r, tx], [s sin r, s cos r, ty]], r = pi tanh(rot), s = exp(.).
+// The reference spends 11 element-wise launches on (N, K) tensors here and ~25 more in the backward; one thread per
+// (sample, head) does either direction.  Same operations in the same order as the ATen kernels the reference runs
+// (tanh, * float(pi), exp, cos, sin, products - nothing to contract).
+constexpr float kPiF = 3.14159274101257324f;         // float(math.pi), the scalar ATen multiplies by
+
+__global__ __launch_bounds__(256) void similarity_matrix_kernel(float* __restrict__ m, const float* __restrict__ p,
+                                                                int n, int k) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * k) return;
+  const int i = idx / k, h = idx - i * k;
+  const float* row = p + (size_t)i * 4 * k;
+  const float r = gg::mul_rn(tanhf(row[h]), kPiF);
+  const float s = expf(row[k + h]);
+  const float c = cosf(r), sn = sinf(r);
+  float* o = m + (size_t)idx * 6;
+  o[0] = gg::mul_rn(s, c);
+  o[1] = gg::mul_rn(-s, sn);
+  o[2] = row[2 * k + h];
+  o[3] = gg::mul_rn(s, sn);
+  o[4] = gg::mul_rn(s, c);
+  o[5] = row[3 * k + h];
+}
+
+__global__ __launch_bounds__(256) void similarity_matrix_bwd_kernel(float* __restrict__ gp, const float* __restrict__ gm,
+                                                                    const float* __restrict__ p, int n, int k) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * k) return;
+  const int i = idx / k, h = idx - i * k;
+  const float* row = p + (size_t)i * 4 * k;
+  const float t = tanhf(row[h]);
+  const float r = gg::mul_rn(t, kPiF);
+  const float s = expf(row[k + h]);
+  const float c = cosf(r), sn = sinf(r);
+  const float* g = gm + (size_t)idx * 6;
+  const float ga = g[0] + g[4];                 // d / d(s cos r)
+  const float gb = g[3] - g[1];                 // d / d(s sin r)
+  const float gs = ga * c + gb * sn;
+  const float gr = s * (gb * c - ga * sn);
+  float* o = gp + (size_t)i * 4 * k;
+  o[h] = gr * kPiF * (1.f - t * t);
+  o[k + h] = gs * s;
+  o[2 * k + h] = g[2];
+  o[3 * k + h] = g[5];
+}
+
 // ---------------------------------------------------------------- flow composition
 
 struct Convex {
@@ -448,6 +496,24 @@ __global__ __launch_bounds__(256) void flow_losses_bwd_kernel(float* __restrict_
 }
 
 }  // namespace
+
+extern "C" int gg_similarity_matrix_f32(float* matrix, const float* params, int n, int heads, void* stream) {
+  if (n <= 0 || heads <= 0) return 0;
+  if (!matrix || !params) return gg::fail(-2, "similarity_matrix: null pointer");
+  if ((long long)n * heads > (1LL << 30)) return gg::fail(-2, "similarity_matrix: too many matrices");
+  similarity_matrix_kernel<<<(unsigned)((n * heads + 255) / 256), 256, 0, gg::as_stream(stream)>>>(matrix, params, n, heads);
+  return gg::launch_status("similarity_matrix");
+}
+
+extern "C" int gg_similarity_matrix_bwd_f32(float* grad_params, const float* grad_matrix, const float* params, int n,
+                                            int heads, void* stream) {
+  if (n <= 0 || heads <= 0) return 0;
+  if (!grad_params || !grad_matrix || !params) return gg::fail(-2, "similarity_matrix_bwd: null pointer");
+  if ((long long)n * heads > (1LL << 30)) return gg::fail(-2, "similarity_matrix_bwd: too many matrices");
+  similarity_matrix_bwd_kernel<<<(unsigned)((n * heads + 255) / 256), 256, 0, gg::as_stream(stream)>>>(
+      grad_params, grad_matrix, params, n, heads);
+  return gg::launch_status("similarity_matrix_bwd");
+}
 
 extern "C" int gg_affine_grid_f32(float* grid, const float* theta, int n, int ho, int wo, void* stream) {
   const long long total = (long long)n * ho * wo;

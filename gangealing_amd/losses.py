@@ -281,9 +281,12 @@ class vgg16(nn.Module):
         for si in range(5):
             for name, mod in getattr(self, f'slice{si + 1}').named_children():
                 if isinstance(mod, nn.Conv2d):
-                    if x.shape[1] % 32 == 0:     # conv + bias + ReLU in one kernel (alpha 0, gain 1)
+                    if x.shape[1] % 32 == 0 or (x.shape[1] <= 4 and x.shape[-1] % 4 == 0 and
+                                                'vgg_stem' not in conv_mfma.DISABLED):
+                        # conv + bias + ReLU in one kernel (alpha 0, gain 1): the MFMA tiles, or - the 3-channel stem -
+                        # the streaming few-input-channel kernel (exact fp32 products; csrc/conv_mfma.hip)
                         x = conv_mfma.conv3x3_bias_act(x, mod.weight, mod.bias, 0.0, 1.0)
-                    else:                        # 3-channel stem: fp32 kernel + separate ReLU
+                    else:                        # fp32 kernel + separate ReLU
                         x = F.relu(conv_mfma.conv2d(x, mod.weight, mod.bias, stride=1, padding=1))
                     if observe is not None:
                         observe(int(name), x)
@@ -390,9 +393,15 @@ class LPIPS(nn.Module):
         # the reference accumulates IN PLACE into res[0] (lpips.py:203-205: `val = res[0]; val += res[l]`), so with
         # retPerLayer the first "per-layer" entry it hands back is the total - reproduced as is
         val = res[0]
+        if retPerLayer:
+            for r in res[1:]:
+                val += r
+            return val, res
+        # same left-to-right sum, out of place: an in-place update of a view of a custom node's output makes autograd
+        # rebase the view (CopySlices: ~13 clone / copy launches in the backward of every step)
         for r in res[1:]:
-            val += r
-        return (val, res) if retPerLayer else val
+            val = val + r
+        return val
 
 
 class _Scaled(nn.Module):

@@ -396,8 +396,11 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             noise, noise_weight, act_bias, alpha, gain = act       # noise / noise_weight / act_bias may be None
             wbuf, stride_l = wmat.split(code) if use_split else (None, 0)
             wm = None if use_split else (wmat.fp32() if isinstance(wmat, PackedWeight) else wmat)
-            if (want_sign_bits and use_split and pack_code == 18 and cout_g % 32 == 0 and 'sign_bits' not in DISABLED
-                    and ACT_OBSERVER is None):
+            # the sign plane comes from the binary16-limb patch tile, or (round 6) from the few-input-channel fp32 kernel
+            # that serves the perceptual trunk's RGB stem
+            few_in = not use_split and cin_g <= 4 and w % 4 == 0 and noise is None and 'fewin_bits' not in DISABLED
+            if (want_sign_bits and ((use_split and pack_code == 18) or few_in) and cout_g % 32 == 0
+                    and 'sign_bits' not in DISABLED and ACT_OBSERVER is None):
                 sign_bits = torch.empty((batch, oh * ow, cout_g // 32), dtype=torch.int32, device=x.device)
             if amax_out is not None and use_split and pack_code == 18:
                 _lib.call('gg_modconv3x3_act_amax_f32', y, x, wm, wbuf, stride_l, code, in_scale, out_scale,
@@ -405,8 +408,8 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
                 if sign_bits is not None and not _lib.load().gg_last_sign_bits_written():
                     sign_bits = None
             elif sign_bits is not None:
-                _lib.call('gg_modconv3x3_act_bits_f32', y, x, wm, wbuf, stride_l, code, in_scale, out_scale,
-                          noise, noise_weight, act_bias, alpha, gain, batch, cin_g, cout_g, h, w, sign_bits)
+                _lib.call('gg_modconv3x3_act_bits_f32', y, x, wm, wbuf, stride_l, code if use_split else 0, in_scale,
+                          out_scale, noise, noise_weight, act_bias, alpha, gain, batch, cin_g, cout_g, h, w, sign_bits)
                 if not _lib.load().gg_last_sign_bits_written():
                     sign_bits = None          # split-K / another kernel served the shape: the backward keeps y
             else:
@@ -661,6 +664,18 @@ class _Conv3x3BiasAct(Function):
             # frozen layer (VGG backbone): only the data gradient is wanted - mask the gradient inside the conv
             wm = packed(weight, 1, cin, cout, 3, 1, 1, wscale)
             dx = masked_dgrad(dy, y, alpha, gain, wm, n, cout, cin, h, w, sign_bits=ctx.sign_bits)
+            if dx is None and ctx.sign_bits is not None and cin <= 4 and cout % 32 == 0:
+                # few-input-channel layer (the perceptual trunk's RGB stem): the streaming few-output-channel data
+                # gradient reads the activation's backward from the sign plane (gg_conv3x3_fewout_masked_bits_f32)
+                dx = torch.empty((n, cin, h, w), dtype=torch.float32, device=dy.device)
+                sig = ('masked_dgrad_fewout', n, cout, cin, h, w)
+                prof, start = _prof_begin(sig)
+                rc = _lib.call('gg_conv3x3_fewout_masked_bits_f32', dx, dy, ctx.sign_bits, alpha, gain, wm.fp32(), n, cout,
+                               cin, h, w, allow=(_lib.NOT_SERVED,))
+                if rc == 0:
+                    _prof_end(prof, start, sig, 2.0 * n * cin * cout * 9 * h * w, last_conv_kernel())
+                else:
+                    dx = None
             if dx is not None:
                 return dx, None, None, None, None, None
         slot = None
@@ -1077,7 +1092,7 @@ class _AddScale(Function):
 
     @staticmethod
     def backward(ctx, g):
-        gs = g * ctx.scale
+        gs = g if ctx.scale == 1.0 else g * ctx.scale
         return gs, gs, None
 
 

@@ -120,6 +120,58 @@ class UpFirDn2dAdd(Function):
         return grad_input, None, None, None, None, (grad_output if ctx.needs_input_grad[5] else None)
 
 
+class _BlurDownTap(Function):
+    """x -> (x, upfirdn2d(x, kernel, down=2, pad)) as ONE autograd node: ResBlock's input feeds conv1 AND the blurred,
+    decimated skip branch (networks.py:383-393).  The backward receives the gradient conv1 produced for x and ADDS the
+    adjoint of the decimating blur into it in the same pass (gg_upfirdn2d_add_f32) - instead of writing the adjoint to a
+    tensor of its own that autograd then sums with the other branch's (a full-size write + read + add launch less)."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, pad):
+        x = x.contiguous()
+        p0, p1 = pad
+        kh, kw = kernel.shape
+        _, _, in_h, in_w = x.shape
+        out_h, out_w = _out_size(in_h, in_w, kh, kw, 1, 1, 2, 2, p0, p1, p0, p1)
+        ctx.save_for_backward(kernel)
+        ctx.g_pad = (kw - p0 - 1, in_w - out_w * 2 + p0, kh - p0 - 1, in_h - out_h * 2 + p0)
+        ctx.in_hw = (in_h, in_w)
+        ctx.set_materialize_grads(False)
+        return x, _launch(x, kernel, 1, 1, 2, 2, p0, p1, p0, p1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_x, g_down):
+        (kernel,) = ctx.saved_tensors
+        if g_down is None:
+            return g_x, None, None
+        gx0, gx1, gy0, gy1 = ctx.g_pad
+        flipped = _flipped(kernel)
+        if g_x is None or g_x.dtype != torch.float32:
+            gd = _launch(g_down, flipped, 2, 2, 1, 1, gx0, gx1, gy0, gy1)
+            return (gd if g_x is None else g_x + gd), None, None
+        g_down, g_x = g_down.contiguous(), g_x.contiguous()
+        n, c, h, w = g_down.shape
+        in_h, in_w = ctx.in_hw
+        if tuple(g_x.shape[-2:]) != (in_h, in_w):
+            raise ValueError(f'blur_down_tap backward: gradient {tuple(g_x.shape)} vs input {(in_h, in_w)}')
+        out = torch.empty_like(g_x)
+        prof = _profiler('upfirdn2d_add<4x4,up2,down1>')
+        start = prof.begin() if prof is not None else None
+        _lib.call('gg_upfirdn2d_add_f32', out, g_down, flipped.to(g_down.dtype).contiguous(), g_x, n * c, h, w,
+                  kernel.shape[0], kernel.shape[1], 2, 2, 1, 1, gx0, gx1, gy0, gy1)
+        if prof is not None:
+            prof.end(start, 4 * (g_down.numel() + 2 * out.numel()), 'upfirdn2d_add<4x4,up2,down1>', 'byte')
+        return out, None, None
+
+
+def blur_down_tap(x, kernel, pad):
+    """-> (x, upfirdn2d(x, kernel, up=1, down=2, pad)); see _BlurDownTap."""
+    if x.device.type != 'cuda':
+        raise _lib.HipLibraryError('blur_down_tap: HIP tensors only')
+    return _BlurDownTap.apply(x, kernel.to(x.dtype), (int(pad[0]), int(pad[1])))
+
+
 def upfirdn2d_add(input, kernel, addend, up=1, down=1, pad=(0, 0)):
     """upfirdn2d(input, kernel, up, down, pad) + addend (float32)."""
     if input.dtype != torch.float32 or addend.dtype != torch.float32:

@@ -37,6 +37,36 @@ class _AffineGrid(Function):
         return gt, None, None
 
 
+class _SimilarityMatrix(Function):
+    """params (N, 4K) -> (N, K, 2, 3), SimilarityHead.make_affine_matrix (warping_heads.py:36-56) as one launch per
+    direction (gg_similarity_matrix_f32 / _bwd_f32) instead of 11 + ~25 element-wise launches on (N, K) tensors."""
+
+    @staticmethod
+    def forward(ctx, params, heads):
+        _f32_cuda(params)
+        params = params.contiguous()
+        n = params.shape[0]
+        if params.dim() != 2 or params.shape[1] != 4 * heads:
+            raise ValueError(f'similarity_matrix: params {tuple(params.shape)} for {heads} head(s)')
+        m = torch.empty((n, heads, 2, 3), dtype=torch.float32, device=params.device)
+        _lib.call('gg_similarity_matrix_f32', m, params, n, heads)
+        ctx.save_for_backward(params)
+        ctx.heads = heads
+        return m
+
+    @staticmethod
+    def backward(ctx, gm):
+        (params,) = ctx.saved_tensors
+        gp = torch.empty_like(params)
+        _lib.call('gg_similarity_matrix_bwd_f32', gp, gm.contiguous(), params, params.shape[0], ctx.heads)
+        return gp, None
+
+
+def similarity_matrix(params, heads=1):
+    """[rot | log-scale | shift_x | shift_y] (N, 4 * heads) -> similarity matrices (N, heads, 2, 3)."""
+    return _SimilarityMatrix.apply(params, int(heads))
+
+
 def affine_grid(theta, size, align_corners=False):
     """F.affine_grid(theta (N,2,3), size (N,C,H,W), align_corners=False)."""
     if align_corners:

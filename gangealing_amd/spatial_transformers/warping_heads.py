@@ -14,7 +14,8 @@ import torch
 import torch.nn as nn
 
 from .antialiased_sampling import MipmapWarp, Warp
-from .flow_ops import affine_grid, flow_compose, flow_resize
+from .flow_ops import affine_grid, flow_compose, flow_resize, similarity_matrix
+from ..op import conv_mfma
 from ..stylegan2.networks import EqualConv2d
 
 
@@ -93,7 +94,10 @@ class SimilarityHead(nn.Module):
             split = 1
         else:
             split = self.num_heads
-        matrix = self.make_affine_matrix(*torch.split(params, split, dim=1))           # (N, split, 2, 3)
+        if params.dtype == torch.float32 and params.is_cuda and 'similarity_matrix' not in conv_mfma.DISABLED:
+            matrix = similarity_matrix(params, split)                                  # (N, split, 2, 3), one launch
+        else:
+            matrix = self.make_affine_matrix(*torch.split(params, split, dim=1))
         if base_warp is not None:
             if base_warp.dim() == 3:
                 base_warp = base_warp.unsqueeze(1)

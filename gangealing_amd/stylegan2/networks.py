@@ -23,7 +23,7 @@ from torch.nn import functional as F
 
 from ..op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from ..op.fused_act import noise_bias_leaky_relu
-from ..op.upfirdn2d import blur_noise_act, blur_noise_act_ok, upfirdn2d_add
+from ..op.upfirdn2d import blur_noise_act, blur_noise_act_ok, upfirdn2d_add, blur_down_tap
 from ..op import conv_mfma
 
 
@@ -476,8 +476,43 @@ class ResBlock(nn.Module):
         self.skip = ConvLayer(in_channel, out_channel, 1, downsample=downsample, activate=False, bias=False)
 
     def forward(self, input):
+        if (input.dtype == torch.float32 and input.is_cuda and 'resblock_fold' not in conv_mfma.DISABLED
+                and self._foldable()):
+            return self._forward_folded(input)
         out = self.conv2(self.conv1(input))
         return conv_mfma.add_scale(out, self.skip(input), 1.0 / math.sqrt(2))
+
+    def _foldable(self):
+        c2, sk = self.conv2, self.skip
+        if isinstance(c2[0], Blur):
+            return (len(c2) == 3 and isinstance(c2[1], EqualConv2d) and isinstance(c2[2], FusedLeakyReLU) and
+                    c2[1].bias is None and len(sk) == 2 and isinstance(sk[0], Blur) and isinstance(sk[1], EqualConv2d) and
+                    sk[1].weight.shape[-1] == 1 and sk[1].stride == 2 and sk[1].padding == 0 and sk[1].bias is None and
+                    tuple(sk[0].kernel.shape) == (4, 4))
+        return (len(c2) == 2 and isinstance(c2[0], EqualConv2d) and isinstance(c2[1], FusedLeakyReLU) and
+                c2[0].bias is None and c2[0].weight.shape[-1] == 3 and c2[0].stride == 1 and c2[0].padding == 1 and
+                len(sk) == 1 and isinstance(sk[0], EqualConv2d) and sk[0].bias is None and sk[0].stride == 1)
+
+    def _forward_folded(self, input):
+        """(conv2(conv1(x)) + skip(x)) / sqrt(2) (networks.py:388-393) with the 1 / sqrt(2) folded into the two branches -
+        conv2's activation gain (sqrt(2) * 1 / sqrt(2)) and the skip convolution's equalised-lr weight scale - so that the
+        merge is a plain sum and its backward hands the incoming gradient to both branches unscaled (one full-size
+        multiply less per block); with down-sampling the skip branch's blur is a tap node (blur_down_tap) whose backward
+        ADDS its adjoint into the gradient conv1 produced for the shared input (one full-size add less per block)."""
+        s = 1.0 / math.sqrt(2)
+        c2, sk = self.conv2, self.skip
+        if isinstance(c2[0], Blur):
+            x, xs = blur_down_tap(input, sk[0].kernel, sk[0].pad)
+            skip = conv_mfma.conv2d(xs, sk[1].weight, bias=None, stride=1, padding=0, weight_scale=sk[1].scale * s)
+            y = c2[0](self.conv1(x))
+            y = conv_mfma.conv2d(y, c2[1].weight, bias=None, stride=2, padding=0, weight_scale=c2[1].scale)
+            y = fused_leaky_relu(y, c2[2].bias, c2[2].negative_slope, c2[2].scale * s)
+        else:
+            skip = conv_mfma.conv2d(input, sk[0].weight, bias=None, stride=1, padding=sk[0].padding,
+                                    weight_scale=sk[0].scale * s)
+            y = conv_mfma.conv3x3_bias_act(self.conv1(input), c2[0].weight, c2[1].bias, c2[1].negative_slope,
+                                           c2[1].scale * s, weight_scale=c2[0].scale)
+        return conv_mfma.add_scale(y, skip, 1.0)
 
 
 CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}

@@ -243,6 +243,17 @@ int gg_mipmap_warp_bwd_f32(float* grad_grid, float* grad_pyr0, float* grad_pyr_r
  * (tests/test_gpu_stn_decisions.py). */
 
 /* ------------------------------------------------------------------------------------------
+ * a7  SimilarityHead.make_affine_matrix (warping_heads.py:36-56): params (N, 4*heads) = the regressed
+ *     [rot | log-scale | shift_x | shift_y] blocks of `heads` columns each ->
+ *     matrix (N, heads, 2, 3) = [[s cos r, -s sin r, tx], [s sin r, s cos r, ty]], r = pi * tanh(rot), s = exp(log-scale)
+ *     (the reference: tanh, mul, exp, cos, sin, 4 products, neg, stack = 11 launches on (N, heads) tensors; ~25 in
+ *     its backward).  bwd: grad_params (N, 4*heads) overwritten.
+ * ------------------------------------------------------------------------------------------ */
+int gg_similarity_matrix_f32(float* matrix, const float* params, int n, int heads, void* stream);
+int gg_similarity_matrix_bwd_f32(float* grad_params, const float* grad_matrix, const float* params, int n, int heads,
+                                 void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * a7  F.affine_grid(theta (N,2,3), (N,C,ho,wo), align_corners=False) (warping_heads.py:135,176)
  *     grid[n,i,j] = theta[n] . [x_j, y_i, 1],  x_j = linspace(-1,1,wo)[j]*(wo-1)/wo.
  * bwd: grad_theta (N,2,3) overwritten.
@@ -427,6 +438,16 @@ int gg_conv3x3_masked_dgrad_bits_f32(float* y, const float* x, const unsigned in
                                      const unsigned short* wsplit, long long limb_stride, int limbs,
                                      const float* in_scale, const float* out_scale, int batch, int cin, int cout, int h,
                                      int w, void* stream);
+/* Round 6 (second half): the perceptual trunk's RGB stem (lpips_backbones.py:109: Conv2d(3, 64, 3, padding=1) + ReLU).
+ * Forward: gg_modconv3x3_act_bits_f32 with limbs = 0 and cin <= 4 runs a streaming few-input-channel kernel that applies
+ * bias + (leaky) ReLU in registers and writes the sign plane (gg_last_sign_bits_written() == 1).
+ * Backward: dx (N, cout <= 4, H, W) = conv3x3(dy * lrelu'(y), wmat) with lrelu'(y) read from that plane (words per pixel =
+ * cin / 32; cin = this launch's reduction channels = the layer's output channels, a multiple of 32) - instead of
+ * threshold_backward / gg_fused_lrelu_bwd_f32 over the 134 MB gradient followed by the few-output-channel convolution.
+ * wmat: the fp32 GEMM layout of the data-gradient convolution (gg_conv_pack_weight_f32, transpose_io = flip = 1).
+ * GG_NOT_SERVED (nothing launched) for shapes the few-output-channel kernel does not take. */
+int gg_conv3x3_fewout_masked_bits_f32(float* dx, const float* dy, const unsigned int* mask_bits, float alpha, float gain,
+                                      const float* wmat, int batch, int cin, int cout, int h, int w, void* stream);
 /* Weight gradient: dw (groups, cout_g, cin_g, k, k) torch layout, overwritten.  (All weight-gradient entry points:
  * the K-splits' partial tiles go to the library's scratch and are added in split order.)
  *   dw[g,co,ci,ky,kx] = sum_{n,oy,ox} dy[n,g*cout_g+co,oy,ox] * x[n,g*cin_g+ci, oy*stride+ky-pad, ox*stride+kx-pad] */

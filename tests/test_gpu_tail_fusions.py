@@ -1,0 +1,250 @@
+"""Round 6 (second half): launches removed from the step's batch-independent tail.  Every fused route is held to the
+route it replaces (the reference's operator order, still reachable through GG_DISABLE switches) on the same inputs:
+forward, every parameter gradient and the input gradient.
+
+  * ResBlock (models/stylegan2/networks.py:375-393 of the reference): 1 / sqrt(2) folded into the two branches, the skip
+    branch's decimating blur as a tap node whose backward adds into conv1's data gradient.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def cm():
+    from gangealing_amd.op import conv_mfma
+    old, dis = conv_mfma.PRECISION, conv_mfma.DISABLED
+    yield conv_mfma
+    conv_mfma.set_precision(old)
+    conv_mfma.DISABLED = dis
+
+
+def _grads(block, x, g, cm, disabled):
+    cm.DISABLED = frozenset(disabled)
+    for p in block.parameters():
+        p.grad = None
+    xx = x.clone().requires_grad_(True)
+    y = block(xx)
+    y.backward(g)
+    return y.detach(), xx.grad.detach(), {n: p.grad.detach().clone() for n, p in block.named_parameters()}
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+@pytest.mark.parametrize('cin,cout,res,down', [(64, 128, 64, True), (128, 512, 32, True), (512, 512, 16, True),
+                                               (512, 512, 8, True), (512, 512, 16, False), (64, 64, 33, True)])
+def test_resblock_folded_equals_reference_order(cm, precision, cin, cout, res, down):
+    """The folded block against the literal (conv2(conv1(x)) + skip(x)) / sqrt(2) on the same kernels: the scale moves
+    from after the sum into the two addends, so the results agree to rounding (a few ulp of the block's output), and so
+    do the gradients of every parameter and of the input."""
+    from gangealing_amd.stylegan2.networks import ResBlock
+    cm.set_precision(precision)
+    torch.manual_seed(cin + res)
+    dev = torch.device('cuda', 0)
+    block = ResBlock(cin, cout, downsample=down).to(dev)
+    with torch.no_grad():
+        for n, p in block.named_parameters():
+            if n.endswith('bias'):
+                p.normal_(0.0, 0.2)
+    n = 4
+    x = torch.randn(n, cin, res, res, device=dev)
+    out_res = block(x[:1]).shape[-1]
+    g = torch.randn(n, cout, out_res, out_res, device=dev)
+    base = set(cm.DISABLED)
+    y0, dx0, gp0 = _grads(block, x, g, cm, base | {'resblock_fold'})
+    y1, dx1, gp1 = _grads(block, x, g, cm, base - {'resblock_fold'})
+    assert y0.shape == y1.shape
+
+    def close(a, b, tol):
+        scale = float(b.abs().max()) + 1e-30
+        return float((a - b).abs().max()) <= tol * scale
+
+    assert close(y1, y0, 2e-6), float((y1 - y0).abs().max())
+    assert close(dx1, dx0, 2e-5 if precision != 'fp32' else 4e-6), float((dx1 - dx0).abs().max())
+    for name in gp0:
+        assert close(gp1[name], gp0[name], 3e-5), (name, float((gp1[name] - gp0[name]).abs().max()))
+
+
+def test_resblock_folded_route_is_taken_and_saves_launches(cm):
+    """The folded block issues no separate scale pass in its backward: the merge's gradient is handed on as is, and the
+    skip branch's adjoint blur accumulates into conv1's data gradient (gg_upfirdn2d_add_f32 instead of gg_upfirdn2d_f32 +
+    an ATen add)."""
+    from gangealing_amd import _lib
+    from gangealing_amd.stylegan2.networks import ResBlock
+    cm.set_precision('fp16x3')
+    dev = torch.device('cuda', 0)
+    block = ResBlock(128, 512).to(dev)
+    x = torch.randn(2, 128, 32, 32, device=dev, requires_grad=True)
+    seen = []
+    orig = _lib.call
+
+    def spy(name, *a, **k):
+        seen.append(name)
+        return orig(name, *a, **k)
+    _lib.call = spy
+    try:
+        block(x).sum().backward()
+    finally:
+        _lib.call = orig
+    assert 'gg_upfirdn2d_add_f32' in seen
+    assert seen.count('gg_add_scale_f32') == 1
+
+
+def test_blur_down_tap_matches_two_nodes():
+    """(x, blur_down(x)) as one node: same forward as upfirdn2d(down=2), and the backward equals the sum autograd forms
+    from the two separate paths - bitwise when only one path carries a gradient, to 1 ulp-of-sum otherwise."""
+    from gangealing_amd.op.upfirdn2d import blur_down_tap, upfirdn2d
+    from gangealing_amd.stylegan2.networks import make_kernel
+    dev = torch.device('cuda', 0)
+    k = make_kernel([1, 3, 3, 1]).to(dev)
+    torch.manual_seed(3)
+    for shape, pad in (((3, 8, 32, 32), (1, 1)), ((2, 5, 33, 33), (1, 1)), ((2, 4, 16, 16), (2, 1))):
+        x = torch.randn(*shape, device=dev)
+        xa = x.clone().requires_grad_(True)
+        xp, xs = blur_down_tap(xa, k, pad)
+        ref = upfirdn2d(x, k, down=2, pad=pad)
+        assert torch.equal(xs, ref) and torch.equal(xp, x)
+        g1, g2 = torch.randn_like(xp), torch.randn_like(xs)
+        (xp * g1).sum().add((xs * g2).sum()).backward()
+        xb = x.clone().requires_grad_(True)
+        (xb * g1).sum().add((upfirdn2d(xb, k, down=2, pad=pad) * g2).sum()).backward()
+        assert float((xa.grad - xb.grad).abs().max()) <= 4e-7 * float(xb.grad.abs().max())
+        # only the decimated path
+        xc = x.clone().requires_grad_(True)
+        (blur_down_tap(xc, k, pad)[1] * g2).sum().backward()
+        xd = x.clone().requires_grad_(True)
+        (upfirdn2d(xd, k, down=2, pad=pad) * g2).sum().backward()
+        assert torch.equal(xc.grad, xd.grad)
+
+
+@pytest.mark.parametrize('n,heads', [(16, 1), (5, 4), (1, 1), (300, 3)])
+def test_similarity_matrix_kernel_vs_reference_chain(n, heads):
+    """gg_similarity_matrix_f32 against SimilarityHead.make_affine_matrix evaluated by ATen on the same device (the
+    reference's 11-launch chain): the same operations in the same order - equal to the last bit, or within 1 ulp where the
+    two builds' libm differ; the backward against autograd through that chain."""
+    from gangealing_amd.spatial_transformers.flow_ops import similarity_matrix
+    from gangealing_amd.spatial_transformers.warping_heads import SimilarityHead
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(n + heads)
+    p = (torch.randn(n, 4 * heads, device=dev) * 1.5)
+    pa = p.clone().requires_grad_(True)
+    pb = p.clone().requires_grad_(True)
+    ma = similarity_matrix(pa, heads)
+    mb = SimilarityHead.make_affine_matrix(*torch.split(pb, heads, dim=1))
+    assert ma.shape == mb.shape == (n, heads, 2, 3)
+    ulp = torch.finfo(torch.float32).eps * mb.abs().clamp_min(1e-30)
+    assert bool(((ma - mb).abs() <= 2 * ulp).all()), float((ma - mb).abs().max())
+    g = torch.randn_like(mb)
+    ma.backward(g)
+    mb.backward(g)
+    assert float((pa.grad - pb.grad).abs().max()) <= 2e-6 * float(pb.grad.abs().max())
+
+
+def test_similarity_head_uses_the_kernel(cm):
+    from gangealing_amd import _lib
+    from gangealing_amd.spatial_transformers.warping_heads import SimilarityHead
+    dev = torch.device('cuda', 0)
+    head = SimilarityHead(512, num_heads=1).to(dev)
+    with torch.no_grad():
+        head.linear.weight.normal_(0, 0.01)
+    img = torch.rand(2, 3, 32, 32, device=dev)
+    feats = torch.randn(2, 512, device=dev)
+    seen, orig = [], _lib.call
+
+    def spy(name, *a, **k):
+        seen.append(name)
+        return orig(name, *a, **k)
+    _lib.call = spy
+    try:
+        out, grid, m, _ = head(img, feats)
+    finally:
+        _lib.call = orig
+    assert 'gg_similarity_matrix_f32' in seen
+    cm.DISABLED = frozenset(cm.DISABLED | {'similarity_matrix'})
+    out2, grid2, m2, _ = head(img, feats)
+    assert float((m.reshape(-1) - m2.reshape(-1)).abs().max()) <= 3e-7 * float(m2.abs().max())
+    assert float((out - out2).abs().max()) <= 1e-5
+
+
+def _unpack_bits(bits, cout):
+    """(N, HW, cout / 32) int32 sign plane -> (N, cout, HW) bool."""
+    n, hw, words = bits.shape
+    b = bits.to(torch.int64) & 0xFFFFFFFF
+    sh = torch.arange(32, device=bits.device, dtype=torch.int64)
+    u = ((b.unsqueeze(-1) >> sh) & 1).reshape(n, hw, words * 32)[..., :cout]
+    return u.permute(0, 2, 1).bool()
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+@pytest.mark.parametrize('n,cin,cout,h,w,alpha,gain', [(4, 3, 64, 128, 128, 0.0, 1.0), (2, 3, 64, 36, 40, 0.2, 2 ** 0.5),
+                                                       (3, 4, 32, 64, 64, 0.0, 1.0), (32, 3, 64, 128, 128, 0.0, 1.0),
+                                                       (2, 1, 96, 128, 128, 0.2, 1.0)])
+def test_few_input_channel_stem_forward_backward(cm, precision, n, cin, cout, h, w, alpha, gain):
+    """The perceptual trunk's RGB stem (Conv2d(3, 64, 3, padding=1) + ReLU, lpips_backbones.py:109) on the streaming
+    few-input-channel kernel: output against float64 conv2d + bias + (leaky) ReLU, the sign plane equal to pack(y > 0) bit
+    for bit, and the input gradient through the sign-plane-masked few-output-channel kernel against float64 autograd."""
+    import torch.nn.functional as F
+    from gangealing_amd import _lib
+    cm.set_precision(precision)
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(n * 7 + cin + h)
+    x = torch.randn(n, cin, h, w, generator=g).to(dev)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).to(dev)
+    b = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    dy = torch.randn(n, cout, h, w, generator=g).to(dev)
+    seen, orig = [], _lib.call
+
+    def spy(name, *a, **k):
+        rc = orig(name, *a, **k)
+        seen.append((name, cm.last_conv_kernel()))
+        return rc
+    xa = x.clone().requires_grad_(True)
+    _lib.call = spy
+    try:
+        y = cm.conv3x3_bias_act(xa, wt, b, alpha, gain)
+        y.backward(dy)
+    finally:
+        _lib.call = orig
+    served = n * h * w >= 65536
+    kernels = [k for _, k in seen]
+    if served:
+        assert any(k.startswith('conv3x3_fewin') for k in kernels), kernels
+        assert any(name == 'gg_conv3x3_fewout_masked_bits_f32' for name, _ in seen), seen
+    x64 = x.double().requires_grad_(True)
+    z = F.conv2d(x64, wt.double(), b.double(), padding=1)
+    y64 = F.leaky_relu(z, alpha) * gain
+    y64.backward(dy.double())
+    assert float((y.double() - y64).abs().max()) <= 2e-6 * float(y64.abs().max())
+    # gradient: a unit whose pre-activation lies within rounding distance of 0 may take the other branch (a handful among
+    # the 33.5 M units of the largest case) and moves single entries by O(|dy| |w|): relative L2 is the metric, single
+    # entries are bounded loosely
+    d = xa.grad.double() - x64.grad
+    assert float(d.norm()) <= 2e-5 * float(x64.grad.norm()), float(d.norm()) / float(x64.grad.norm())
+    assert float(d.abs().max()) <= 2e-2 * float(x64.grad.abs().max())
+
+
+def test_few_input_channel_stem_sign_plane(cm):
+    from gangealing_amd import _lib
+    cm.set_precision('fp16x3')
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(5)
+    n, cin, cout, h, w = 8, 3, 64, 128, 128
+    x = torch.randn(n, cin, h, w, device=dev)
+    wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.3
+    b = torch.randn(cout, device=dev) * 0.1
+    pw = cm.PackedWeight(wt, 1, cout, cin, 3, 0, 0, 1.0)
+    y, bits = cm.conv_forward(x, pw, n, 1, cin, cout, 3, 1, 1, 0, act=(None, None, b, 0.0, 1.0), want_sign_bits=True)
+    assert bits is not None and cm.last_conv_kernel().startswith('conv3x3_fewin')
+    assert torch.equal(_unpack_bits(bits, cout), (y > 0).reshape(n, cout, h * w))
+    # the masked few-output-channel gradient == the unmasked kernel on the explicitly masked gradient, bit for bit
+    dy = torch.randn(n, cout, h, w, device=dev)
+    wb = cm.PackedWeight(wt, 1, cin, cout, 3, 1, 1, 1.0)
+    dx = torch.empty(n, cin, h, w, device=dev)
+    _lib.call('gg_conv3x3_fewout_masked_bits_f32', dx, dy, bits, 0.2, 1.5, wb.fp32(), n, cout, cin, h, w)
+    neg = torch.tensor(0.2, device=dev) * torch.tensor(1.5, device=dev)          # float32 product, as the kernel forms it
+    masked = dy * torch.where(y > 0, torch.tensor(1.5, device=dev), neg)
+    ref = cm.conv_forward(masked, wb, n, 1, cout, cin, 3, 1, 1, 0, grad=True)
+    assert cm.last_conv_kernel().startswith('conv3x3_fewout')
+    assert torch.equal(dx, ref)
