@@ -30,6 +30,7 @@ _PROTOS = {
     'gg_upfirdn2d_f64': 'pppiiiiiiiiiiiiis',
     'gg_upfirdn2d_f16': 'pppiiiiiiiiiiiiis',
     'gg_blur4_fused_f32': 'pppiiiiiiiippppffs',
+    'gg_blur4_fused_bits_f32': 'pppiiiiiiiippppffs',
     'gg_splat_forward_f32': 'pppppiiiiis',
     'gg_splat2d_f32': 'ppppppiiiiiis',
     'gg_mip_downsample2x_f32': 'ppiiis',
@@ -55,6 +56,8 @@ _PROTOS = {
     'gg_conv3x3_masked_dgrad_f32': 'pppffpqippiiiiis',
     'gg_conv_pack_weights_many': 'pis',
     'gg_conv2d_split_f32': 'pppqipppiiiiiiiiiiiis',
+    'gg_conv2d_split_act_f32': 'pppqipppffiiiiiiiiiiiis',
+    'gg_conv1x1_split_residual_f32': 'pppqippppiiiiiiis',
     'gg_modconv3x3_act_f32': 'ppppqipppppffiiiiis',
     'gg_modconv3x3_act_bits_f32': 'ppppqipppppffiiiiips',
     'gg_conv3x3_masked_dgrad_bits_f32': 'pppffpqippiiiiis',
@@ -94,7 +97,8 @@ class HipLibraryError(RuntimeError):
 
 def exported_symbols():
     return ['gg_abi_version', 'gg_last_error', 'gg_build_arch', 'gg_scratch_release', 'gg_set_allocator',
-            'gg_last_conv_kernel', 'gg_set_tuning', 'gg_last_sign_bits_written', 'gg_last_amax_written'] + sorted(_PROTOS)
+            'gg_last_conv_kernel', 'gg_set_tuning', 'gg_last_sign_bits_written', 'gg_last_amax_written',
+            'gg_blur4_bits_words'] + sorted(_PROTOS)
 
 
 def load():

@@ -71,6 +71,10 @@ struct ConvArgs {
   // forward launches with the fused activation: amax_out[image] receives max |stored output| (atomic max on the bit
   // pattern of a non-negative float: order-independent, so reproducible) - what the limb-writing pass takes its exponent from
   float* amax_out;
+  // round 6 (second half): a tensor of the OUTPUT's shape added after scale / bias (/ activation) - ResBlock's residual
+  // merge inside the skip branch's 1x1 convolution (networks.py:392-393).  Carried by the generic tiles' epilogues and by
+  // the split-K reduce pass only (1x1 convolutions always take those).
+  const float* residual;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

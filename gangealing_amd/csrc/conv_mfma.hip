@@ -228,6 +228,7 @@ __global__ __launch_bounds__(WCO * WPIX * 64) void conv_igemm_kernel(const ConvA
     float* yp = ybase + (size_t)ochan0 * ohw + (size_t)oy * a.ow + ox;
     const float* osc = (a.out_scale && !partial) ? a.out_scale + ochan0 : nullptr;
     const float* bia = (a.bias && !partial) ? a.bias + g * a.cout_g : nullptr;
+    const float* res = (a.residual && !partial) ? a.residual + (size_t)ochan0 * ohw + (size_t)oy * a.ow + ox : nullptr;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(WCO * WPIX * 64) void conv_igemm_kernel(const ConvA
         float v = acc[i][j][r];
         if (osc) v *= osc[co];
         if (bia) v += bia[co];
+        if (res) v += res[(size_t)co * ohw];
         yp[(size_t)co * ohw] = v;
       }
     }
@@ -489,6 +491,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
     float* yp = ybase + (size_t)ochan0 * ohw + (size_t)oy * a.ow + ox;
     const float* osc = (a.out_scale && !partial) ? a.out_scale + ochan0 : nullptr;
     const float* bia = (a.bias && !partial) ? a.bias + g * a.cout_g : nullptr;
+    const float* res = (a.residual && !partial) ? a.residual + (size_t)ochan0 * ohw + (size_t)oy * a.ow + ox : nullptr;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -499,6 +502,7 @@ __global__ __launch_bounds__(TPIX * 2, 2) void conv_split_kernel(const ConvArgs 
         if (!partial) v *= a.acc_scale;
         if (osc) v *= osc[co];
         if (bia) v += bia[co];
+        if (res) v += res[(size_t)co * ohw];
         yp[(size_t)co * ohw] = v;
       }
     }
@@ -2480,6 +2484,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ 
         v[q] = (t > 0.f ? t : t * a.act_alpha) * a.act_gain;
       }
     }
+    if (a.residual) {
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) v[q] += a.residual[e + q];
+    }
     if (VEC == 4) *reinterpret_cast<float4*>(y + e) = make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]);
     else y[e] = v[0];
   }
@@ -3392,12 +3400,9 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     if (tpix == 256 && !s2_patch_serves(a, 256)) tpix = 128;
     if (s2_patch_serves(a, tpix)) return launch_conv_s2_patch(a, 2, tpix, st);
   }
-  if (a.act) {            // no other kernel carries the activation in its epilogue
-    ConvArgs plain = a;
-    plain.act = 0;
-    const int rc = conv_dispatch<KS>(plain, stride, pad, mode, st, limbs);
-    return rc ? rc : post_activation(a, st);
-  }
+  // no other kernel carries the activation in its epilogue: the split-K reduce pass applies it when the launch has one,
+  // a separate in-place pass otherwise (act_later)
+  const bool act_later = a.act != 0;
   // tile selector.  (Measured on the 128->128 @256^2 layer: an 8-wave 128x128 variant, a 128co x 256pix
   // variant with 8 accumulators per wave and BK = 32 are all within -20..+1 % of this 4-wave tile.)
   const int narrow = a.cout_g <= 32 ? 1 : (a.cout_g <= 64 ? 2 : 0);
@@ -3456,7 +3461,8 @@ int conv_dispatch(ConvArgs a, int stride, int pad, int mode, hipStream_t st, int
     else rc = (mode == 0) ? launch_conv<KS, 0>(plans[i], narrow, st) : launch_conv<KS, 1>(plans[i], narrow, st);
     if (rc) return rc;
   }
-  return max_split > 1 ? splitk_reduce(a, max_split, st) : 0;
+  if (max_split > 1) return splitk_reduce(a, max_split, st);       // + out_scale / bias / activation / residual
+  return act_later ? post_activation(a, st) : 0;
 }
 
 }  // namespace
@@ -3503,12 +3509,15 @@ struct BitArgs {
   const int* xlimb_e = nullptr;
 };
 
+constexpr int kNotFusedEarly = GG_NOT_SERVED;
+
 struct ActArgs {
   int on = 0;
   const float* noise = nullptr;
   const float* noise_w = nullptr;
   const float* bias = nullptr;
   float alpha = 0.f, gain = 1.f;
+  const float* residual = nullptr;     // ConvArgs::residual (independent of `on`)
 };
 
 int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned short* wsplit, long long wsplit_stride,
@@ -3557,6 +3566,9 @@ int conv2d_entry(float* y, const float* x, const float* wmat, const unsigned sho
   a.sign_bits = (act.on && groups == 1 && cout_g % 32 == 0) ? bits.sign : nullptr;
   a.bit_words = mask.bits ? cin_g / 32 : cout_g / 32;
   a.act = act.on; a.act_noise = act.noise; a.act_noise_w = act.noise_w; a.act_bias = act.bias;
+  a.residual = act.residual;
+  // only the generic tiles (and the split-K reduce) add a residual: 1x1 split-precision launches always run on those
+  if (a.residual && !(ksize == 1 && limbs && mode == 0 && !act.on)) return kNotFusedEarly;
   a.act_alpha = act.alpha; a.act_gain = act.gain;
   a.batch = batch; a.groups = groups; a.cin_g = cin_g; a.cout_g = cout_g; a.h = h; a.w = w;
   if (mode == 0) {
@@ -3595,6 +3607,37 @@ extern "C" int gg_conv2d_split_f32(float* y, const float* x, const unsigned shor
                                    int pad, int mode, int out_h, int out_w, void* stream) {
   return conv2d_entry(y, x, nullptr, wsplit, limb_stride, limbs, in_scale, out_scale, bias, batch, groups, cin_g,
                       cout_g, h, w, ksize, stride, pad, mode, out_h, out_w, stream);
+}
+
+// gg_conv2d_split_f32 + bias + leaky ReLU for ANY served geometry (ResBlock's blur -> 3x3 / stride-2 convolution ->
+// FusedLeakyReLU, networks.py:375-386): the stride-2 patch tile carries the activation in its epilogue, split-K launches in
+// their reduce pass, everything else in an in-place pass of the library's own (no separate entry-point call).
+extern "C" int gg_conv2d_split_act_f32(float* y, const float* x, const unsigned short* wsplit, long long limb_stride,
+                                       int limbs, const float* in_scale, const float* out_scale, const float* act_bias,
+                                       float alpha, float gain, int batch, int groups, int cin_g, int cout_g, int h,
+                                       int w, int ksize, int stride, int pad, int mode, int out_h, int out_w,
+                                       void* stream) {
+  if (!wsplit || !(limbs & 15)) return gg::fail(-2, "conv2d_split_act: split weights missing");
+  const int oh = mode == 0 ? (h + 2 * pad - ksize) / (stride > 0 ? stride : 1) + 1 : out_h;
+  const int ow = mode == 0 ? (w + 2 * pad - ksize) / (stride > 0 ? stride : 1) + 1 : out_w;
+  if (((long long)oh * ow) % 4 != 0 || (reinterpret_cast<uintptr_t>(y) & 15)) return kNotFusedEarly;
+  ActArgs act;
+  act.on = 1; act.bias = act_bias; act.alpha = alpha; act.gain = gain;
+  return conv2d_entry(y, x, nullptr, wsplit, limb_stride, limbs, in_scale, out_scale, nullptr, batch, groups, cin_g,
+                      cout_g, h, w, ksize, stride, pad, mode, out_h, out_w, stream, act);
+}
+
+// gg_conv2d_split_f32 of a 1x1 convolution + residual: y = conv1x1(x) * out_scale + bias + residual, residual of y's
+// shape (ResBlock's skip branch with the merge inside, networks.py:386-393).  GG_NOT_SERVED for other kernel sizes.
+extern "C" int gg_conv1x1_split_residual_f32(float* y, const float* x, const unsigned short* wsplit,
+                                             long long limb_stride, int limbs, const float* in_scale,
+                                             const float* out_scale, const float* bias, const float* residual, int batch,
+                                             int groups, int cin_g, int cout_g, int h, int w, int stride, void* stream) {
+  if (!wsplit || !(limbs & 15) || !residual) return gg::fail(-2, "conv1x1_split_residual: null pointer");
+  ActArgs act;
+  act.residual = residual;
+  return conv2d_entry(y, x, nullptr, wsplit, limb_stride, limbs, in_scale, out_scale, bias, batch, groups, cin_g, cout_g,
+                      h, w, 1, stride, 0, 0, 0, 0, stream, act);
 }
 
 extern "C" int gg_modconv3x3_act_f32(float* y, const float* x, const float* wmat, const unsigned short* wsplit,

@@ -35,6 +35,14 @@ struct BlurFuse {
   const float* ref;        // same shape as `in`
   float alpha, gain;
   int channels;
+  // round 6: the activation's sign as ONE BIT per element in the stream kernel's own tiling of the FORWARD output
+  // (strips of SW_OUT = 61 columns x chunks of SROWS = 16 rows): uint64 [plane][chunk_y][strip_x][row in chunk], bit j =
+  // column strip_x * 61 + j.  A wave of the forward owns one (chunk, strip) cell and writes its 16 words with one
+  // 128-byte store (no atomics, nothing to clear); a lane of the adjoint (PRO = 2) reads the 32-bit half that holds its
+  // column - a 64-lane row load touches <= 24 bytes instead of 256.  bit_strips / bit_chunks: the forward's tiling.
+  unsigned long long* sign_bits = nullptr;
+  const unsigned* ref_bits = nullptr;
+  int bit_strips = 0, bit_chunks = 0;
 };
 
 template <bool EPI, bool PRO>
@@ -182,7 +190,8 @@ __device__ __forceinline__ float wave_shl1(float v) {     // lane i <- lane i+1;
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
-template <bool EPI, bool PRO>
+// PRO: 0 = plain input; 1 = input * lrelu'(ref) from the saved fp32 output; 2 = the same factor from the sign plane
+template <bool EPI, int PRO>
 __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
     float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ kernel,
     int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0,
@@ -220,7 +229,15 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
   const unsigned out_off = (lane < SW_OUT && ox < out_w) ? (unsigned)ox * 4u : gg::kOobOffset;
   const int in_bytes = in_h * in_w * 4, out_bytes = out_h * out_w * 4;
   const __amdgpu_buffer_rsrc_t src = gg::uniform_rsrc(in + (size_t)plane * in_h * in_w, in_bytes);
-  const __amdgpu_buffer_rsrc_t rsrc = gg::uniform_rsrc(PRO ? f.ref + (size_t)plane * in_h * in_w : in, in_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc = gg::uniform_rsrc(PRO == 1 ? f.ref + (size_t)plane * in_h * in_w : in, in_bytes);
+  // PRO == 2: the 32-bit half of the forward's (chunk, strip) word that holds this lane's column (neighbouring lanes share it)
+  const int bits_bytes = f.bit_chunks * f.bit_strips * SROWS * 8;
+  const __amdgpu_buffer_rsrc_t brsrc = gg::uniform_rsrc(
+      PRO == 2 ? reinterpret_cast<const float*>(f.ref_bits + (size_t)plane * (bits_bytes / 4)) : in,
+      PRO == 2 ? bits_bytes : in_bytes);
+  const int bstrip = ix >= 0 ? ix / SW_OUT : 0, bcol = ix - bstrip * SW_OUT;
+  const unsigned bit_off = (ix >= 0 && ix < in_w) ? (unsigned)(bstrip * SROWS * 8 + (bcol >> 5) * 4) : gg::kOobOffset;
+  const int bit_sh = bcol & 31;
   const __amdgpu_buffer_rsrc_t dst = gg::uniform_rsrc(out + (size_t)plane * out_h * out_w, out_bytes);
   float nw = 0.f, ab = 0.f;
   const int n_img = EPI ? (int)(plane / f.channels) : 0;
@@ -234,7 +251,14 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
     const unsigned vo = row_ok ? in_off : gg::kOobOffset;
     const int so = row_ok ? iy * in_w * 4 : 0;
     float v = gg::buffer_load_f32(src, vo, so);
-    if (PRO) v *= (gg::buffer_load_f32(rsrc, vo, so) > 0.f) ? f.gain : f.gain * f.alpha;
+    if (PRO == 1) v *= (gg::buffer_load_f32(rsrc, vo, so) > 0.f) ? f.gain : f.gain * f.alpha;
+    if (PRO == 2) {
+      // (iy >> 4, iy & 15: chunk and row of the forward's tiling; wave-uniform -> the scalar offset)
+      const unsigned wd = __builtin_bit_cast(
+          unsigned, gg::buffer_load_f32(brsrc, row_ok ? bit_off : gg::kOobOffset,
+                                        row_ok ? ((iy >> 4) * f.bit_strips * SROWS + (iy & 15)) * 8 : 0));
+      v *= ((wd >> bit_sh) & 1u) ? f.gain : f.gain * f.alpha;
+    }
     return v;
   };
   // noise of output row oy at this lane's column (EPI); loaded with the rows, BEFORE the strip's first store: VMEM loads
@@ -244,7 +268,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
     const bool row_ok = oy < out_h;
     return gg::buffer_load_f32(nz, row_ok ? out_off : gg::kOobOffset, row_ok ? oy * out_w * 4 : 0);
   };
-  auto finish = [&](float acc, int oy, float noise) {
+  unsigned long long my_bits = 0ull;                       // EPI + sign plane: lane r keeps row r's word of this cell
+  auto finish = [&](float acc, int oy, float noise, int u) {
     const bool row_ok = oy < out_h;
     const unsigned vo = row_ok ? out_off : gg::kOobOffset;
     const int so = row_ok ? oy * out_w * 4 : 0;
@@ -253,11 +278,21 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
       acc = (t > 0.f ? t : t * f.alpha) * f.gain;
     }
     gg::buffer_store_f32(acc, dst, vo, so);
+    if (EPI && f.sign_bits) {                               // (wave-uniform) exactly the test the backward applies to `out`
+      const unsigned long long m = __ballot(row_ok && lane < SW_OUT && ox < out_w && acc > 0.f);
+      if (lane == u) my_bits = m;
+    }
+  };
+  auto flush_bits = [&]() {
+    if (EPI && f.sign_bits && lane < SROWS)
+      f.sign_bits[(((size_t)plane * f.bit_chunks + cy) * f.bit_strips + sx) * SROWS + lane] = my_bits;
   };
   if (sep) {
     auto hpass = [&](float v) -> float {
       const float s1 = wave_shl1(v), s2 = wave_shl1(s1), s3 = wave_shl1(s2);
-      return v * kb[0] + s1 * kb[1] + s2 * kb[2] + s3 * kb[3];
+      // explicit FMA chains (here and in the vertical pass): every instantiation of this kernel rounds the same way,
+      // whatever the compiler's contraction choices around the masked / plain loads (route-equivalence tests are bitwise)
+      return fmaf(s3, kb[3], fmaf(s2, kb[2], fmaf(s1, kb[1], v * kb[0])));
     };
     // every load of the strip (3 + SROWS input rows, SROWS noise rows) is issued before its first store
     const float r0 = fetch(iy0), r1 = fetch(iy0 + 1), r2 = fetch(iy0 + 2);
@@ -270,9 +305,10 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
 #pragma unroll
     for (int u = 0; u < SROWS; ++u) {
       const float h3 = hpass(nv[u]);
-      finish(h0 * ka[0] + h1 * ka[1] + h2 * ka[2] + h3 * ka[3], oy0 + u, nzv[u]);
+      finish(fmaf(h3, ka[3], fmaf(h2, ka[2], fmaf(h1, ka[1], h0 * ka[0]))), oy0 + u, nzv[u], u);
       h0 = h1; h1 = h2; h2 = h3;
     }
+    flush_bits();
     return;
   }
   // general taps: window[row][shift]
@@ -291,12 +327,13 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc += w[r][c] * kf[r * 4 + c];
-    finish(acc, oy0 + rr, EPI ? noise_at(oy0 + rr) : 0.f);
+    finish(acc, oy0 + rr, EPI ? noise_at(oy0 + rr) : 0.f, rr);
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) w[r][c] = w[r + 1][c];
   }
+  flush_bits();
 }
 
 // A/B switch for measurements: GG_BLUR_TILE=1 selects the round-1 LDS tile kernel.
@@ -305,14 +342,14 @@ inline bool blur_use_tile_kernel() {
   return v;
 }
 
-template <bool EPI, bool PRO>
+template <bool EPI, int PRO>
 int launch_blur4(float* out, const float* in, const float* kernel, long long planes, int in_h, int in_w, int out_h,
                  int out_w, int pad_x0, int pad_y0, const BlurFuse& f, hipStream_t st) {
-  if (blur_use_tile_kernel()) {
+  if (blur_use_tile_kernel() && PRO != 2 && !f.sign_bits) {
     const int tiles_x = (out_w + TILE - 1) / TILE, tiles_y = (out_h + TILE - 1) / TILE;
     const long long ntiles = (long long)tiles_x * tiles_y * planes;
     if (ntiles >= (1LL << 31)) return gg::fail(-2, "blur4: too many tiles");
-    upfirdn2d_blur4_tile<EPI, PRO><<<(unsigned)ntiles, 256, 0, st>>>(out, in, kernel, (int)planes, in_h, in_w, out_h,
+    upfirdn2d_blur4_tile<EPI, PRO == 1><<<(unsigned)ntiles, 256, 0, st>>>(out, in, kernel, (int)planes, in_h, in_w, out_h,
                                                                     out_w, pad_x0, pad_y0, tiles_x, tiles_y,
                                                                     (unsigned)ntiles, f);
     return gg::launch_status("upfirdn2d_blur4_tile");
@@ -614,9 +651,47 @@ extern "C" int gg_blur4_fused_f32(float* out, const float* in, const float* kern
   f.channels = c;
   hipStream_t st = gg::as_stream(stream);
   const long long planes = (long long)n * c;
-  if (epi) return launch_blur4<true, false>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
-  if (pro) return launch_blur4<false, true>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
-  return launch_blur4<false, false>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+  if (epi) return launch_blur4<true, 0>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+  if (pro) return launch_blur4<false, 1>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+  return launch_blur4<false, 0>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+}
+
+// gg_blur4_fused_f32 with the activation's sign as a 1-bit plane in the stream kernel's tiling of the FORWARD output
+// (H, W) = the backward's input: uint64 [n * c][ceil(H / 16)][ceil(W / 61)][16] (BlurFuse::sign_bits; gg_blur4_bits_words
+// uint32 words per plane).  noise != NULL: forward, every word of `bits` is written; noise == NULL: backward, `bits`
+// replaces `ref` (bitwise the same result as gg_blur4_fused_f32 on the fp32 output the plane was taken from).
+extern "C" int gg_blur4_fused_bits_f32(float* out, const float* in, const float* kernel, int n, int c, int in_h, int in_w,
+                                       int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise,
+                                       const float* noise_weight, const float* act_bias, unsigned int* bits, float alpha,
+                                       float gain, void* stream) {
+  const int out_h = in_h + pad_y0 + pad_y1 - 3, out_w = in_w + pad_x0 + pad_x1 - 3;
+  if (n <= 0 || c <= 0 || out_h <= 0 || out_w <= 0) return 0;
+  if (!out || !in || !kernel || !bits) return gg::fail(-2, "blur4_fused_bits: null pointer");
+  const bool epi = noise != nullptr;
+  if (epi && (!noise_weight || !act_bias)) return gg::fail(-2, "blur4_fused_bits: noise weight / bias missing");
+  BlurFuse f;
+  f.noise = noise; f.noise_w = noise_weight; f.bias = act_bias; f.ref = nullptr; f.alpha = alpha; f.gain = gain;
+  f.channels = c;
+  hipStream_t st = gg::as_stream(stream);
+  const long long planes = (long long)n * c;
+  // the plane is tiled like the FORWARD output: (H, W) = (out_h, out_w) here in the forward, (in_h, in_w) in the backward
+  const int ph = epi ? out_h : in_h, pw = epi ? out_w : in_w;
+  f.bit_strips = (pw + SW_OUT - 1) / SW_OUT;
+  f.bit_chunks = (ph + SROWS - 1) / SROWS;
+  if ((long long)f.bit_strips * f.bit_chunks * SROWS * 8 >= (1LL << 31)) return gg::fail(-2, "blur4_fused_bits: plane too large");
+  if (epi) {
+    f.sign_bits = reinterpret_cast<unsigned long long*>(bits);
+    return launch_blur4<true, 0>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+  }
+  f.ref_bits = bits;
+  return launch_blur4<false, 2>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+}
+
+// words (uint32) per plane of gg_blur4_fused_bits_f32's sign plane for an (h, w) forward output
+extern "C" int gg_blur4_bits_words(int h, int w) {
+  if (h <= 0 || w <= 0) return 0;
+  const long long words = 2LL * ((w + SW_OUT - 1) / SW_OUT) * ((h + SROWS - 1) / SROWS) * SROWS;
+  return words < (1LL << 29) ? (int)words : -1;
 }
 // binary16 tensors (the reference dispatches half, upfirdn2d_kernel.cu:311); taps stay fp32
 extern "C" int gg_upfirdn2d_f16(unsigned short* out, const unsigned short* in, const float* kernel, int major, int in_h,

@@ -344,7 +344,8 @@ def pack_weight(weight, groups, cout_g, cin_g, k, transpose_io, flip, scale=1.0)
 
 
 def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in_scale=None, out_scale=None,
-                 bias=None, out_hw=None, act=None, grad=False, want_sign_bits=None, amax_out=None, prelimb=None):
+                 bias=None, out_hw=None, act=None, grad=False, want_sign_bits=None, amax_out=None, prelimb=None,
+                 residual=None):
     """act = (noise (N,1,OH,OW), noise_weight (1,), act_bias (Cout,), alpha, gain): the StyledConv tail
     lrelu(y + noise_weight*noise + act_bias)*gain fused behind a 3x3/stride-1/pad-1 convolution
     (gg_modconv3x3_act_f32).  grad: this launch is a gradient convolution (data gradient): bf16 limbs in every
@@ -390,7 +391,28 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
                 prof = PROFILER          # fp32 mode: conv_igemm_kernel<3,0,2,2,2,2,*> launches without split-K
         if prof is not None:
             start = prof.begin()
-        if act is not None:
+        if residual is not None and (act is not None or tuple(residual.shape) != tuple(y.shape)
+                                     or residual.dtype != torch.float32):
+            raise NotImplementedError('conv_forward: residual = a float32 tensor of the output shape, without activation')
+        if act is not None and (k, stride, pad, mode) != (3, 1, 1, 0):
+            # any other geometry (ResBlock's 3x3 / stride-2 convolution): bias + leaky ReLU inside the library when the
+            # split-precision kernels serve the launch (gg_conv2d_split_act_f32), else convolution + activation pass
+            noise, noise_weight, act_bias, alpha, gain = act
+            if noise is not None or bias is not None or want_sign_bits is not None:
+                raise NotImplementedError('conv_forward: noise / epilogue bias / sign plane need the 3x3 stride-1 layer')
+            rc = _lib.NOT_SERVED
+            if use_split and (oh * ow) % 4 == 0:
+                wbuf, stride_l = wmat.split(code)
+                rc = _lib.call('gg_conv2d_split_act_f32', y, x, wbuf, stride_l, code, in_scale, out_scale, act_bias, alpha,
+                               gain, batch, groups, cin_g, cout_g, h, w, k, stride, pad, mode, oh if mode == 1 else 0,
+                               ow if mode == 1 else 0, allow=(_lib.NOT_SERVED,))
+            if rc != 0:
+                y = conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in_scale, out_scale,
+                                 out_hw=out_hw, grad=grad)
+                hw = oh * ow
+                _lib.call('gg_fused_bias_act_f32', y, y, act_bias, None, 3, 0, alpha, gain, y.numel(), hw,
+                          0 if act_bias is None else act_bias.numel())
+        elif act is not None:
             if (k, stride, pad, mode, groups) != (3, 1, 1, 0, 1) or bias is not None or (oh * ow) % 4:
                 raise NotImplementedError('conv_forward: the fused activation needs a 3x3 stride-1 pad-1 single-group conv')
             noise, noise_weight, act_bias, alpha, gain = act       # noise / noise_weight / act_bias may be None
@@ -423,6 +445,12 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
                 rc = _lib.call('gg_convT3x3s2_prelimb_f32', y, prelimb[0], prelimb[1], wbuf, stride_l, out_scale, bias,
                                batch, cin_g, cout_g, h, w, pad, oh, ow, allow=(_lib.NOT_SERVED,))
                 served = rc == 0
+            if not served and residual is not None and k == 1 and mode == 0 and 'conv_residual' not in DISABLED:
+                # ResBlock's skip convolution with the residual merge in its epilogue / split-K reduce pass
+                rc = _lib.call('gg_conv1x1_split_residual_f32', y, x, wbuf, stride_l, code, in_scale, out_scale, bias,
+                               residual.contiguous(), batch, groups, cin_g, cout_g, h, w, stride, allow=(_lib.NOT_SERVED,))
+                if rc == 0:
+                    served, residual = True, None
             if not served:
                 _lib.call('gg_conv2d_split_f32', y, x, wbuf, stride_l, code, in_scale, out_scale, bias, batch, groups,
                           cin_g, cout_g, h, w, k, stride, pad, mode, oh if mode == 1 else 0, ow if mode == 1 else 0)
@@ -430,6 +458,8 @@ def conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, pad, mode, in
             wm = wmat.fp32() if isinstance(wmat, PackedWeight) else wmat
             _lib.call('gg_conv2d_f32', y, x, wm, in_scale, out_scale, bias, batch, groups, cin_g, cout_g, h, w,
                       k, stride, pad, mode, oh if mode == 1 else 0, ow if mode == 1 else 0)
+        if residual is not None:             # not merged inside the convolution: one pass of its own
+            _lib.call('gg_add_scale_f32', y, y, residual.contiguous(), 1.0, y.numel())
         if prof is not None:
             # algorithmic FLOPs: a transposed stride-2 convolution does its multiply-adds at the INPUT positions
             pos = oh * ow if mode == 0 else h * w
@@ -554,9 +584,13 @@ class _Conv2d(Function):
     """F.conv2d / F.conv_transpose2d semantics (square 1x1 / 3x3 kernels, stride 1 or 2, dilation 1)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, groups, transposed, output_padding, wscale=1.0):
+    def forward(ctx, x, weight, bias, stride, padding, groups, transposed, output_padding, wscale=1.0, residual=None):
+        """residual (plain convolutions only): a tensor of the output's shape added to it (ResBlock's merge); its
+        gradient is the incoming gradient."""
         if x.dtype != torch.float32 or weight.dtype != torch.float32:
             raise TypeError('conv_mfma: float32 only')
+        if residual is not None and transposed:
+            raise NotImplementedError('conv_mfma: residual with a transposed convolution')
         x = x.contiguous()
         weight = weight.contiguous()
         batch, cin = x.shape[0], x.shape[1]
@@ -570,7 +604,7 @@ class _Conv2d(Function):
             cout_g = weight.shape[0] // groups
             assert weight.shape[1] == cin_g, 'weight / input channel mismatch'
             wmat = packed(weight, groups, cout_g, cin_g, k, 0, 0, wscale)
-            y = conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, padding, 0, bias=bias)
+            y = conv_forward(x, wmat, batch, groups, cin_g, cout_g, k, stride, padding, 0, bias=bias, residual=residual)
         else:
             cout_g = weight.shape[1]
             assert weight.shape[0] == cin, 'weight / input channel mismatch'
@@ -591,7 +625,7 @@ class _Conv2d(Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dx, dw, db = conv2d_backward(x, weight, dy, ctx.conf, ctx.needs_input_grad[:3])
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, (dy if len(ctx.needs_input_grad) > 9 and ctx.needs_input_grad[9] else None)
 
 
 def conv2d_backward(x, weight, dy, conf, needs):
@@ -727,13 +761,58 @@ def conv3x3_bias_act(input, weight, bias=None, negative_slope=0.2, scale=2 ** 0.
     return _Conv3x3BiasAct.apply(input, weight, bias, float(negative_slope), float(scale), float(weight_scale))
 
 
-def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, weight_scale=1.0):
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, weight_scale=1.0, residual=None):
     """weight_scale folds EqualConv2d's runtime `weight * scale` (networks.py:98,112) into the weight
-    packing kernel (and into the weight gradient), saving an elementwise pass per call."""
+    packing kernel (and into the weight gradient), saving an elementwise pass per call.
+    residual: conv2d(...) + residual with the sum inside the convolution where the kernel allows (1x1, split precision)."""
     if _pair_eq(dilation, 'dilation') != 1:
         raise NotImplementedError('conv_mfma: dilation != 1')
     return _Conv2d.apply(input, weight, bias, _pair_eq(stride, 'stride'), _pair_eq(padding, 'padding'), groups,
-                         False, 0, float(weight_scale))
+                         False, 0, float(weight_scale), residual)
+
+
+class _ConvBiasActS2(Function):
+    """leaky_relu(conv3x3(x, weight * wscale, stride 2, pad 0) + bias, alpha) * gain: ResBlock's down-sampling convolution
+    with its FusedLeakyReLU (networks.py:375-386) as one node - the activation inside the library in the forward
+    (gg_conv2d_split_act_f32), its backward + bias gradient in one pass in front of the two gradient convolutions."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, alpha, gain, wscale):
+        x = x.contiguous()
+        weight = weight.contiguous()
+        n, cin = x.shape[0], x.shape[1]
+        cout = weight.shape[0]
+        wmat = packed(weight, 1, cout, cin, 3, 0, 0, wscale)
+        y = conv_forward(x, wmat, n, 1, cin, cout, 3, 2, 0, 0, act=(None, None, bias.contiguous(), alpha, gain))
+        observe_activation('fused_leaky_relu', y)
+        ctx.save_for_backward(x, weight, y)
+        ctx.conf = (alpha, gain, wscale, cin, cout)
+        ctx.bias_ref = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        alpha, gain, wscale, cin, cout = ctx.conf
+        dy = dy.contiguous()
+        n, _, oh, ow = y.shape
+        need_db = ctx.needs_input_grad[2]
+        g = torch.empty_like(dy)
+        bslot = _slot_for(ctx.bias_ref) if (need_db and ctx.bias_ref is not None) else None
+        if bslot is not None:
+            _lib.call('gg_fused_lrelu_bwd_acc_f32', g, bslot, dy, y, alpha, gain, n, cout, oh * ow, 1)
+            db = None
+        else:
+            db = torch.empty(cout, dtype=torch.float32, device=dy.device) if need_db else None
+            _lib.call('gg_fused_lrelu_bwd_f32', g, db, dy, y, alpha, gain, n, cout, oh * ow)
+        dx, dw, _ = conv2d_backward(x, weight, g, (2, 0, 1, False, 0, False, cin, cout, 3, wscale),
+                                    (ctx.needs_input_grad[0], ctx.needs_input_grad[1], False))
+        return dx, dw, db, None, None, None
+
+
+def conv3x3s2_bias_act(input, weight, bias, negative_slope=0.2, scale=2 ** 0.5, weight_scale=1.0):
+    """3x3 / stride 2 / pad 0 convolution + bias + leaky ReLU (* scale)."""
+    return _ConvBiasActS2.apply(input, weight, bias, float(negative_slope), float(scale), float(weight_scale))
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):

@@ -197,15 +197,31 @@ class _BlurNoiseAct(Function):
         n, c, in_h, in_w = x.shape
         p0, p1 = pad
         out = torch.empty((n, c, in_h + p0 + p1 - 3, in_w + p0 + p1 - 3), dtype=x.dtype, device=x.device)
+        from . import conv_mfma
+        # the backward needs only the SIGN of `out` (fused_act.py:33-38): when a gradient will be asked for, the kernel
+        # also leaves it as one bit per element (in its own 61-column x 16-row tiling, see gg_blur4_fused_bits_f32), and the
+        # adjoint blur reads that instead of the fp32 tensor (a third less traffic; bitwise the same gradient).  Not with a diagnostics
+        # observer installed: it may edit `out` (decision replay), and the backward must then see the edited tensor.
+        bits = None
+        if (ctx.needs_input_grad[0] and x.dtype == torch.float32 and 'blur_bits' not in conv_mfma.DISABLED
+                and conv_mfma.ACT_OBSERVER is None):
+            bits = torch.empty((n * c, blur_bits_words(out.shape[2], out.shape[3])), dtype=torch.int32, device=x.device)
         prof = _profiler('blur4_fused<noise+bias+lrelu>')
         start = prof.begin() if prof is not None else None
-        _lib.call('gg_blur4_fused_f32', out, x, kernel, n, c, in_h, in_w, p0, p1, p0, p1, noise.contiguous(),
-                  noise_weight.contiguous(), bias.contiguous(), None, negative_slope, scale)
+        if bits is not None:
+            rc = _lib.call('gg_blur4_fused_bits_f32', out, x, kernel, n, c, in_h, in_w, p0, p1, p0, p1, noise.contiguous(),
+                           noise_weight.contiguous(), bias.contiguous(), bits, negative_slope, scale,
+                           allow=(_lib.NOT_SERVED,))
+            if rc != 0:
+                bits = None
+        if bits is None:
+            _lib.call('gg_blur4_fused_f32', out, x, kernel, n, c, in_h, in_w, p0, p1, p0, p1, noise.contiguous(),
+                      noise_weight.contiguous(), bias.contiguous(), None, negative_slope, scale)
         if prof is not None:
             prof.end(start, 4 * (x.numel() + out.numel() + noise.numel()), 'blur4_fused<noise+bias+lrelu>', 'byte')
-        from . import conv_mfma
         conv_mfma.observe_activation('blur_noise_act', out)
-        ctx.save_for_backward(kernel, out)
+        ctx.has_bits = bits is not None
+        ctx.save_for_backward(kernel, bits if bits is not None else out)
         # adjoint padding (reference upfirdn2d.py:113-118 with up = down = 1)
         ctx.g_pad = (4 - p0 - 1, in_w - out.shape[3] + p0)
         ctx.conf = (negative_slope, scale)
@@ -221,11 +237,31 @@ class _BlurNoiseAct(Function):
         dx = torch.empty((n, c, h + g0 + g1 - 3, w + g0 + g1 - 3), dtype=grad_output.dtype, device=grad_output.device)
         prof = _profiler('blur4_fused<lrelu mask>')
         start = prof.begin() if prof is not None else None
-        _lib.call('gg_blur4_fused_f32', dx, grad_output, _flipped(kernel), n, c, h, w,
-                  g0, g1, g0, g1, None, None, None, out, negative_slope, scale)
+        if ctx.has_bits:
+            _lib.call('gg_blur4_fused_bits_f32', dx, grad_output, _flipped(kernel), n, c, h, w,
+                      g0, g1, g0, g1, None, None, None, out, negative_slope, scale)
+        else:
+            _lib.call('gg_blur4_fused_f32', dx, grad_output, _flipped(kernel), n, c, h, w,
+                      g0, g1, g0, g1, None, None, None, out, negative_slope, scale)
         if prof is not None:
-            prof.end(start, 4 * (2 * grad_output.numel() + dx.numel()), 'blur4_fused<lrelu mask>', 'byte')
+            prof.end(start, 4 * ((1 if ctx.has_bits else 2) * grad_output.numel() + dx.numel()) + (out.numel() * 4 if ctx.has_bits else 0),
+                     'blur4_fused<lrelu mask>', 'byte')
         return dx, None, None, None, None, None, None, None
+
+
+def blur_bits_words(h, w):
+    """uint32 words per plane of the blur tail's sign plane for an (h, w) output (gg_blur4_bits_words)."""
+    return 2 * ((w + 60) // 61) * ((h + 15) // 16) * 16
+
+
+def blur_bits_unpack(bits, h, w):
+    """(planes, blur_bits_words(h, w)) int32 -> (planes, h, w) bool (tests)."""
+    planes = bits.shape[0]
+    strips, chunks = (w + 60) // 61, (h + 15) // 16
+    words = (bits.to(torch.int64) & 0xFFFFFFFF).reshape(planes, chunks, strips, 16, 2)
+    sh = torch.arange(32, device=bits.device, dtype=torch.int64)
+    b = ((words.unsqueeze(-1) >> sh) & 1).reshape(planes, chunks, strips, 16, 64)[..., :61]     # [p][cy][sx][row][col]
+    return b.permute(0, 1, 3, 2, 4).reshape(planes, chunks * 16, strips * 61)[:, :h, :w].bool()
 
 
 def blur_noise_act_ok(x, kernel, pad):

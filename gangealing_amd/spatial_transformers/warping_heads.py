@@ -141,6 +141,22 @@ class FlowHead(nn.Module):
         self.num_heads = num_heads
         self.flow_res = (flow_downsample * in_shape[2], flow_downsample * in_shape[3])
 
+    @staticmethod
+    def _head(seq, features):
+        """conv3x3 -> ReLU -> conv3x3 (warping_heads.py:160-169).  The first convolution carries its bias + ReLU in the
+        epilogue and the ReLU's backward + bias gradient in one pass (conv_mfma.conv3x3_bias_act with slope 0, gain 1) -
+        unless a diagnostics observer is installed (conv_mfma.ACT_OBSERVER: the decision-replay test pins the nn.ReLU
+        outputs through forward hooks while it is).  Like ConvLayer's and ResBlock's fused routes, this one does not call
+        the child modules, so forward hooks registered on them do not fire."""
+        conv0, conv1 = seq[0], seq[2]
+        if (features.dtype == torch.float32 and features.is_cuda and 'head_relu' not in conv_mfma.DISABLED and
+                conv_mfma.ACT_OBSERVER is None and isinstance(seq[1], nn.ReLU) and
+                conv0.weight.shape[-1] == 3 and conv0.stride == 1 and conv0.padding == 1 and conv0.bias is not None and
+                (features.shape[-1] * features.shape[-2]) % 4 == 0):
+            y = conv_mfma.conv3x3_bias_act(features, conv0.weight, conv0.bias, 0.0, 1.0, weight_scale=conv0.scale)
+            return conv1(y)
+        return seq(features)
+
     @property
     def identity_flow(self):
         """(1, H, W, 2) identity sampling grid (reference attribute, warping_heads.py:158,173-178)."""
@@ -152,8 +168,8 @@ class FlowHead(nn.Module):
                 padding_mode='border', return_out_of_bounds=False, image_bounds=None, warp_policy='cartesian',
                 unfold=False):
         ds, k = self.flow_downsample, self.num_heads
-        low = self.flow_out(features)                          # (N, K*2, h, w)
-        mask = self.mask_out(features)                         # (N, K*9*ds*ds, h, w)
+        low = self._head(self.flow_out, features)              # (N, K*2, h, w)
+        mask = self._head(self.mask_out, features)             # (N, K*9*ds*ds, h, w)
         n, _, h, w = low.shape
         policy, assignments = _resolve_policy(warp_policy, img, k)
         if policy == 'assign_only':

@@ -503,15 +503,23 @@ class ResBlock(nn.Module):
         c2, sk = self.conv2, self.skip
         if isinstance(c2[0], Blur):
             x, xs = blur_down_tap(input, sk[0].kernel, sk[0].pad)
-            skip = conv_mfma.conv2d(xs, sk[1].weight, bias=None, stride=1, padding=0, weight_scale=sk[1].scale * s)
             y = c2[0](self.conv1(x))
-            y = conv_mfma.conv2d(y, c2[1].weight, bias=None, stride=2, padding=0, weight_scale=c2[1].scale)
-            y = fused_leaky_relu(y, c2[2].bias, c2[2].negative_slope, c2[2].scale * s)
+            if 'conv_s2_act' in conv_mfma.DISABLED or conv_mfma.ACT_OBSERVER is not None:
+                y = conv_mfma.conv2d(y, c2[1].weight, bias=None, stride=2, padding=0, weight_scale=c2[1].scale)
+                y = fused_leaky_relu(y, c2[2].bias, c2[2].negative_slope, c2[2].scale * s)
+            else:           # convolution + FusedLeakyReLU as one node, the activation inside the library
+                y = conv_mfma.conv3x3s2_bias_act(y, c2[1].weight, c2[2].bias, c2[2].negative_slope, c2[2].scale * s,
+                                                 weight_scale=c2[1].scale)
+            sconv, sin = sk[1], xs
         else:
-            skip = conv_mfma.conv2d(input, sk[0].weight, bias=None, stride=1, padding=sk[0].padding,
-                                    weight_scale=sk[0].scale * s)
             y = conv_mfma.conv3x3_bias_act(self.conv1(input), c2[0].weight, c2[1].bias, c2[1].negative_slope,
                                            c2[1].scale * s, weight_scale=c2[0].scale)
+            sconv, sin = sk[0], input
+        if sconv.weight.shape[-1] == 1 and sconv.padding == 0 and 'conv_residual' not in conv_mfma.DISABLED:
+            # the merge (y + skip) rides in the 1x1 skip convolution's epilogue / split-K reduce pass
+            return conv_mfma.conv2d(sin, sconv.weight, bias=None, stride=1, padding=0, weight_scale=sconv.scale * s,
+                                    residual=y)
+        skip = conv_mfma.conv2d(sin, sconv.weight, bias=None, stride=1, padding=sconv.padding, weight_scale=sconv.scale * s)
         return conv_mfma.add_scale(y, skip, 1.0)
 
 

@@ -36,8 +36,11 @@ class FlatArena:
         # weights and the biases of FusedLeakyReLU activations - nothing else is registered (other 1-D parameters get
         # their gradient from autograd as usual)
         from .op.fused_act import FusedLeakyReLU
+        from .stylegan2.networks import EqualConv2d
+        # (EqualConv2d biases: the flow head's conv + ReLU pairs run as conv3x3_bias_act, whose backward looks the bias up
+        # here; a bias whose layer takes another route simply never asks)
         self._slot_ids = {id(m.bias) for m in module.modules()
-                          if isinstance(m, FusedLeakyReLU) and getattr(m, 'bias', None) is not None}
+                          if isinstance(m, (FusedLeakyReLU, EqualConv2d)) and getattr(m, 'bias', None) is not None}
         self._slot_ids |= {id(p) for p in params if p.dim() == 4}
         self.numel = sum(p.numel() for p in params)
         dev = params[0].device

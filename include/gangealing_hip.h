@@ -155,6 +155,17 @@ int gg_blur4_fused_f32(float* out, const float* in, const float* kernel, int n, 
                        int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise,
                        const float* noise_weight, const float* act_bias, const float* ref, float alpha, float gain,
                        void* stream);
+/* Round 6 (second half): the same with the activation's sign as ONE BIT per element, in the kernel's own tiling of the
+ * forward's output (H, W) = the backward's input: bits = uint64 [n * c][ceil(H / 16)][ceil(W / 61)][16 rows], bit j of a
+ * word = column strip * 61 + j of that row (gg_blur4_bits_words(H, W) uint32 words per plane; 8-byte aligned).
+ *   noise != NULL (forward): every word of `bits` is written with (out > 0) - no atomics, nothing to clear;
+ *   noise == NULL (backward): out = blur(in * (bit ? 1 : alpha) * gain) - bitwise what gg_blur4_fused_f32 gives on the
+ *   fp32 output the plane was taken from, at a third less traffic (the mask stream is ~1 / 25 of its size). */
+int gg_blur4_bits_words(int h, int w);
+int gg_blur4_fused_bits_f32(float* out, const float* in, const float* kernel, int n, int c, int in_h, int in_w,
+                            int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise,
+                            const float* noise_weight, const float* act_bias, unsigned int* bits, float alpha, float gain,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a11  splat2d.
@@ -367,6 +378,19 @@ int gg_conv2d_split_f32(float* y, const float* x, const unsigned short* wsplit, 
                         const float* in_scale, const float* out_scale, const float* bias, int batch, int groups,
                         int cin_g, int cout_g, int h, int w, int ksize, int stride, int pad, int mode, int out_h,
                         int out_w, void* stream);
+/* Round 6 (second half), ResBlock (networks.py:375-393) without its two element-wise passes:
+ *   gg_conv2d_split_act_f32: gg_conv2d_split_f32 followed by lrelu(y + act_bias[c], alpha) * gain inside the library - in
+ *     the stride-2 patch tile's epilogue, in the split-K reduce pass, or (generic tile without split-K) as the library's
+ *     own in-place pass.  H_out * W_out must be a multiple of 4 (GG_NOT_SERVED otherwise).
+ *   gg_conv1x1_split_residual_f32: y = conv1x1(x) (* out_scale, + bias) + residual, residual (N, Cout, H_out, W_out) - the
+ *     skip branch's 1x1 convolution with the residual merge (out + skip) in its epilogue / reduce pass. */
+int gg_conv2d_split_act_f32(float* y, const float* x, const unsigned short* wsplit, long long limb_stride, int limbs,
+                            const float* in_scale, const float* out_scale, const float* act_bias, float alpha, float gain,
+                            int batch, int groups, int cin_g, int cout_g, int h, int w, int ksize, int stride, int pad,
+                            int mode, int out_h, int out_w, void* stream);
+int gg_conv1x1_split_residual_f32(float* y, const float* x, const unsigned short* wsplit, long long limb_stride, int limbs,
+                                  const float* in_scale, const float* out_scale, const float* bias, const float* residual,
+                                  int batch, int groups, int cin_g, int cout_g, int h, int w, int stride, void* stream);
 /* StyledConv without upsampling in ONE pass (networks.py:243-298, 344-350: ModulatedConv2d -> NoiseInjection ->
  * FusedLeakyReLU):  y = lrelu(out_scale[n,co] * conv3x3(W, in_scale[n,ci] * x) + noise_weight[0] * noise[n,0] +
  * act_bias[co], alpha) * gain.  3x3 / stride 1 / pad 1, one group.  limbs = 0: fp32 MFMA kernel with `wmat`

@@ -89,7 +89,9 @@ def test_resblock_folded_route_is_taken_and_saves_launches(cm):
     finally:
         _lib.call = orig
     assert 'gg_upfirdn2d_add_f32' in seen
-    assert seen.count('gg_add_scale_f32') == 1
+    # the merge rides in the skip convolution, conv2's activation in its convolution: no element-wise pass of their own
+    assert 'gg_conv1x1_split_residual_f32' in seen and 'gg_conv2d_split_act_f32' in seen
+    assert 'gg_add_scale_f32' not in seen and 'gg_fused_bias_act_f32' not in seen
 
 
 def test_blur_down_tap_matches_two_nodes():
@@ -215,14 +217,17 @@ def test_few_input_channel_stem_forward_backward(cm, precision, n, cin, cout, h,
     x64 = x.double().requires_grad_(True)
     z = F.conv2d(x64, wt.double(), b.double(), padding=1)
     y64 = F.leaky_relu(z, alpha) * gain
-    y64.backward(dy.double())
-    assert float((y.double() - y64).abs().max()) <= 2e-6 * float(y64.abs().max())
-    # gradient: a unit whose pre-activation lies within rounding distance of 0 may take the other branch (a handful among
-    # the 33.5 M units of the largest case) and moves single entries by O(|dy| |w|): relative L2 is the metric, single
-    # entries are bounded loosely
+    assert float((y.double() - y64.detach()).abs().max()) <= 2e-6 * float(y64.abs().max())
+    # gradient: a unit whose pre-activation lies within rounding distance of 0 may take the other branch in float32 (a
+    # handful among the 33.5 M units of the largest case; each moves 9 * cin entries by O(|dy| |w|)), so the float64
+    # reference is evaluated with the branch decisions the kernel stored (its output's sign - what its backward reads),
+    # after checking that the two disagree only where the pre-activation is at rounding distance from the kink
+    ours_pos = y.detach() > 0
+    flips = ours_pos != (z.detach() > 0)
+    assert int(flips.sum()) <= 64 and (not bool(flips.any()) or float(z.detach()[flips].abs().max()) <= 1e-5)
+    (torch.where(ours_pos, z, z * alpha) * gain).backward(dy.double())
     d = xa.grad.double() - x64.grad
-    assert float(d.norm()) <= 2e-5 * float(x64.grad.norm()), float(d.norm()) / float(x64.grad.norm())
-    assert float(d.abs().max()) <= 2e-2 * float(x64.grad.abs().max())
+    assert float(d.abs().max()) <= 2e-5 * float(x64.grad.abs().max()), float(d.abs().max())
 
 
 def test_few_input_channel_stem_sign_plane(cm):
@@ -248,3 +253,88 @@ def test_few_input_channel_stem_sign_plane(cm):
     ref = cm.conv_forward(masked, wb, n, 1, cout, cin, 3, 1, 1, 0, grad=True)
     assert cm.last_conv_kernel().startswith('conv3x3_fewout')
     assert torch.equal(dx, ref)
+
+
+@pytest.mark.parametrize('n,c,h,w', [(2, 8, 129, 129), (1, 3, 65, 65), (2, 4, 257, 257), (1, 5, 61, 93), (3, 2, 33, 33)])
+def test_blur_sign_plane_forward_backward_bitwise(cm, n, c, h, w):
+    """The up-sampling StyledConv's tail (blur + noise + bias + leaky ReLU, networks.py:268-298) with the activation's sign
+    kept as a plane-major 1-bit plane: the plane equals (out > 0) bit for bit, the forward output is unchanged, and the
+    adjoint blur that reads the plane reproduces the fp32-masked adjoint BITWISE."""
+    from gangealing_amd import _lib
+    from gangealing_amd.op.upfirdn2d import blur_noise_act
+    from gangealing_amd.stylegan2.networks import make_kernel
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(h + w)
+    k = (make_kernel([1, 3, 3, 1]) * 4).to(dev)
+    pad = (1, 1)
+    x = torch.randn(n, c, h, w, device=dev)
+    oh, ow = h + 2 - 3, w + 2 - 3
+    noise = torch.randn(n, 1, oh, ow, device=dev)
+    nw = torch.tensor([0.3], device=dev)
+    b = torch.randn(c, device=dev) * 0.2
+    g = torch.randn(n, c, oh, ow, device=dev)
+    res = {}
+    for route in ('fp32', 'bits'):
+        cm.DISABLED = frozenset(cm.DISABLED | {'blur_bits'}) if route == 'fp32' else frozenset(cm.DISABLED - {'blur_bits'})
+        xa = x.clone().requires_grad_(True)
+        seen, orig = [], _lib.call
+
+        def spy(name, *a, **kw):
+            seen.append(name)
+            return orig(name, *a, **kw)
+        _lib.call = spy
+        try:
+            y = blur_noise_act(xa, k, pad, noise, nw, b, 0.2, 2 ** 0.5)
+            y.backward(g)
+        finally:
+            _lib.call = orig
+        res[route] = (y.detach(), xa.grad.detach(), seen)
+    assert res['bits'][2].count('gg_blur4_fused_bits_f32') == 2 and 'gg_blur4_fused_bits_f32' not in res['fp32'][2]
+    assert torch.equal(res['bits'][0], res['fp32'][0])
+    assert torch.equal(res['bits'][1], res['fp32'][1])
+    # the plane itself
+    from gangealing_amd.op.upfirdn2d import blur_bits_words, blur_bits_unpack
+    lib = _lib.load()
+    assert lib.gg_blur4_bits_words(oh, ow) == blur_bits_words(oh, ow)
+    out = torch.empty(n, c, oh, ow, device=dev)
+    bits = torch.full((n * c, blur_bits_words(oh, ow)), -1, dtype=torch.int32, device=dev)   # stale contents must not survive
+    _lib.call('gg_blur4_fused_bits_f32', out, x, k, n, c, h, w, 1, 1, 1, 1, noise, nw, b, bits, 0.2, 2 ** 0.5)
+    assert torch.equal(out, res['fp32'][0])
+    assert torch.equal(blur_bits_unpack(bits, oh, ow), (out > 0).reshape(n * c, oh, ow))
+    # every word is written (columns / rows beyond the plane as zeros): nothing of the -1 fill survives
+    words = (bits.to(torch.int64) & 0xFFFFFFFF).reshape(n * c, -1, 2)
+    assert int((words[..., 1] >> 29).max()) == 0        # bits 61 .. 63 of each 64-bit cell row
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+def test_flow_head_conv_relu_fused_equals_module_sequence(cm, precision):
+    """FlowHead's conv3x3 -> ReLU -> conv3x3 stacks (warping_heads.py:160-169) with the first convolution's bias + ReLU in
+    its epilogue: same low-resolution flow / mask logits and the same parameter gradients as the nn.Sequential route."""
+    from gangealing_amd.spatial_transformers.warping_heads import FlowHead
+    cm.set_precision(precision)
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(11)
+    head = FlowHead((1, 512, 16, 16)).to(dev)
+    with torch.no_grad():
+        for seq in (head.flow_out, head.mask_out):
+            seq[2].weight.normal_(0, 0.02)
+            seq[0].bias.normal_(0, 0.1)
+    feats = torch.randn(4, 512, 16, 16, device=dev)
+    base = set(cm.DISABLED)
+    res = {}
+    for route in ('seq', 'fused'):
+        cm.DISABLED = frozenset(base | {'head_relu'}) if route == 'seq' else frozenset(base - {'head_relu'})
+        for p in head.parameters():
+            p.grad = None
+        f = feats.clone().requires_grad_(True)
+        low, mask = head._head(head.flow_out, f), head._head(head.mask_out, f)
+        (low.square().sum() + mask.square().sum() * 0.01).backward()
+        res[route] = (low.detach(), mask.detach(), f.grad.detach(), {n: p.grad.clone() for n, p in head.named_parameters()
+                                                                     if p.grad is not None})
+    tol = 2e-6 if precision == 'fp32' else 2e-5
+    for a, b in zip(res['fused'][:3], res['seq'][:3]):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max())
+    assert set(res['fused'][3]) == set(res['seq'][3])
+    for name, gb in res['seq'][3].items():
+        ga = res['fused'][3][name]
+        assert float((ga - gb).abs().max()) <= 5 * tol * float(gb.abs().max()) + 1e-12, name
