@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GANGEALING_HIP_LIB selects another build of the same library (kernel A/B measurements); the ABI check still applies.
 LIB_PATH = os.environ.get('GANGEALING_HIP_LIB') or os.path.join(_HERE, 'lib', 'libgangealing_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 NOT_SERVED = -1000            # GG_NOT_SERVED of the header
 
 # signature alphabet: p device pointer (tensor or None), i int, q long long, f float, d double, s stream

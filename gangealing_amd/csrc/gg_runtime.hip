@@ -169,6 +169,6 @@ extern "C" int gg_set_allocator(gg_alloc_fn alloc, gg_free_fn free_fn) {
   return 0;
 }
 
-extern "C" int gg_abi_version(void) { return 5; }
+extern "C" int gg_abi_version(void) { return 6; }
 extern "C" const char* gg_last_error(void) { return gg::g_err; }
 extern "C" const char* gg_build_arch(void) { return "gfx950"; }

@@ -42,7 +42,10 @@ extern "C" {
  * 4: gg_modconv3x3_act_bits_f32 / gg_conv3x3_masked_dgrad_bits_f32 (1-bit sign plane), gg_set_tuning; the ticket page of
  *    a stream may not be created inside a hipGraph capture (error -4)
  * 5: gg_mipmap_warp_fwd/bwd_f32 take the pyramid as (level 0, the deeper levels in one buffer, num_levels <= 8) instead of
- *    four level pointers; SplatForwardGpu (the reference's own symbol) exported */
+ *    four level pointers; SplatForwardGpu (the reference's own symbol) exported
+ * 6: additive - gg_similarity_matrix_f32 / _bwd_f32, gg_conv3x3_fewout_masked_bits_f32 (+ the few-input-channel stem kernel
+ *    behind gg_modconv3x3_act_bits_f32 with limbs = 0), gg_blur4_fused_bits_f32 / gg_blur4_bits_words,
+ *    gg_conv2d_split_act_f32, gg_conv1x1_split_residual_f32 */
 int gg_abi_version(void);
 /* Pre-size the scratch buffer of `stream` on the current device to at least `bytes` and create its ticket page.
  * Optional for eager use (the entry points grow the scratch on demand); REQUIRED once per stream before a hipGraph

@@ -140,6 +140,8 @@ def test_generator_is_bitwise_the_same_with_and_without_the_limb_route(cuda, cm)
     # max |y| * max |style| where the fp32-operand tile takes one per tile and chunk from the operand itself - with the
     # deterministic test weights that bound leaves the E = 0 band on some layers, so the same values are split at another
     # scale (both splits keep 22 bits)
-    for a, b, tol in zip(out['on'][:3], out['off'][:3], (2e-6, 2e-6, 2e-5)):
+    # (the latent gradient: 1e-4 - a leaky-ReLU unit of an up-sampling layer whose pre-activation the two splits round to
+    # different sides of 0 moves it by ~5e-5 of its largest entry; which units those are follows the last ulp of the blur)
+    for a, b, tol in zip(out['on'][:3], out['off'][:3], (2e-6, 2e-6, 1e-4)):
         assert float((a - b).abs().max()) <= tol * float(b.abs().max()), float((a - b).abs().max() / b.abs().max())
     assert float(out['on'][2].abs().max()) > 0
