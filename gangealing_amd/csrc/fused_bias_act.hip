@@ -60,25 +60,32 @@ __global__ __launch_bounds__(256) void fused_lrelu_bwd_kernel(
   long long hi = lo + chunk;
   if (hi > hw) hi = hw;
   T acc = T(0);
-  for (int s = 0; s < n; ++s) {
-    const long long base = ((long long)s * c + ch) * hw;
-    for (long long p = lo + (long long)threadIdx.x * VEC; p < hi; p += 256 * VEC) {
-      if (VEC == 4) {
-        Vec4<T> g = *reinterpret_cast<const Vec4<T>*>(gout + base + p);
-        Vec4<T> o = *reinterpret_cast<const Vec4<T>*>(outv + base + p);
-        Vec4<T> r;
+  // the block's work is the hw-range [lo, hi) of EVERY sample: one flat index over (sample, position) keeps all 256 lanes
+  // busy on the small planes too (hw = 256: a per-sample loop ran 64 lanes for 16 dependent iterations; round 6)
+  const long long per = (hi - lo + VEC - 1) / VEC;          // vectors per sample in this range
+  const long long items = (long long)n * per;
+  const bool small = items < (1LL << 31);
+  for (long long i = threadIdx.x; i < items; i += 256) {
+    long long s, q;
+    if (small) { const unsigned ss = (unsigned)i / (unsigned)per; s = ss; q = (unsigned)i - ss * (unsigned)per; }
+    else { s = i / per; q = i - s * per; }
+    const long long p = lo + q * VEC;
+    const long long base = (s * c + ch) * hw;
+    if (VEC == 4) {
+      Vec4<T> g = *reinterpret_cast<const Vec4<T>*>(gout + base + p);
+      Vec4<T> o = *reinterpret_cast<const Vec4<T>*>(outv + base + p);
+      Vec4<T> r;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          r.v[j] = ((o.v[j] > T(0)) ? g.v[j] : g.v[j] * alpha) * scale;
-          acc += r.v[j];
-        }
-        *reinterpret_cast<Vec4<T>*>(gin + base + p) = r;
-      } else {
-        const T g = gout[base + p], o = outv[base + p];
-        const T r = ((o > T(0)) ? g : g * alpha) * scale;
-        gin[base + p] = r;
-        acc += r;
+      for (int j = 0; j < 4; ++j) {
+        r.v[j] = ((o.v[j] > T(0)) ? g.v[j] : g.v[j] * alpha) * scale;
+        acc += r.v[j];
       }
+      *reinterpret_cast<Vec4<T>*>(gin + base + p) = r;
+    } else {
+      const T g = gout[base + p], o = outv[base + p];
+      const T r = ((o > T(0)) ? g : g * alpha) * scale;
+      gin[base + p] = r;
+      acc += r;
     }
   }
   if (gbias) {

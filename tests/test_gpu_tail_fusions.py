@@ -349,3 +349,4 @@ def test_flow_head_conv_relu_fused_equals_module_sequence(cm, precision):
     for name, gb in res['seq'][3].items():
         ga = res['fused'][3][name]
         assert float((ga - gb).abs().max()) <= 5 * tol * float(gb.abs().max()) + 1e-12, name
+
