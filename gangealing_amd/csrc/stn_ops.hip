@@ -372,25 +372,39 @@ __device__ __forceinline__ float tent(int t, int stride) {          // kernel[t]
   return (float)((double)v / (double)(2 * stride * stride));
 }
 
+constexpr int TENT_LDS = 64;
 __global__ __launch_bounds__(256) void bilinear_down_kernel(float* __restrict__ out, const float* __restrict__ in,
                                                             long long total, int h, int w, int stride) {
   const int r = stride / 2;
   const int oh = (h + 2 * r - 2 * stride) / stride + 1, ow = (w + 2 * r - 2 * stride) / stride + 1;
+  // the 2 * stride taps once per block (tent() divides in double: exact, and ~20 of them per output in the loops below)
+  __shared__ float tw[TENT_LDS];
+  const bool tabled = 2 * stride <= TENT_LDS;
+  if (tabled && (int)threadIdx.x < 2 * stride) tw[threadIdx.x] = tent((int)threadIdx.x, stride);
+  __syncthreads();
   const long long gstride = (long long)gridDim.x * blockDim.x;
+  const bool small = total < (1LL << 31);
   for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gstride) {
-    const int ox = (int)(o % ow);
-    const long long q = o / ow;
-    const int oy = (int)(q % oh);
-    const float* src = in + (size_t)(q / oh) * h * w;
+    int ox, oy;
+    long long plane;
+    if (small) {
+      const unsigned q = (unsigned)o / (unsigned)ow, pl = q / (unsigned)oh;
+      ox = (int)((unsigned)o - q * (unsigned)ow); oy = (int)(q - pl * (unsigned)oh); plane = pl;
+    } else {
+      ox = (int)(o % ow);
+      const long long q = o / ow;
+      oy = (int)(q % oh); plane = q / oh;
+    }
+    const float* src = in + (size_t)plane * h * w;
     float acc = 0.f;
     for (int ty = 0; ty < 2 * stride; ++ty) {
       const int iy = reflect_idx(stride * oy + ty - r, h);
       float row = 0.f;
       for (int tx = 0; tx < 2 * stride; ++tx) {
         const int ix = reflect_idx(stride * ox + tx - r, w);
-        row += src[(size_t)iy * w + ix] * tent(tx, stride);
+        row += src[(size_t)iy * w + ix] * (tabled ? tw[tx] : tent(tx, stride));
       }
-      acc += row * tent(ty, stride);
+      acc += row * (tabled ? tw[ty] : tent(ty, stride));
     }
     out[o] = acc;
   }
@@ -410,12 +424,24 @@ __global__ __launch_bounds__(256) void bilinear_down_bwd_kernel(float* __restric
                                                                 int h, int w, int stride) {
   const int r = stride / 2;
   const int oh = (h + 2 * r - 2 * stride) / stride + 1, ow = (w + 2 * r - 2 * stride) / stride + 1;
+  __shared__ float tw[TENT_LDS];                            // (as in the forward kernel)
+  const bool tabled = 2 * stride <= TENT_LDS;
+  if (tabled && (int)threadIdx.x < 2 * stride) tw[threadIdx.x] = tent((int)threadIdx.x, stride);
+  __syncthreads();
   const long long gstride = (long long)gridDim.x * blockDim.x;
+  const bool small = total < (1LL << 31);                  // 32-bit index math (a 64-bit division is ~100 VALU instructions)
   for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gstride) {
-    const int ix = (int)(o % w);
-    const long long q = o / w;
-    const int iy = (int)(q % h);
-    const float* g = gout + (size_t)(q / h) * oh * ow;
+    int ix, iy;
+    long long plane;
+    if (small) {
+      const unsigned q = (unsigned)o / (unsigned)w, pl = q / (unsigned)h;
+      ix = (int)((unsigned)o - q * (unsigned)w); iy = (int)(q - pl * (unsigned)h); plane = pl;
+    } else {
+      ix = (int)(o % w);
+      const long long q = o / w;
+      iy = (int)(q % h); plane = q / h;
+    }
+    const float* g = gout + (size_t)plane * oh * ow;
     int qy[3], qx[3];
     const int ny = pad_sources(iy, h, r, qy), nx = pad_sources(ix, w, r, qx);
     float acc = 0.f;
@@ -425,13 +451,13 @@ __global__ __launch_bounds__(256) void bilinear_down_bwd_kernel(float* __restric
       for (int oy = max(y_lo, 0); oy <= y_hi; ++oy) {
         const int ty = qy[a] - stride * oy;
         if (ty < 0 || ty >= 2 * stride) continue;
-        const float ky = tent(ty, stride);
+        const float ky = tabled ? tw[ty] : tent(ty, stride);
         for (int b = 0; b < nx; ++b) {
           const int x_hi = min(qx[b] / stride, ow - 1);
           for (int ox = max(x_hi - 2, 0); ox <= x_hi; ++ox) {
             const int tx = qx[b] - stride * ox;
             if (tx < 0 || tx >= 2 * stride) continue;
-            acc += g[(size_t)oy * ow + ox] * ky * tent(tx, stride);
+            acc += g[(size_t)oy * ow + ox] * ky * (tabled ? tw[tx] : tent(tx, stride));
           }
         }
       }

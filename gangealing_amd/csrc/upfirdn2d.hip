@@ -372,16 +372,18 @@ constexpr int MAX_LDS_TAPS = 1024;
 // 16-tap filter); the tap geometry depends on the position only, so it is computed once and the thread then walks over
 // planes blockIdx.y, blockIdx.y + gridDim.y, ...
 // FAST: 0 = any up / down / taps; 1 = 4x4 taps, up 1, down 2 (the ResBlock skip's blur + stride-2 read-out and the
-// adjoint of the ToRGB up-sampling); 2 = 4x4 taps, up 2, down 1 (ToRGB skip up-sampling, adjoint of the former): the
-// tap loops have constant trip counts there.
+// adjoint of the ToRGB up-sampling); 2 = 4x4 taps, up 2, down 1 (ToRGB skip up-sampling, adjoint of the former); 3 (round
+// 6) = 4x4 taps, up = down = 1 on planes too small for the streaming blur (the generator's and the STN's blurs at <= 16^2:
+// the generic loop's per-tap branches and 64-bit offsets ran them at 0.74 TB/s): the tap loops have constant trip counts there.
 template <typename T, typename K = T, int FAST = 0>
 __global__ __launch_bounds__(256) void upfirdn2d_direct(
     T* __restrict__ out, const T* __restrict__ in, const K* __restrict__ kernel,
     int major, int in_h, int in_w, int out_h, int out_w, int kh_, int kw_,
     int up_x_, int up_y_, int down_x_, int down_y_, int pad_x0, int pad_y0, const T* __restrict__ addend = nullptr) {
   const int kh = FAST ? 4 : kh_, kw = FAST ? 4 : kw_;
-  const int up_x = FAST == 1 ? 1 : FAST == 2 ? 2 : up_x_, up_y = FAST == 1 ? 1 : FAST == 2 ? 2 : up_y_;
-  const int down_x = FAST == 1 ? 2 : FAST == 2 ? 1 : down_x_, down_y = FAST == 1 ? 2 : FAST == 2 ? 1 : down_y_;
+  const int up_x = (FAST == 1 || FAST == 3) ? 1 : FAST == 2 ? 2 : up_x_, up_y = (FAST == 1 || FAST == 3) ? 1 : FAST == 2 ? 2 : up_y_;
+  const int down_x = FAST == 1 ? 2 : (FAST == 2 || FAST == 3) ? 1 : down_x_;
+  const int down_y = FAST == 1 ? 2 : (FAST == 2 || FAST == 3) ? 1 : down_y_;
   __shared__ K sk[MAX_LDS_TAPS];
   const bool lds_taps = kh * kw <= MAX_LDS_TAPS;
   if (lds_taps) {
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_direct(
     if (FAST) {
       // constant trip counts: NT taps per axis starting at (tx0, ty0) in {0 .. up - 1}; a tap outside the image reads a
       // clamped (always valid) address and is replaced by zero - no branches in the plane loop
-      constexpr int NT = FAST == 1 ? 4 : 2, UP = FAST == 1 ? 1 : 2;
+      constexpr int NT = FAST == 2 ? 2 : 4, UP = FAST == 2 ? 2 : 1;
       K kv[NT][NT];
       int off[NT][NT];
       unsigned okm = 0;
@@ -562,6 +564,12 @@ bool launch_fir4_down2(float* out, const float* in, const float* kernel, int maj
 }
 
 // grid: x covers one plane's outputs, y strides over planes (<= 64 planes per thread)
+// A/B switch for measurements: GG_NO_FIR4_SMALL=1 keeps the generic loop for small-plane 4x4 blurs.
+inline bool fir4_small_fast() {
+  static const bool v = getenv("GG_NO_FIR4_SMALL") == nullptr;
+  return v;
+}
+
 template <typename T, typename K>
 int launch_direct(T* out, const T* in, const K* kernel, const T* addend, int major, int in_h, int in_w, int out_h,
                   int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_y0,
@@ -572,6 +580,7 @@ int launch_direct(T* out, const T* in, const K* kernel, const T* addend, int maj
   const unsigned gx = (per_out + 255u) / 256u;
   unsigned gy = (unsigned)major;
   // enough blocks to fill the chip, but let a thread reuse its tap geometry over several planes when there are many
+  // (measured on the small-plane blurs, round 6: 1024 blocks instead of 4096 = more planes per thread: 26 against 23 us)
   while (gy > 1 && (unsigned long long)gx * gy > 4096ull && gy * 2u > (unsigned)major / 32u) gy = (gy + 1) / 2;
   if (gy > 65535u) gy = 65535u;
   const dim3 grid(gx, gy);
@@ -585,6 +594,9 @@ int launch_direct(T* out, const T* in, const K* kernel, const T* addend, int maj
                                                      down_x, down_y, pad_x0, pad_y0, addend);
   else if (fir4 && up_x == 2 && down_x == 1)
     upfirdn2d_direct<T, K, 2><<<grid, 256, 0, st>>>(out, in, kernel, major, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y,
+                                                     down_x, down_y, pad_x0, pad_y0, addend);
+  else if (fir4 && up_x == 1 && down_x == 1 && fir4_small_fast())
+    upfirdn2d_direct<T, K, 3><<<grid, 256, 0, st>>>(out, in, kernel, major, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y,
                                                      down_x, down_y, pad_x0, pad_y0, addend);
   else
     upfirdn2d_direct<T, K, 0><<<grid, 256, 0, st>>>(out, in, kernel, major, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y,

@@ -350,3 +350,31 @@ def test_flow_head_conv_relu_fused_equals_module_sequence(cm, precision):
         ga = res['fused'][3][name]
         assert float((ga - gb).abs().max()) <= 5 * tol * float(gb.abs().max()) + 1e-12, name
 
+
+
+@pytest.mark.parametrize('shape,pad', [((16, 64, 17, 17), (1, 1)), ((4, 32, 9, 9), (2, 1)), ((2, 8, 19, 23), (1, 1)),
+                                       ((3, 5, 5, 5), (2, 2)), ((2, 16, 16, 16), (2, 1))])
+def test_small_plane_blur_constant_trip_count_path(shape, pad):
+    """4x4 FIR with up = down = 1 on planes below the streaming kernel's 24 x 24 minimum (the generator's and the STN's
+    blurs at <= 16^2) on upfirdn2d_direct's constant-trip-count path: against float64 correlation with the flipped taps,
+    forward and adjoint (the adjoint is the same operator with flipped taps and the adjoint padding)."""
+    import torch.nn.functional as F
+    from gangealing_amd.op.upfirdn2d import upfirdn2d
+    from gangealing_amd.stylegan2.networks import make_kernel
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(shape[2] * 7 + shape[3])
+    k = make_kernel([1, 3, 3, 1]).to(dev)
+    x = torch.randn(*shape, device=dev)
+    xa = x.clone().requires_grad_(True)
+    y = upfirdn2d(xa, k, pad=pad)
+    g = torch.randn_like(y)
+    y.backward(g)
+    x64 = x.double().requires_grad_(True)
+    n, c, h, w = shape
+    xp = F.pad(x64, (pad[0], pad[1], pad[0], pad[1]))
+    w64 = torch.flip(k.double(), [0, 1])[None, None].expand(c, 1, 4, 4)
+    y64 = F.conv2d(xp, w64, groups=c)
+    y64.backward(g.double())
+    assert y.shape == y64.shape
+    assert float((y.double() - y64).abs().max()) <= 1e-6 * float(y64.abs().max())
+    assert float((xa.grad.double() - x64.grad).abs().max()) <= 1e-6 * float(x64.grad.abs().max())
