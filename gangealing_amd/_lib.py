@@ -31,6 +31,7 @@ _PROTOS = {
     'gg_upfirdn2d_f16': 'pppiiiiiiiiiiiiis',
     'gg_blur4_fused_f32': 'pppiiiiiiiippppffs',
     'gg_blur4_fused_bits_f32': 'pppiiiiiiiippppffs',
+    'gg_blur4_act_bwd_f32': 'pppiiiiiiiipffpis',
     'gg_splat_forward_f32': 'pppppiiiiis',
     'gg_splat2d_f32': 'ppppppiiiiiis',
     'gg_mip_downsample2x_f32': 'ppiiis',

@@ -43,6 +43,12 @@ struct BlurFuse {
   unsigned long long* sign_bits = nullptr;
   const unsigned* ref_bits = nullptr;
   int bit_strips = 0, bit_chunks = 0;
+  // EPI = 2 (round 6): the blur is the ADJOINT of a Blur that followed a conv + leaky-ReLU layer (ResBlock's conv1 -> Blur,
+  // networks.py:375-386) and the activation's backward rides in its epilogue: out = lrelu'(out_ref) * blur(in), out_ref =
+  // the layer's saved output (the shape of `out`); wave_sums[unit] receives the sum of the strip's outputs - the bias
+  // gradient's partial sums, added per channel in a fixed order by blur_bias_reduce_kernel.
+  const float* out_ref = nullptr;
+  float* wave_sums = nullptr;
 };
 
 template <bool EPI, bool PRO>
@@ -191,7 +197,8 @@ __device__ __forceinline__ float wave_shl1(float v) {     // lane i <- lane i+1;
 }
 
 // PRO: 0 = plain input; 1 = input * lrelu'(ref) from the saved fp32 output; 2 = the same factor from the sign plane
-template <bool EPI, int PRO>
+// EPI: 0 = plain store; 1 = + noise + bias, leaky ReLU (the up-sampling StyledConv's tail); 2 = * lrelu'(out_ref) (+ strip sums)
+template <int EPI, int PRO>
 __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
     float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ kernel,
     int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0,
@@ -240,9 +247,13 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
   const int bit_sh = bcol & 31;
   const __amdgpu_buffer_rsrc_t dst = gg::uniform_rsrc(out + (size_t)plane * out_h * out_w, out_bytes);
   float nw = 0.f, ab = 0.f;
-  const int n_img = EPI ? (int)(plane / f.channels) : 0;
-  const __amdgpu_buffer_rsrc_t nz = gg::uniform_rsrc(EPI ? f.noise + (size_t)n_img * out_h * out_w : in, out_bytes);
-  if (EPI) {
+  const int n_img = EPI == 1 ? (int)(plane / f.channels) : 0;
+  // the epilogue's second operand at the OUTPUT position: the noise image (EPI = 1) or the saved activation (EPI = 2)
+  const __amdgpu_buffer_rsrc_t nz = gg::uniform_rsrc(
+      EPI == 1 ? f.noise + (size_t)n_img * out_h * out_w : (EPI == 2 ? f.out_ref + (size_t)plane * out_h * out_w : in),
+      out_bytes);
+  float wsum = 0.f;                                         // EPI = 2: sum of this lane's outputs
+  if (EPI == 1) {
     nw = f.noise_w[0];
     ab = f.bias[plane - (unsigned)n_img * (unsigned)f.channels];
   }
@@ -273,19 +284,27 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
     const bool row_ok = oy < out_h;
     const unsigned vo = row_ok ? out_off : gg::kOobOffset;
     const int so = row_ok ? oy * out_w * 4 : 0;
-    if (EPI) {
+    if (EPI == 1) {
       const float t = acc + nw * noise + ab;
       acc = (t > 0.f ? t : t * f.alpha) * f.gain;
     }
+    if (EPI == 2) {                                         // fused_act.py:33-38 on the blurred gradient (`noise` = out_ref here)
+      acc = ((noise > 0.f) ? acc : acc * f.alpha) * f.gain;
+      if (row_ok && lane < SW_OUT && ox < out_w) wsum += acc;
+    }
     gg::buffer_store_f32(acc, dst, vo, so);
-    if (EPI && f.sign_bits) {                               // (wave-uniform) exactly the test the backward applies to `out`
+    if (EPI == 1 && f.sign_bits) {                          // (wave-uniform) exactly the test the backward applies to `out`
       const unsigned long long m = __ballot(row_ok && lane < SW_OUT && ox < out_w && acc > 0.f);
       if (lane == u) my_bits = m;
     }
   };
   auto flush_bits = [&]() {
-    if (EPI && f.sign_bits && lane < SROWS)
+    if (EPI == 1 && f.sign_bits && lane < SROWS)
       f.sign_bits[(((size_t)plane * f.bit_chunks + cy) * f.bit_strips + sx) * SROWS + lane] = my_bits;
+    if (EPI == 2 && f.wave_sums) {                          // fixed shuffle tree: the same sum on every run
+      const float tot = gg::wave_sum(wsum);
+      if (lane == 0) f.wave_sums[unit] = tot;
+    }
   };
   if (sep) {
     auto hpass = [&](float v) -> float {
@@ -300,7 +319,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
 #pragma unroll
     for (int u = 0; u < SROWS; ++u) nv[u] = fetch(iy0 + 3 + u);
 #pragma unroll
-    for (int u = 0; u < SROWS; ++u) nzv[u] = EPI ? noise_at(oy0 + u) : 0.f;
+    for (int u = 0; u < SROWS; ++u) nzv[u] = EPI != 0 ? noise_at(oy0 + u) : 0.f;
     float h0 = hpass(r0), h1 = hpass(r1), h2 = hpass(r2);
 #pragma unroll
     for (int u = 0; u < SROWS; ++u) {
@@ -327,7 +346,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_blur4_stream(
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc += w[r][c] * kf[r * 4 + c];
-    finish(acc, oy0 + rr, EPI ? noise_at(oy0 + rr) : 0.f, rr);
+    finish(acc, oy0 + rr, EPI != 0 ? noise_at(oy0 + rr) : 0.f, rr);
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -342,14 +361,14 @@ inline bool blur_use_tile_kernel() {
   return v;
 }
 
-template <bool EPI, int PRO>
+template <int EPI, int PRO>
 int launch_blur4(float* out, const float* in, const float* kernel, long long planes, int in_h, int in_w, int out_h,
                  int out_w, int pad_x0, int pad_y0, const BlurFuse& f, hipStream_t st) {
-  if (blur_use_tile_kernel() && PRO != 2 && !f.sign_bits) {
+  if (blur_use_tile_kernel() && PRO != 2 && EPI != 2 && !f.sign_bits) {
     const int tiles_x = (out_w + TILE - 1) / TILE, tiles_y = (out_h + TILE - 1) / TILE;
     const long long ntiles = (long long)tiles_x * tiles_y * planes;
     if (ntiles >= (1LL << 31)) return gg::fail(-2, "blur4: too many tiles");
-    upfirdn2d_blur4_tile<EPI, PRO == 1><<<(unsigned)ntiles, 256, 0, st>>>(out, in, kernel, (int)planes, in_h, in_w, out_h,
+    upfirdn2d_blur4_tile<EPI == 1, PRO == 1><<<(unsigned)ntiles, 256, 0, st>>>(out, in, kernel, (int)planes, in_h, in_w, out_h,
                                                                     out_w, pad_x0, pad_y0, tiles_x, tiles_y,
                                                                     (unsigned)ntiles, f);
     return gg::launch_status("upfirdn2d_blur4_tile");
@@ -617,7 +636,7 @@ int upfirdn2d_impl(T* out, const T* in, const T* kernel, int major, int in_h, in
   const bool blur4 = sizeof(T) == 4 && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4 &&
                      out_h >= 24 && out_w >= 24;
   if (blur4)
-    return launch_blur4<false, false>(reinterpret_cast<float*>(out), reinterpret_cast<const float*>(in),
+    return launch_blur4<0, 0>(reinterpret_cast<float*>(out), reinterpret_cast<const float*>(in),
                                       reinterpret_cast<const float*>(kernel), major, in_h, in_w, out_h, out_w, pad_x0,
                                       pad_y0, BlurFuse{}, st);
   return launch_direct<T, T>(out, in, kernel, nullptr, major, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y, down_x, down_y,
@@ -663,9 +682,9 @@ extern "C" int gg_blur4_fused_f32(float* out, const float* in, const float* kern
   f.channels = c;
   hipStream_t st = gg::as_stream(stream);
   const long long planes = (long long)n * c;
-  if (epi) return launch_blur4<true, 0>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
-  if (pro) return launch_blur4<false, 1>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
-  return launch_blur4<false, 0>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+  if (epi) return launch_blur4<1, 0>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+  if (pro) return launch_blur4<0, 1>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+  return launch_blur4<0, 0>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
 }
 
 // gg_blur4_fused_f32 with the activation's sign as a 1-bit plane in the stream kernel's tiling of the FORWARD output
@@ -693,10 +712,59 @@ extern "C" int gg_blur4_fused_bits_f32(float* out, const float* in, const float*
   if ((long long)f.bit_strips * f.bit_chunks * SROWS * 8 >= (1LL << 31)) return gg::fail(-2, "blur4_fused_bits: plane too large");
   if (epi) {
     f.sign_bits = reinterpret_cast<unsigned long long*>(bits);
-    return launch_blur4<true, 0>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+    return launch_blur4<1, 0>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
   }
   f.ref_bits = bits;
-  return launch_blur4<false, 2>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+  return launch_blur4<0, 2>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+}
+
+// dbias[c] (+)= sum over (sample, chunk, strip) of the EPI = 2 launch's strip sums, in a fixed order: thread t of the
+// channel's block takes items t, t + 256, ... (ascending), then the fixed tree of block_sum_256
+__global__ __launch_bounds__(256) void blur_bias_reduce_kernel(float* __restrict__ dbias, const float* __restrict__ sums,
+                                                               int n, int c, int per_plane, int accumulate) {
+  __shared__ float red[4];
+  const int ch = blockIdx.x;
+  const int items = n * per_plane;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < items; i += 256) {
+    const int s = i / per_plane, u = i - s * per_plane;
+    acc += sums[((size_t)s * c + ch) * per_plane + u];
+  }
+  const float tot = gg::block_sum_256<float>(acc, red);
+  if (threadIdx.x == 0) dbias[ch] = (accumulate ? dbias[ch] : 0.f) + tot;
+}
+
+// The adjoint of a 4x4 Blur that followed a conv + bias + leaky-ReLU layer, with that activation's backward in its
+// epilogue (ResBlock's conv1 -> Blur, networks.py:375-386; fused_act.py:27-38): out = lrelu'(out_ref) * gain *
+// blur(in, kernel), kernel = the FLIPPED taps and pads = the adjoint padding (upfirdn2d.py:113-118), out_ref (n, c, out_h,
+// out_w) = the layer's saved output; dbias (c), when given, receives (accumulate: is added) the bias gradient
+// sum_{n, y, x} out - strip sums in the library's scratch, added per channel in a fixed order.  Replaces the adjoint blur
+// followed by gg_fused_lrelu_bwd_f32 (a read of the blurred gradient and of out_ref, a write of the masked gradient).
+// GG_NOT_SERVED (nothing launched) for planes below the streaming kernel's 24 x 24 minimum.
+extern "C" int gg_blur4_act_bwd_f32(float* out, const float* in, const float* kernel, int n, int c, int in_h, int in_w,
+                                    int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* out_ref, float alpha,
+                                    float gain, float* dbias, int accumulate, void* stream) {
+  const int out_h = in_h + pad_y0 + pad_y1 - 3, out_w = in_w + pad_x0 + pad_x1 - 3;
+  if (n <= 0 || c <= 0 || out_h <= 0 || out_w <= 0) return 0;
+  if (!out || !in || !kernel || !out_ref) return gg::fail(-2, "blur4_act_bwd: null pointer");
+  if (out_h < 24 || out_w < 24 || blur_use_tile_kernel()) return GG_NOT_SERVED;
+  hipStream_t st = gg::as_stream(stream);
+  const long long planes = (long long)n * c;
+  const int strips_x = (out_w + SW_OUT - 1) / SW_OUT, chunks_y = (out_h + SROWS - 1) / SROWS;
+  const long long nunits = planes * strips_x * chunks_y;
+  if (nunits >= (1LL << 31) || c > 65535) return gg::fail(-2, "blur4_act_bwd: too many strips / channels");
+  BlurFuse f;
+  f.noise = nullptr; f.noise_w = nullptr; f.bias = nullptr; f.ref = nullptr; f.alpha = alpha; f.gain = gain;
+  f.channels = c;
+  f.out_ref = out_ref;
+  if (dbias) {
+    f.wave_sums = reinterpret_cast<float*>(gg::scratch(st, sizeof(float) * (size_t)nunits));
+    if (!f.wave_sums) return -3;
+  }
+  const int rc = launch_blur4<2, 0>(out, in, kernel, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, f, st);
+  if (rc || !dbias) return rc;
+  blur_bias_reduce_kernel<<<(unsigned)c, 256, 0, st>>>(dbias, f.wave_sums, n, c, strips_x * chunks_y, accumulate ? 1 : 0);
+  return gg::launch_status("blur_bias_reduce");
 }
 
 // words (uint32) per plane of gg_blur4_fused_bits_f32's sign plane for an (h, w) forward output

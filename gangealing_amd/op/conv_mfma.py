@@ -747,6 +747,65 @@ class _Conv3x3BiasAct(Function):
         return dx, dw, db, None, None, None
 
 
+class _Conv3x3BiasActBlur(Function):
+    """blur4x4(leaky_relu(conv3x3(x, weight * wscale, pad 1) + bias, alpha) * gain): ResBlock's conv1 and the Blur in front
+    of its down-sampling convolution (networks.py:375-386) as ONE node.  The forward is the two launches it always was; in
+    the backward the Blur's adjoint applies the activation's backward in its epilogue and leaves the bias gradient
+    (gg_blur4_act_bwd_f32) - the masked gradient is produced once instead of being written blurred, re-read with the saved
+    output and written again by a separate pass - and the two gradient convolutions follow as in _Conv3x3BiasAct."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, alpha, gain, wscale, kernel, pad):
+        from .upfirdn2d import _launch
+        x = x.contiguous()
+        weight = weight.contiguous()
+        n, cin = x.shape[0], x.shape[1]
+        cout = weight.shape[0]
+        wmat = packed(weight, 1, cout, cin, 3, 0, 0, wscale)
+        y = conv_forward(x, wmat, n, 1, cin, cout, 3, 1, 1, 0, act=(None, None, bias.contiguous(), alpha, gain))
+        p0, p1 = pad
+        b = _launch(y, kernel, 1, 1, 1, 1, p0, p1, p0, p1)
+        ctx.save_for_backward(x, weight, y, kernel)
+        ctx.conf = (alpha, gain, wscale, p0, p1)
+        ctx.bias_ref = bias
+        return b
+
+    @staticmethod
+    def backward(ctx, db):
+        from .upfirdn2d import _flipped, _launch
+        x, weight, y, kernel = ctx.saved_tensors
+        alpha, gain, wscale, p0, p1 = ctx.conf
+        db = db.contiguous()
+        n, cout, h, w = y.shape
+        cin = x.shape[1]
+        bh, bw = db.shape[-2:]
+        g0, g1 = 4 - p0 - 1, w - bw + p0                      # the adjoint's padding (upfirdn2d.py:113-118, up = down = 1)
+        need_db = ctx.needs_input_grad[2]
+        bslot = _slot_for(ctx.bias_ref) if need_db else None
+        dbias = bslot if bslot is not None else (torch.empty(cout, dtype=torch.float32, device=db.device) if need_db else None)
+        g = torch.empty_like(y)
+        rc = _lib.call('gg_blur4_act_bwd_f32', g, db, _flipped(kernel), n, cout, bh, bw, g0, g1, g0, g1, y, alpha, gain, dbias,
+                       1 if bslot is not None else 0, allow=(_lib.NOT_SERVED,))
+        if rc != 0:                                           # small planes: adjoint blur, then the activation's backward
+            dy = _launch(db, _flipped(kernel), 1, 1, 1, 1, g0, g1, g0, g1)
+            if bslot is not None:
+                _lib.call('gg_fused_lrelu_bwd_acc_f32', g, bslot, dy, y, alpha, gain, n, cout, h * w, 1)
+            else:
+                _lib.call('gg_fused_lrelu_bwd_f32', g, dbias, dy, y, alpha, gain, n, cout, h * w)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_forward(g, packed(weight, 1, cin, cout, 3, 1, 1, wscale), n, 1, cout, cin, 3, 1, 1, 0, grad=True)
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(x, g, n, 1, cin, cout, 3, 1, 1, wscale, into=_slot_for(weight))
+        return dx, dw, (None if bslot is not None else dbias), None, None, None, None, None
+
+
+def conv3x3_bias_act_blur(input, weight, bias, kernel, pad, negative_slope=0.2, scale=2 ** 0.5, weight_scale=1.0):
+    """blur4x4(conv3x3 + bias + leaky ReLU) with the Blur's backward carrying the activation's (see _Conv3x3BiasActBlur)."""
+    return _Conv3x3BiasActBlur.apply(input, weight, bias, float(negative_slope), float(scale), float(weight_scale),
+                                     kernel.to(input.dtype), (int(pad[0]), int(pad[1])))
+
+
 def conv3x3_bias_act(input, weight, bias=None, negative_slope=0.2, scale=2 ** 0.5, weight_scale=1.0):
     """3x3 / stride 1 / pad 1 convolution + bias + leaky ReLU (* scale) in one kernel where the shape allows
     (gg_modconv3x3_act_f32; the library falls back to conv + activation pass internally otherwise)."""

@@ -507,7 +507,16 @@ class ResBlock(nn.Module):
         c2, sk = self.conv2, self.skip
         if isinstance(c2[0], Blur):
             x, xs = blur_down_tap(input, sk[0].kernel, sk[0].pad)
-            y = c2[0](self.conv1(x))
+            c1 = self.conv1
+            if ('conv_blur_bwd' not in conv_mfma.DISABLED and conv_mfma.ACT_OBSERVER is None and len(c1) == 2 and
+                    isinstance(c1[0], EqualConv2d) and isinstance(c1[1], FusedLeakyReLU) and c1[0].bias is None and
+                    c1[0].weight.shape[-1] == 3 and c1[0].stride == 1 and c1[0].padding == 1 and
+                    tuple(c2[0].kernel.shape) == (4, 4) and min(x.shape[-2:]) >= 24 and (x.shape[-1] * x.shape[-2]) % 4 == 0):
+                # conv1 + its activation + the Blur as one node: the Blur's adjoint carries the activation's backward
+                y = conv_mfma.conv3x3_bias_act_blur(x, c1[0].weight, c1[1].bias, c2[0].kernel, c2[0].pad,
+                                                    c1[1].negative_slope, c1[1].scale, weight_scale=c1[0].scale)
+            else:
+                y = c2[0](c1(x))
             if 'conv_s2_act' in conv_mfma.DISABLED or conv_mfma.ACT_OBSERVER is not None:
                 y = conv_mfma.conv2d(y, c2[1].weight, bias=None, stride=2, padding=0, weight_scale=c2[1].scale)
                 y = fused_leaky_relu(y, c2[2].bias, c2[2].negative_slope, c2[2].scale * s)

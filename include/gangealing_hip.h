@@ -45,7 +45,7 @@ extern "C" {
  *    four level pointers; SplatForwardGpu (the reference's own symbol) exported
  * 6: additive - gg_similarity_matrix_f32 / _bwd_f32, gg_conv3x3_fewout_masked_bits_f32 (+ the few-input-channel stem kernel
  *    behind gg_modconv3x3_act_bits_f32 with limbs = 0), gg_blur4_fused_bits_f32 / gg_blur4_bits_words,
- *    gg_conv2d_split_act_f32, gg_conv1x1_split_residual_f32 */
+ *    gg_conv2d_split_act_f32, gg_conv1x1_split_residual_f32, gg_blur4_act_bwd_f32 */
 int gg_abi_version(void);
 /* Pre-size the scratch buffer of `stream` on the current device to at least `bytes` and create its ticket page.
  * Optional for eager use (the entry points grow the scratch on demand); REQUIRED once per stream before a hipGraph
@@ -165,6 +165,15 @@ int gg_blur4_fused_f32(float* out, const float* in, const float* kernel, int n, 
  *   noise == NULL (backward): out = blur(in * (bit ? 1 : alpha) * gain) - bitwise what gg_blur4_fused_f32 gives on the
  *   fp32 output the plane was taken from, at a third less traffic (the mask stream is ~1 / 25 of its size). */
 int gg_blur4_bits_words(int h, int w);
+/* Round 6 (second half): the ADJOINT of a 4x4 Blur that followed a conv + bias + leaky-ReLU layer (ResBlock's conv1 -> Blur,
+ * networks.py:375-386) with that activation's backward (fused_act.py:27-38) in its epilogue:
+ *   out = (out_ref > 0 ? 1 : alpha) * gain * blur(in, kernel)      kernel = the flipped taps, pads = the adjoint padding
+ *   dbias[c] (=, or += with accumulate) sum_{n,y,x} out            (NULL: not wanted) - strip sums added in a fixed order
+ * in (n,c,in_h,in_w) = the gradient of the blur's output, out / out_ref (n,c,in_h+pad_y0+pad_y1-3, ...) = the layer's
+ * output.  Replaces gg_upfirdn2d_f32 + gg_fused_lrelu_bwd(_acc)_f32.  GG_NOT_SERVED below 24 x 24 outputs. */
+int gg_blur4_act_bwd_f32(float* out, const float* in, const float* kernel, int n, int c, int in_h, int in_w, int pad_x0,
+                         int pad_x1, int pad_y0, int pad_y1, const float* out_ref, float alpha, float gain, float* dbias,
+                         int accumulate, void* stream);
 int gg_blur4_fused_bits_f32(float* out, const float* in, const float* kernel, int n, int c, int in_h, int in_w,
                             int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise,
                             const float* noise_weight, const float* act_bias, unsigned int* bits, float alpha, float gain,

@@ -378,3 +378,53 @@ def test_small_plane_blur_constant_trip_count_path(shape, pad):
     assert y.shape == y64.shape
     assert float((y.double() - y64).abs().max()) <= 1e-6 * float(y64.abs().max())
     assert float((xa.grad.double() - x64.grad).abs().max()) <= 1e-6 * float(x64.grad.abs().max())
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+@pytest.mark.parametrize('n,cin,cout,res', [(4, 64, 64, 128), (2, 128, 128, 64), (2, 512, 512, 32), (2, 32, 64, 40),
+                                            (2, 512, 512, 16)])
+def test_conv_act_blur_node_equals_the_three_separate_nodes(cm, precision, n, cin, cout, res):
+    """ResBlock's conv1 -> FusedLeakyReLU -> Blur as one node whose backward applies the activation's backward in the
+    Blur's adjoint (gg_blur4_act_bwd_f32): forward, input gradient and weight gradient BITWISE those of the three
+    separate nodes (the masked gradient is the same tensor: explicit FMA chains in the blur, the same mask expression);
+    the bias gradient to rounding (another, equally fixed summation order).  16^2 planes take the node's fallback."""
+    from gangealing_amd import _lib
+    from gangealing_amd.op.upfirdn2d import upfirdn2d
+    from gangealing_amd.stylegan2.networks import make_kernel
+    cm.set_precision(precision)
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(cin + res)
+    k = make_kernel([1, 3, 3, 1]).to(dev)
+    pad = (2, 2)
+    x = torch.randn(n, cin, res, res, device=dev)
+    wt = (torch.randn(cout, cin, 3, 3, device=dev))
+    b = torch.randn(cout, device=dev) * 0.2
+    wscale = 1.0 / math.sqrt(cin * 9)
+    gshape = (n, cout, res + 1, res + 1)
+    g = torch.randn(*gshape, device=dev)
+    res_ = {}
+    for route in ('separate', 'node'):
+        xa, wa, ba = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        seen, orig = [], _lib.call
+
+        def spy(name, *a, **kw):
+            seen.append(name)
+            return orig(name, *a, **kw)
+        _lib.call = spy
+        try:
+            if route == 'separate':
+                y = upfirdn2d(cm.conv3x3_bias_act(xa, wa, ba, 0.2, 2 ** 0.5, weight_scale=wscale), k, pad=pad)
+            else:
+                y = cm.conv3x3_bias_act_blur(xa, wa, ba, k, pad, 0.2, 2 ** 0.5, weight_scale=wscale)
+            assert tuple(y.shape) == gshape
+            y.backward(g)
+        finally:
+            _lib.call = orig
+        res_[route] = (y.detach(), xa.grad, wa.grad, ba.grad, seen)
+    if res >= 24:
+        assert 'gg_blur4_act_bwd_f32' in res_['node'][4] and not any('lrelu_bwd' in s for s in res_['node'][4])
+    assert torch.equal(res_['node'][0], res_['separate'][0])
+    assert torch.equal(res_['node'][1], res_['separate'][1])
+    assert torch.equal(res_['node'][2], res_['separate'][2])
+    db0, db1 = res_['separate'][3], res_['node'][3]
+    assert float((db1 - db0).abs().max()) <= 2e-5 * float(db0.abs().max())
