@@ -2319,6 +2319,108 @@ __global__ __launch_bounds__(256) void wgrad_1x1_smallcin_kernel(float* __restri
     }
 }
 
+// 3x3 / stride 1 / pad 1 weight gradient with <= 4 OUTPUT channels (the flow head's last layer, 512 -> 2 @16^2: the generic
+// 128 x 128-tile kernel spent 78 us on it with 2 of its 128 rows in use).  dW[co][ci][tap] = sum_{n,p} dy[n,co,p] x[n,ci,p+tap]:
+// one block per input channel, threads stride over (sample, pixel) with the NCO x 9 sums in registers, then the fixed tree
+// of block_sum_256 per output - no partial tiles, no reduce pass, exact fp32 products, reproducible.
+template <int NCO>
+__global__ __launch_bounds__(256) void wgrad3x3_fewout_kernel(float* __restrict__ dw, const float* __restrict__ x,
+                                                              const float* __restrict__ dy, int batch, int cin, int h,
+                                                              int w, float scale, int accumulate) {
+  __shared__ float red[4];
+  const int ci = blockIdx.x;
+  const unsigned hw = (unsigned)h * (unsigned)w, total = (unsigned)batch * hw;
+  float acc[NCO][9];
+#pragma unroll
+  for (int j = 0; j < NCO; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[j][t] = 0.f;
+  for (unsigned i = threadIdx.x; i < total; i += 256u) {
+    const unsigned n = i / hw, p = i - n * hw;
+    const int py = (int)(p / (unsigned)w), px = (int)(p - (unsigned)py * (unsigned)w);
+    float d[NCO];
+#pragma unroll
+    for (int j = 0; j < NCO; ++j) d[j] = dy[((size_t)n * NCO + j) * hw + p];
+    const float* xp = x + ((size_t)n * cin + ci) * hw;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = py + ky - 1, ix = px + kx - 1;
+        const bool ok = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+        const float v = ok ? xp[iy * w + ix] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NCO; ++j) acc[j][ky * 3 + kx] = fmaf(d[j], v, acc[j][ky * 3 + kx]);
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < NCO; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float tot = gg::block_sum_256<float>(acc[j][t], red);
+      if (threadIdx.x == 0) {
+        float* dst = dw + ((size_t)j * cin + ci) * 9 + t;
+        *dst = fmaf(tot, scale, accumulate ? *dst : 0.f);
+      }
+    }
+}
+
+// Weight gradient of a convolution whose OUTPUT is tiny (<= 32 positions per image: the similarity trunk's layers at 4^2 -
+// the 1x1 skip; the 3x3 layers there were tried and stay on the generic tile, see wgrad_entry).  OH * OW is not a multiple of 32 there, so the split-precision
+// K-slab loaders do not apply and the launches fell to the exact-fp32 generic tile: K = 256 pixels in all, 78 us for 1.2
+// GFLOP.  Here a block owns 32 output x 8 input channels and walks the samples: dy[n, 32 co, P] and x[n, 8 ci, H * W] are
+// staged in LDS - x in im2col form [ci][position][tap], gathered once per block and sample through a table of the (position,
+// tap) offsets - and a thread (co, ci) adds its KK taps from contiguous rows.  Exact fp32 products, samples and positions in
+// ascending order.
+constexpr int TS_CO = 32, TS_CI = 8, TS_MAXP = 32, TS_MAXHW = 256;
+template <int KS>
+__global__ __launch_bounds__(256) void wgrad_tiny_spatial_kernel(float* __restrict__ dw, const float* __restrict__ x,
+                                                                 const float* __restrict__ dy, int batch, int cin,
+                                                                 int cout, int h, int w, int oh, int ow, int stride,
+                                                                 int pad, float scale, int accumulate) {
+  constexpr int KK = KS * KS;
+  __shared__ float sdy[TS_CO][TS_MAXP + 1];
+  __shared__ float sxc[TS_CI][TS_MAXP * KK + 1];            // x of one sample in im2col form: [ci][position][tap]
+  __shared__ short sidx[TS_MAXP * KK];                      // x offset of (position, tap); -1 = padding
+  const int tid = threadIdx.x, co_l = tid & (TS_CO - 1), ci_l = tid >> 5;
+  const int co0 = blockIdx.x * TS_CO, ci0 = blockIdx.y * TS_CI;
+  const int P = oh * ow, hw = h * w, PK = P * KK;
+  for (int i = tid; i < PK; i += 256) {
+    const int p = i / KK, t = i - p * KK;
+    const int iy = (p / ow) * stride + t / KS - pad, ix = (p % ow) * stride + t % KS - pad;
+    sidx[i] = ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) ? (short)(iy * w + ix) : (short)-1;
+  }
+  float acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) acc[t] = 0.f;
+  for (int n = 0; n < batch; ++n) {
+    __syncthreads();                                        // (also publishes sidx before its first use)
+    for (int i = tid; i < TS_CO * P; i += 256) {
+      const int r = i / P, p = i - r * P;
+      sdy[r][p] = (co0 + r < cout) ? dy[((size_t)n * cout + co0 + r) * P + p] : 0.f;
+    }
+    for (int i = tid; i < TS_CI * PK; i += 256) {           // the gather happens once per block and sample, not per thread
+      const int r = i / PK, e = i - r * PK;
+      const int off = sidx[e];
+      sxc[r][e] = (off >= 0 && ci0 + r < cin) ? x[((size_t)n * cin + ci0 + r) * hw + off] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int p = 0; p < P; ++p) {
+      const float d = sdy[co_l][p];
+      const float* row = &sxc[ci_l][p * KK];
+#pragma unroll
+      for (int t = 0; t < KK; ++t) acc[t] = fmaf(d, row[t], acc[t]);
+    }
+  }
+  const int co = co0 + co_l, ci = ci0 + ci_l;
+  if (co < cout && ci < cin) {
+    float* dst = dw + ((size_t)co * cin + ci) * KK;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) dst[t] = fmaf(acc[t], scale, accumulate ? dst[t] : 0.f);
+  }
+}
+
 // out[i] (+)= scale * sum_b ws[b * count + i]: one wave per output element, lanes stride over the partials
 __global__ __launch_bounds__(256) void partial_sum_kernel(float* __restrict__ out, const float* __restrict__ ws,
                                                           int nblocks, int count, float scale, int accumulate) {
@@ -3842,6 +3944,36 @@ int wgrad_entry(float* dw, const float* x, const float* dy, int batch, int group
       partial_sum_kernel<<<(count + 3) / 4, 256, 0, st>>>(dw, workspace, nblocks, count, scale, accumulate ? 1 : 0);
       return gg::launch_status("partial_sum");
     }
+  }
+  static const bool no_tiny_wgrad = getenv("GG_NO_TINY_WGRAD") != nullptr;          // measurement switch
+  // (1x1 only: 62 -> 27 us on the 512 -> 512 skip at 4^2.  The 3x3 instantiation - 144 LDS-fed FMAs per thread and sample -
+  // measured 81 us against the generic tile's 78 on the two 3x3 layers at 4^2 and is not dispatched: GG_TINY_WGRAD3=1 tries it.)
+  static const bool tiny3 = getenv("GG_TINY_WGRAD3") != nullptr;
+  if (!no_tiny_wgrad && groups == 1 && !mask_ref && a.oh * a.ow <= TS_MAXP && h * w <= TS_MAXHW && (a.oh * a.ow) % BKS != 0 &&
+      (ksize == 1 || tiny3) && (cout_g + TS_CO - 1) / TS_CO <= 65535 && (cin_g + TS_CI - 1) / TS_CI <= 65535) {
+    // tiny outputs (4 x 4): the split-precision slab loaders do not apply; see wgrad_tiny_spatial_kernel
+    NOTE_KERNEL("wgrad_tiny_spatial<k%d>", ksize);
+    dim3 grid((unsigned)((cout_g + TS_CO - 1) / TS_CO), (unsigned)((cin_g + TS_CI - 1) / TS_CI));
+    if (ksize == 3)
+      wgrad_tiny_spatial_kernel<3><<<grid, 256, 0, st>>>(dw, x, dy, batch, cin_g, cout_g, h, w, a.oh, a.ow, stride, pad, scale,
+                                                         accumulate ? 1 : 0);
+    else
+      wgrad_tiny_spatial_kernel<1><<<grid, 256, 0, st>>>(dw, x, dy, batch, cin_g, cout_g, h, w, a.oh, a.ow, stride, pad, scale,
+                                                         accumulate ? 1 : 0);
+    return gg::launch_status("wgrad_tiny_spatial");
+  }
+  static const bool no_fewout_wgrad = getenv("GG_NO_FEWOUT_WGRAD") != nullptr;      // measurement switch
+  if (!no_fewout_wgrad && ksize == 3 && stride == 1 && pad == 1 && groups == 1 && cout_g <= 4 && !mask_ref && cin_g <= 65535 &&
+      (long long)batch * h * w < (1LL << 31)) {
+    // few-output-channel layer (the flow head's 512 -> 2): streaming reduction, exact fp32 in every precision mode
+    NOTE_KERNEL("wgrad3x3_fewout");
+    switch (cout_g) {
+      case 1: wgrad3x3_fewout_kernel<1><<<cin_g, 256, 0, st>>>(dw, x, dy, batch, cin_g, h, w, scale, accumulate ? 1 : 0); break;
+      case 2: wgrad3x3_fewout_kernel<2><<<cin_g, 256, 0, st>>>(dw, x, dy, batch, cin_g, h, w, scale, accumulate ? 1 : 0); break;
+      case 3: wgrad3x3_fewout_kernel<3><<<cin_g, 256, 0, st>>>(dw, x, dy, batch, cin_g, h, w, scale, accumulate ? 1 : 0); break;
+      default: wgrad3x3_fewout_kernel<4><<<cin_g, 256, 0, st>>>(dw, x, dy, batch, cin_g, h, w, scale, accumulate ? 1 : 0); break;
+    }
+    return gg::launch_status("wgrad3x3_fewout");
   }
   const bool strip16 = a.w == 16 && a.h % 2 == 0 && !mask_ref;            // 16-wide images: two rows per slab
   if (limbs && ksize == 3 && stride == 1 && pad == 1 && (a.w % 32 == 0 || strip16) &&

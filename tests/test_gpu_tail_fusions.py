@@ -428,3 +428,39 @@ def test_conv_act_blur_node_equals_the_three_separate_nodes(cm, precision, n, ci
     assert torch.equal(res_['node'][2], res_['separate'][2])
     db0, db1 = res_['separate'][3], res_['node'][3]
     assert float((db1 - db0).abs().max()) <= 2e-5 * float(db0.abs().max())
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+@pytest.mark.parametrize('n,cin,cout,res,k,stride,pad', [
+    (16, 512, 512, 4, 3, 1, 1),      # the similarity trunk's final 3x3 at 4^2
+    (16, 512, 512, 9, 3, 2, 0),      # ... its last down-sampling convolution: 9^2 -> 4^2
+    (16, 512, 512, 4, 1, 1, 0),      # ... and that block's 1x1 skip
+    (3, 40, 72, 5, 3, 1, 1),         # channel counts off the tile sizes, 25 positions
+    (2, 8, 33, 3, 1, 1, 0),
+    (16, 512, 2, 16, 3, 1, 1),       # the flow head's last layer (few output channels)
+    (5, 96, 3, 20, 3, 1, 1),
+    (4, 17, 1, 8, 3, 1, 1)])
+def test_small_layer_weight_gradients(cm, precision, n, cin, cout, res, k, stride, pad):
+    """Weight gradients of the layers the K-slab kernels do not serve - outputs of <= 32 positions per image
+    (wgrad_tiny_spatial_kernel) and <= 4 output channels (wgrad3x3_fewout_kernel): against float64, into a fresh tensor
+    and accumulating into a slot, and through the entry point the training path uses."""
+    from gangealing_amd import _lib
+    cm.set_precision(precision)
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(cin * 3 + res + k)
+    x = torch.randn(n, cin, res, res, device=dev)
+    oh = (res + 2 * pad - k) // stride + 1
+    dy = torch.randn(n, cout, oh, oh, device=dev)
+    base = torch.randn(cout, cin, k, k, device=dev)
+    fresh = cm.conv_wgrad(x, dy, n, 1, cin, cout, k, stride, pad, 0.37)
+    kernel = cm.last_conv_kernel()
+    into = base.clone()
+    cm.conv_wgrad(x, dy, n, 1, cin, cout, k, stride, pad, 0.37, into=into)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), dy.double(), stride=stride, padding=pad) * 0.37
+    scale = float(ref.abs().max())
+    assert float((fresh.double() - ref).abs().max()) <= 2e-6 * scale, kernel
+    assert float((into.double() - (base.double() + ref)).abs().max()) <= 2e-6 * (scale + float(base.abs().max())), kernel
+    if cout <= 4 and k == 3:
+        assert kernel == 'wgrad3x3_fewout', kernel
+    elif k == 1 and oh * oh <= 32 and (oh * oh) % 32:
+        assert kernel.startswith('wgrad_tiny_spatial'), kernel
