@@ -3260,12 +3260,18 @@ __global__ __launch_bounds__(256) void conv3x3_fewin_kernel(float* __restrict__ 
   }
 }
 
+// smallest batch * H * W the few-input-channel 3x3 kernel takes (GG_FEWIN3_MIN: measurement override; at 2048 it would also
+// take the data gradient of the flow head's last layer, 2 -> 512 @16^2: 13 us against the fp32 MFMA tile's 14, session 33)
+static long long fewin3_min_pixels() {
+  static const long long v = env_int("GG_FEWIN3_MIN", 65536);
+  return v;
+}
 bool fewin3_serves(const ConvArgs& a, int stride, int pad, int mode) {
   static const bool off = getenv("GG_NO_FEWIN3") != nullptr;      // measurement switch
   const long long hw = (long long)a.h * a.w;
   return !off && mode == 0 && stride == 1 && pad == 1 && a.groups == 1 && a.cin_g >= 1 && a.cin_g <= 4 && a.cout_g >= 16 &&
          a.wmat && !a.in_scale && !a.out_scale && !a.mask_ref && !a.mask_bits && !(a.act && a.act_noise) &&
-         a.w % 4 == 0 && (long long)a.batch * hw >= 65536 && a.batch <= 65535 &&
+         a.w % 4 == 0 && (long long)a.batch * hw >= fewin3_min_pixels() && a.batch <= 65535 &&
          (a.cout_g + FEWIN3_CO - 1) / FEWIN3_CO <= 65535 && (!a.sign_bits || a.cout_g % 32 == 0) &&
          (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
 }
